@@ -1,0 +1,253 @@
+"""
+ctypes binding of libglimship.so (the only compute backend; there is no CPU fallback).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C glimslib_amd/csrc``.
+Signatures mirror ``include/glims_hip.h`` one to one.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libglimship.so")
+
+GLIMS_OK, GLIMS_NOT_CONVERGED, GLIMS_NAN = 0, 1, 2
+GLIMS_E_USAGE, GLIMS_E_HIP, GLIMS_E_RCCL, GLIMS_E_NO_DEVICE = -1, -2, -3, -4
+GLIMS_UNIQUE_ID_BYTES = 256
+FLAG_EXTRAPOLATE_GUESS = 1
+
+
+class BackendError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libglimship: %s (status %d)" % (msg, code))
+        self.code = code
+
+
+class Options(C.Structure):
+    _fields_ = [("dt", C.c_double), ("newton_rtol", C.c_double), ("newton_atol", C.c_double),
+                ("newton_maxit", C.c_int), ("cg_rtol", C.c_double), ("cg_atol", C.c_double),
+                ("cg_maxit", C.c_int), ("mech_rtol", C.c_double), ("mech_atol", C.c_double),
+                ("mech_maxit", C.c_int), ("check_every", C.c_int), ("flags", C.c_int)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("steps", C.c_int64), ("newton_its", C.c_int64), ("rd_assemblies", C.c_int64),
+                ("cg_its", C.c_int64), ("mech_solves", C.c_int64), ("mech_cg_its", C.c_int64),
+                ("last_newton_res", C.c_double), ("last_cg_res", C.c_double), ("last_mech_res", C.c_double),
+                ("ms_steps", C.c_double), ("ms_spmv", C.c_double), ("n_rows", C.c_int64), ("nnz", C.c_int64),
+                ("nnz_padded", C.c_int64), ("n_corners", C.c_int64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_dp = C.POINTER(C.c_double)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_h = C.c_void_p
+
+# name -> (restype, argtypes); every symbol declared in include/glims_hip.h
+SIGNATURES = {
+    "glims_abi_version": (C.c_int, []),
+    "glims_create": (C.c_int, [C.POINTER(_h), C.c_int, C.c_int64, C.c_int64, C.c_int64, _dp, _i32p, _i32p, C.c_int]),
+    "glims_destroy": (C.c_int, [_h]),
+    "glims_last_error": (C.c_char_p, [_h]),
+    "glims_set_materials": (C.c_int, [_h, C.c_int, _dp, _dp, _dp, _dp, _dp]),
+    "glims_options_default": (C.c_int, [C.POINTER(Options)]),
+    "glims_set_options": (C.c_int, [_h, C.POINTER(Options)]),
+    "glims_set_dirichlet_u": (C.c_int, [_h, C.c_int64, _i64p, _dp]),
+    "glims_set_dirichlet_c": (C.c_int, [_h, C.c_int64, _i64p, _dp]),
+    "glims_set_rd_load": (C.c_int, [_h, _dp]),
+    "glims_set_mech_load": (C.c_int, [_h, _dp]),
+    "glims_setup": (C.c_int, [_h, C.c_int]),
+    "glims_set_state": (C.c_int, [_h, _dp, _dp]),
+    "glims_get_state": (C.c_int, [_h, _dp, _dp]),
+    "glims_step": (C.c_int, [_h, C.c_int]),
+    "glims_solve_mechanics": (C.c_int, [_h]),
+    "glims_get_stats": (C.c_int, [_h, C.POINTER(Stats)]),
+    "glims_reset_stats": (C.c_int, [_h]),
+    "glims_apply": (C.c_int, [_h, C.c_int, _dp, _dp, C.c_int, _dp]),
+    "glims_rd_residual": (C.c_int, [_h, _dp, _dp, _dp]),
+    "glims_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "glims_comm_init": (C.c_int, [_h, C.c_int, C.c_int, C.c_char_p]),
+    "glims_set_halo": (C.c_int, [_h, C.c_int, _i32p, _i64p, _i32p, _i64p]),
+}
+
+_lib = None
+
+
+def load_library():
+    """Load libglimship.so or fail loudly -- there is no alternative compute path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "glimslib_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C glimslib_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        assert a.shape == shape, (a.shape, shape)
+    return a
+
+
+def _ptr(a, typ):
+    return a.ctypes.data_as(typ) if a is not None else None
+
+
+class Handle:
+    """Thin OO view of one ``glims_ctx`` (one mesh on one GPU)."""
+
+    def __init__(self, points, cells, cell_label, n_own=None, device=0):
+        lib = load_library()
+        self.lib = lib
+        pts = _f64(points)
+        cl = np.ascontiguousarray(cells, dtype=np.int32)
+        lab = np.ascontiguousarray(cell_label, dtype=np.int32)
+        self.dim = pts.shape[1]
+        self.n_nodes = pts.shape[0]
+        self.n_own = self.n_nodes if n_own is None else int(n_own)
+        self.n_cells = cl.shape[0]
+        assert cl.shape[1] == self.dim + 1 and lab.shape == (self.n_cells,)
+        h = _h()
+        st = lib.glims_create(C.byref(h), self.dim, self.n_nodes, self.n_own, self.n_cells,
+                              _ptr(pts, _dp), _ptr(cl, _i32p), _ptr(lab, _i32p), int(device))
+        if st != GLIMS_OK:
+            raise BackendError(st, (lib.glims_last_error(None) or b"").decode())
+        self._h = h
+        self.options = Options()
+        lib.glims_options_default(C.byref(self.options))
+
+    # -- plumbing --------------------------------------------------------------------------------
+    def _check(self, st, allow=()):
+        if st != GLIMS_OK and st not in allow:
+            raise BackendError(st, (self.lib.glims_last_error(self._h) or b"").decode())
+        return st
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.glims_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- model data ------------------------------------------------------------------------------
+    def set_materials(self, D, rho, gamma, E, nu):
+        arrs = [_f64(a) for a in (D, rho, gamma, E, nu)]
+        n = len(arrs[0])
+        assert all(a.shape == (n,) for a in arrs)
+        self._check(self.lib.glims_set_materials(self._h, n, *[_ptr(a, _dp) for a in arrs]))
+
+    def set_options(self, **kw):
+        for k, v in kw.items():
+            if not hasattr(self.options, k):
+                raise KeyError(k)
+            setattr(self.options, k, v)
+        self._check(self.lib.glims_set_options(self._h, C.byref(self.options)))
+
+    def set_dirichlet_u(self, dofs, values):
+        dofs = np.ascontiguousarray(dofs, dtype=np.int64)
+        values = _f64(np.broadcast_to(values, dofs.shape))
+        self._check(self.lib.glims_set_dirichlet_u(self._h, len(dofs), _ptr(dofs, _i64p), _ptr(values, _dp)))
+
+    def set_dirichlet_c(self, nodes, values):
+        nodes = np.ascontiguousarray(nodes, dtype=np.int64)
+        values = _f64(np.broadcast_to(values, nodes.shape))
+        self._check(self.lib.glims_set_dirichlet_c(self._h, len(nodes), _ptr(nodes, _i64p), _ptr(values, _dp)))
+
+    def set_rd_load(self, f):
+        f = None if f is None else _f64(f, (self.n_nodes,))
+        self._check(self.lib.glims_set_rd_load(self._h, _ptr(f, _dp)))
+
+    def set_mech_load(self, f):
+        f = None if f is None else _f64(np.asarray(f).reshape(-1), (self.n_nodes * self.dim,))
+        self._check(self.lib.glims_set_mech_load(self._h, _ptr(f, _dp)))
+
+    def setup(self, with_mechanics=True):
+        self._check(self.lib.glims_setup(self._h, 1 if with_mechanics else 0))
+
+    # -- state -----------------------------------------------------------------------------------
+    def set_state(self, c, u=None):
+        c = _f64(c, (self.n_nodes,))
+        u = None if u is None else _f64(np.asarray(u).reshape(-1), (self.n_nodes * self.dim,))
+        self._check(self.lib.glims_set_state(self._h, _ptr(c, _dp), _ptr(u, _dp)))
+
+    def get_state(self, want_u=True):
+        c = np.empty(self.n_nodes)
+        u = np.empty(self.n_nodes * self.dim) if want_u else None
+        self._check(self.lib.glims_get_state(self._h, _ptr(c, _dp), _ptr(u, _dp)))
+        return c, u
+
+    def step(self, n_steps=1):
+        """Returns the status (GLIMS_OK / GLIMS_NOT_CONVERGED / GLIMS_NAN); raises on usage/HIP/RCCL errors."""
+        return self._check(self.lib.glims_step(self._h, int(n_steps)), allow=(GLIMS_NOT_CONVERGED, GLIMS_NAN))
+
+    def solve_mechanics(self):
+        return self._check(self.lib.glims_solve_mechanics(self._h), allow=(GLIMS_NOT_CONVERGED, GLIMS_NAN))
+
+    def stats(self):
+        s = Stats()
+        self._check(self.lib.glims_get_stats(self._h, C.byref(s)))
+        return s.as_dict()
+
+    def reset_stats(self):
+        self._check(self.lib.glims_reset_stats(self._h))
+
+    # -- operator hooks --------------------------------------------------------------------------
+    def apply(self, which, x, reps=1):
+        """which: 0 A(c), 1 S, 2 M, 3 K_el, 4 G.  Returns (y, ms_total)."""
+        d = self.dim
+        nin = self.n_nodes * (d if which == 3 else 1)
+        nout = self.n_nodes * (d if which in (3, 4) else 1)
+        x = _f64(np.asarray(x).reshape(-1), (nin,))
+        y = np.empty(nout)
+        ms = C.c_double(0.0)
+        self._check(self.lib.glims_apply(self._h, int(which), _ptr(x, _dp), _ptr(y, _dp), int(reps), C.byref(ms)))
+        return y, ms.value
+
+    def rd_residual(self, c, c_prev):
+        c = _f64(c, (self.n_nodes,))
+        cp = _f64(c_prev, (self.n_nodes,))
+        R = np.empty(self.n_nodes)
+        self._check(self.lib.glims_rd_residual(self._h, _ptr(c, _dp), _ptr(cp, _dp), _ptr(R, _dp)))
+        return R
+
+    # -- multi-GPU -------------------------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        lib = load_library()
+        buf = C.create_string_buffer(GLIMS_UNIQUE_ID_BYTES)
+        st = lib.glims_comm_unique_id(buf)
+        if st != GLIMS_OK:
+            raise BackendError(st, "ncclGetUniqueId failed")
+        return buf.raw
+
+    def comm_init(self, rank, world, uid):
+        assert len(uid) == GLIMS_UNIQUE_ID_BYTES
+        self._check(self.lib.glims_comm_init(self._h, int(rank), int(world), uid))
+
+    def set_halo(self, peer_rank, send_ptr, send_idx, recv_count):
+        pr = np.ascontiguousarray(peer_rank, dtype=np.int32)
+        sp = np.ascontiguousarray(send_ptr, dtype=np.int64)
+        si = np.ascontiguousarray(send_idx, dtype=np.int32)
+        rc = np.ascontiguousarray(recv_count, dtype=np.int64)
+        assert len(sp) == len(pr) + 1 and len(rc) == len(pr)
+        self._check(self.lib.glims_set_halo(self._h, len(pr), _ptr(pr, _i32p), _ptr(sp, _i64p), _ptr(si, _i32p),
+                                            _ptr(rc, _i64p)))

@@ -1,0 +1,534 @@
+// extern "C" surface of libglimship.so (see include/glims_hip.h for the contract of every entry point).
+#include "glims_internal.h"
+
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* slice_list, const double* vals,
+                    const double* x, double* y, const uint8_t* fixed, const double* addv, const double* r,
+                    double* partials, int partial_off, const int* done);
+
+namespace {
+
+std::mutex g_err_mu;
+std::string g_create_err;
+
+// internal[new] <- staged[old]   /   staged[old] <- internal[new]
+__global__ void k_perm_in(int64_t n, int bs, const int32_t* __restrict__ old2new, const double* __restrict__ ext,
+                          double* __restrict__ in) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * bs) return;
+  const int64_t o = i / bs;
+  const int a = (int)(i - o * bs);
+  in[(int64_t)old2new[o] * bs + a] = ext[i];
+}
+__global__ void k_perm_out(int64_t n, int64_t n_valid_new, int bs, const int32_t* __restrict__ old2new,
+                           const double* __restrict__ in, double* __restrict__ ext) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * bs) return;
+  const int64_t o = i / bs;
+  const int a = (int)(i - o * bs);
+  const int64_t nw = old2new[o];
+  ext[i] = nw < n_valid_new ? in[nw * bs + a] : 0.0;
+}
+
+inline unsigned grid_exact(int64_t n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
+
+void to_device_perm(glims_ctx* h, const double* host, double* dst, int bs) {
+  const int64_t n = h->n_nodes;
+  GL_HIP(hipMemcpyAsync(h->stage.p, host, (size_t)n * bs * sizeof(double), hipMemcpyHostToDevice, h->st));
+  hipLaunchKernelGGL(k_perm_in, dim3(grid_exact(n * bs)), dim3(256), 0, h->st, n, bs, h->d_old2new.p, h->stage.p,
+                     dst);
+  GL_HIP(hipGetLastError());
+  GL_HIP(hipStreamSynchronize(h->st));
+}
+void from_device_perm(glims_ctx* h, const double* src, double* host, int bs, int64_t n_valid_new) {
+  const int64_t n = h->n_nodes;
+  hipLaunchKernelGGL(k_perm_out, dim3(grid_exact(n * bs)), dim3(256), 0, h->st, n, n_valid_new, bs,
+                     h->d_old2new.p, src, h->stage.p);
+  GL_HIP(hipGetLastError());
+  GL_HIP(hipMemcpyAsync(host, h->stage.p, (size_t)n * bs * sizeof(double), hipMemcpyDeviceToHost, h->st));
+  GL_HIP(hipStreamSynchronize(h->st));
+}
+
+template <class F>
+int guarded(glims_ctx* h, F&& f) {
+  if (!h) return GLIMS_E_USAGE;
+  try {
+    if (hipSetDevice(h->device) != hipSuccess) throw glims_error(GLIMS_E_HIP, "hipSetDevice failed");
+    return f();
+  } catch (const glims_error& e) {
+    h->err = e.what();
+    return e.code;
+  } catch (const std::exception& e) {
+    h->err = e.what();
+    return GLIMS_E_USAGE;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int glims_abi_version(void) { return GLIMS_ABI_VERSION; }
+
+int glims_options_default(glims_options* o) {
+  if (!o) return GLIMS_E_USAGE;
+  o->dt = 1.0;
+  o->newton_rtol = 1e-10;
+  o->newton_atol = 1e-13;
+  o->newton_maxit = 50;
+  o->cg_rtol = 1e-6;
+  o->cg_atol = 0.0;
+  o->cg_maxit = 5000;
+  o->mech_rtol = 1e-10;
+  o->mech_atol = 0.0;
+  o->mech_maxit = 200000;
+  o->check_every = 8;
+  o->flags = 0;
+  return GLIMS_OK;
+}
+
+const char* glims_last_error(const glims_ctx* h) {
+  if (h) return h->err.c_str();
+  std::lock_guard<std::mutex> lk(g_err_mu);
+  static thread_local std::string copy;
+  copy = g_create_err;
+  return copy.c_str();
+}
+
+int glims_create(glims_ctx** out, int dim, int64_t n_nodes, int64_t n_own, int64_t n_cells, const double* xyz,
+                 const int32_t* cells, const int32_t* cell_label, int device) {
+  if (!out) return GLIMS_E_USAGE;
+  *out = nullptr;
+  glims_ctx* h = nullptr;
+  try {
+    GL_REQUIRE(xyz && cells && cell_label, "null mesh arrays");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+      throw glims_error(GLIMS_E_NO_DEVICE,
+                        "no HIP device visible: libglimship has no CPU fallback (gfx950 / MI355X required)");
+    GL_REQUIRE(device >= 0 && device < ndev, "device ordinal out of range");
+    GL_HIP(hipSetDevice(device));
+    h = new glims_ctx();
+    h->device = device;
+    h->dim = dim;
+    h->nv = dim + 1;
+    h->n_nodes = n_nodes;
+    h->n_own = n_own;
+    h->n_cells = n_cells;
+    glims_options_default(&h->opt);
+    std::memset(&h->stats, 0, sizeof(h->stats));
+    GL_HIP(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
+    GL_HIP(hipStreamCreateWithFlags(&h->st_comm, hipStreamNonBlocking));
+    GL_HIP(hipEventCreate(&h->ev_a));
+    GL_HIP(hipEventCreate(&h->ev_b));
+    GL_HIP(hipEventCreateWithFlags(&h->ev_pack, hipEventDisableTiming));
+    GL_HIP(hipEventCreateWithFlags(&h->ev_halo, hipEventDisableTiming));
+    GL_HIP(hipHostMalloc((void**)&h->h_pinned, 32 * sizeof(double)));
+
+    for (int64_t e = 0; e < n_cells; ++e)
+      GL_REQUIRE(cell_label[e] >= 0 && cell_label[e] < GL_MAX_LABELS, "cell label outside [0, 256)");
+
+    HostPattern hp;
+    build_host_pattern(hp, dim, n_nodes, n_own, n_cells, xyz, cells);
+    h->old2new = hp.old2new;
+    h->new2old = hp.new2old;
+    h->nnz = hp.nnz;
+    h->n_corners = hp.n_corners;
+
+    DevPattern& p = h->pat;
+    p.n_slices = hp.n_slices;
+    p.max_len = hp.max_len;
+    p.max_clen = hp.max_clen;
+    p.total_entries = hp.slice_ptr[hp.n_slices];
+    p.total_corners = hp.cslice_ptr[hp.n_slices];
+    p.slice_ptr.upload(hp.slice_ptr, h->st);
+    p.cols.upload(hp.cols, h->st);
+    p.diag_k.upload(hp.diag_k, h->st);
+    p.cslice_ptr.upload(hp.cslice_ptr, h->st);
+    p.cslots.upload(hp.cslots, h->st);
+    p.celem.upload(hp.celem, h->st);
+    p.interior_slices.upload(hp.interior_slices, h->st);
+    p.boundary_slices.upload(hp.boundary_slices, h->st);
+    p.n_interior = (int32_t)hp.interior_slices.size();
+    p.n_boundary = (int32_t)hp.boundary_slices.size();
+    h->d_old2new.upload(hp.old2new, h->st);
+
+    std::vector<uint8_t> lab(n_cells);
+    for (int64_t e = 0; e < n_cells; ++e) lab[e] = (uint8_t)cell_label[e];
+    h->label.upload(lab, h->st);
+
+    {   // per-cell geometry from the caller's numbering; coordinates and connectivity are not kept on the device
+      dvec<double> d_xyz;
+      dvec<int32_t> d_cells;
+      d_xyz.upload(xyz, (size_t)n_nodes * dim, h->st);
+      d_cells.upload(cells, (size_t)n_cells * (dim + 1), h->st);
+      gl_compute_egeo(h, d_xyz.p, d_cells.p);
+      GL_HIP(hipStreamSynchronize(h->st));
+    }
+
+    const size_t nn = (size_t)n_nodes, nd = (size_t)n_nodes * dim;
+    h->c.alloc_zero(nn, h->st);
+    h->c_old.alloc_zero(nn, h->st);
+    h->b.alloc_zero(nn, h->st);
+    h->dinv.alloc_zero(nn, h->st);
+    h->cg_p.alloc_zero(nn, h->st);
+    h->cg_s.alloc_zero(nn, h->st);
+    h->cg_u.alloc_zero(nn, h->st);
+    h->cg_w.alloc_zero(nn, h->st);
+    h->cg_r.alloc_zero(nn, h->st);
+    h->stage.alloc_zero(nd, h->st);
+    h->mat.alloc_zero(5 * GL_MAX_LABELS, h->st);
+    h->partials.alloc_zero((size_t)p.n_slices * 3 + 4096, h->st);
+    h->red.alloc_zero(4, h->st);
+    h->scal.alloc_zero(SC_COUNT, h->st);
+    h->done.alloc_zero(1, h->st);
+    GL_HIP(hipStreamSynchronize(h->st));
+
+    h->stats.n_rows = n_own;
+    h->stats.nnz = hp.nnz;
+    h->stats.nnz_padded = p.total_entries;
+    h->stats.n_corners = hp.n_corners;
+    *out = h;
+    return GLIMS_OK;
+  } catch (const glims_error& e) {
+    {
+      std::lock_guard<std::mutex> lk(g_err_mu);
+      g_create_err = e.what();
+    }
+    if (h) glims_destroy(h);
+    return e.code;
+  } catch (const std::exception& e) {
+    {
+      std::lock_guard<std::mutex> lk(g_err_mu);
+      g_create_err = e.what();
+    }
+    if (h) glims_destroy(h);
+    return GLIMS_E_USAGE;
+  }
+}
+
+int glims_destroy(glims_ctx* h) {
+  if (!h) return GLIMS_OK;
+  (void)hipSetDevice(h->device);
+  if (h->st) (void)hipStreamSynchronize(h->st);
+  if (h->st_comm) (void)hipStreamSynchronize(h->st_comm);
+  gl_comm_destroy(h);
+  if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+  if (h->ev_a) (void)hipEventDestroy(h->ev_a);
+  if (h->ev_b) (void)hipEventDestroy(h->ev_b);
+  if (h->ev_pack) (void)hipEventDestroy(h->ev_pack);
+  if (h->ev_halo) (void)hipEventDestroy(h->ev_halo);
+  if (h->st) (void)hipStreamDestroy(h->st);
+  if (h->st_comm) (void)hipStreamDestroy(h->st_comm);
+  delete h;   // dvec destructors release device memory
+  return GLIMS_OK;
+}
+
+int glims_set_materials(glims_ctx* h, int n_labels, const double* D, const double* rho, const double* gamma,
+                        const double* E, const double* nu) {
+  return guarded(h, [&]() {
+    GL_REQUIRE(n_labels > 0 && n_labels <= GL_MAX_LABELS, "n_labels out of range");
+    GL_REQUIRE(D && rho && gamma && E && nu, "null material table");
+    std::vector<double> m(5 * GL_MAX_LABELS, 0.0);
+    for (int l = 0; l < n_labels; ++l) {
+      GL_REQUIRE(std::isfinite(D[l]) && std::isfinite(rho[l]) && std::isfinite(gamma[l]) && std::isfinite(E[l]) &&
+                     std::isfinite(nu[l]),
+                 "non-finite material value");
+      m[0 * GL_MAX_LABELS + l] = D[l];
+      m[1 * GL_MAX_LABELS + l] = rho[l];
+      m[2 * GL_MAX_LABELS + l] = gamma[l];
+      // math_linear_elasticity.py:6-10
+      m[3 * GL_MAX_LABELS + l] = E[l] / (2.0 * (1.0 + nu[l]));
+      m[4 * GL_MAX_LABELS + l] = E[l] * nu[l] / ((1.0 + nu[l]) * (1.0 - 2.0 * nu[l]));
+    }
+    h->mat.upload(m, h->st);
+    GL_HIP(hipStreamSynchronize(h->st));
+    h->have_materials = true;
+    h->is_setup = false;
+    return GLIMS_OK;
+  });
+}
+
+int glims_set_options(glims_ctx* h, const glims_options* opt) {
+  return guarded(h, [&]() {
+    GL_REQUIRE(opt, "null options");
+    GL_REQUIRE(opt->dt > 0.0 && std::isfinite(opt->dt), "dt must be positive");
+    GL_REQUIRE(opt->newton_maxit >= 0 && opt->cg_maxit > 0 && opt->mech_maxit > 0, "bad iteration caps");
+    if (opt->dt != h->opt.dt) h->is_setup = false;
+    h->opt = *opt;
+    return GLIMS_OK;
+  });
+}
+
+int glims_set_dirichlet_c(glims_ctx* h, int64_t n, const int64_t* node_ids, const double* values) {
+  return guarded(h, [&]() {
+    if (n <= 0) {
+      h->have_fixed_c = false;
+      return GLIMS_OK;
+    }
+    GL_REQUIRE(node_ids && values, "null Dirichlet arrays");
+    std::vector<uint8_t> fx(h->n_nodes, 0);
+    std::vector<double> val(h->n_nodes, 0.0);
+    for (int64_t k = 0; k < n; ++k) {
+      GL_REQUIRE(node_ids[k] >= 0 && node_ids[k] < h->n_nodes, "Dirichlet node out of range");
+      const int32_t nw = h->old2new[node_ids[k]];
+      fx[nw] = 1;
+      val[nw] = values[k];
+    }
+    h->fixed_c.upload(fx, h->st);
+    h->cD.upload(val, h->st);
+    GL_HIP(hipStreamSynchronize(h->st));
+    h->have_fixed_c = true;
+    return GLIMS_OK;
+  });
+}
+
+int glims_set_dirichlet_u(glims_ctx* h, int64_t n, const int64_t* dof_ids, const double* values) {
+  return guarded(h, [&]() {
+    if (n <= 0) {
+      h->have_fixed_u = false;
+      return GLIMS_OK;
+    }
+    GL_REQUIRE(dof_ids && values, "null Dirichlet arrays");
+    const int d = h->dim;
+    std::vector<uint8_t> fx((size_t)h->n_nodes * d, 0);
+    std::vector<double> val((size_t)h->n_nodes * d, 0.0);
+    for (int64_t k = 0; k < n; ++k) {
+      GL_REQUIRE(dof_ids[k] >= 0 && dof_ids[k] < h->n_nodes * d, "Dirichlet dof out of range");
+      const int64_t node = dof_ids[k] / d;
+      const int a = (int)(dof_ids[k] % d);
+      const int64_t j = (int64_t)h->old2new[node] * d + a;
+      fx[j] = 1;
+      val[j] = values[k];
+    }
+    h->fixed_u.upload(fx, h->st);
+    h->m_uD.upload(val, h->st);
+    GL_HIP(hipStreamSynchronize(h->st));
+    h->have_fixed_u = true;
+    return GLIMS_OK;
+  });
+}
+
+int glims_set_rd_load(glims_ctx* h, const double* f) {
+  return guarded(h, [&]() {
+    if (!f) {
+      h->have_load_rd = false;
+      return GLIMS_OK;
+    }
+    h->load_rd.alloc((size_t)h->n_nodes);
+    to_device_perm(h, f, h->load_rd.p, 1);
+    h->have_load_rd = true;
+    return GLIMS_OK;
+  });
+}
+
+int glims_set_mech_load(glims_ctx* h, const double* f) {
+  return guarded(h, [&]() {
+    if (!f) {
+      h->have_mload = false;
+      return GLIMS_OK;
+    }
+    h->mload.alloc((size_t)h->n_nodes * h->dim);
+    to_device_perm(h, f, h->mload.p, h->dim);
+    h->have_mload = true;
+    return GLIMS_OK;
+  });
+}
+
+int glims_setup(glims_ctx* h, int with_mechanics) {
+  return guarded(h, [&]() {
+    GL_REQUIRE(h->have_materials, "glims_setup before glims_set_materials");
+    if (with_mechanics) {
+      const size_t nd = (size_t)h->n_nodes * h->dim;
+      if (!h->U.p) {
+        h->U.alloc_zero(nd, h->st);
+        h->m_rhs.alloc_zero(nd, h->st);
+        h->m_p.alloc_zero(nd, h->st);
+        h->m_s.alloc_zero(nd, h->st);
+        h->m_u.alloc_zero(nd, h->st);
+        h->m_w.alloc_zero(nd, h->st);
+        h->m_r.alloc_zero(nd, h->st);
+        h->m_dinv.alloc_zero((size_t)h->n_nodes * h->dim * h->dim, h->st);
+      }
+      if (!h->m_uD.p) h->m_uD.alloc_zero(nd, h->st);
+    }
+    gl_assemble_static(h, with_mechanics);
+    GL_HIP(hipStreamSynchronize(h->st));
+    h->is_setup = true;
+    h->have_mech = with_mechanics != 0;
+    return GLIMS_OK;
+  });
+}
+
+int glims_set_state(glims_ctx* h, const double* c, const double* u) {
+  return guarded(h, [&]() {
+    GL_REQUIRE(c, "null concentration");
+    to_device_perm(h, c, h->c.p, 1);
+    if (h->U.p) {
+      if (u)
+        to_device_perm(h, u, h->U.p, h->dim);
+      else
+        GL_HIP(hipMemsetAsync(h->U.p, 0, (size_t)h->n_nodes * h->dim * sizeof(double), h->st));
+    }
+    GL_HIP(hipStreamSynchronize(h->st));
+    h->have_state = true;
+    h->stats.steps = 0;
+    return GLIMS_OK;
+  });
+}
+
+int glims_get_state(glims_ctx* h, double* c, double* u) {
+  return guarded(h, [&]() {
+    GL_REQUIRE(h->have_state, "glims_get_state before glims_set_state");
+    if (c) from_device_perm(h, h->c.p, c, 1, h->n_nodes);
+    if (u) {
+      GL_REQUIRE(h->U.p, "no displacement field: glims_setup(with_mechanics=1) first");
+      from_device_perm(h, h->U.p, u, h->dim, h->n_nodes);
+    }
+    return GLIMS_OK;
+  });
+}
+
+int glims_step(glims_ctx* h, int n_steps) {
+  return guarded(h, [&]() { return gl_step(h, n_steps); });
+}
+
+int glims_solve_mechanics(glims_ctx* h) {
+  return guarded(h, [&]() { return gl_solve_mechanics(h); });
+}
+
+int glims_get_stats(const glims_ctx* h, glims_stats* st) {
+  if (!h || !st) return GLIMS_E_USAGE;
+  *st = h->stats;
+  return GLIMS_OK;
+}
+
+int glims_reset_stats(glims_ctx* h) {
+  if (!h) return GLIMS_E_USAGE;
+  glims_stats keep = h->stats;
+  std::memset(&h->stats, 0, sizeof(h->stats));
+  h->stats.n_rows = keep.n_rows;
+  h->stats.nnz = keep.nnz;
+  h->stats.nnz_padded = keep.nnz_padded;
+  h->stats.n_corners = keep.n_corners;
+  h->stats.steps = keep.steps;   // step counter drives the extrapolated guess; keep it
+  return GLIMS_OK;
+}
+
+int glims_apply(glims_ctx* h, int which, const double* x, double* y, int reps, double* ms_total) {
+  return guarded(h, [&]() {
+    GL_REQUIRE(h->is_setup, "glims_apply before glims_setup");
+    GL_REQUIRE(x && y && reps >= 1, "bad arguments");
+    GL_REQUIRE(which >= 0 && which <= 4, "unknown operator");
+    const int d = h->dim;
+    const bool blk_in = which == 3, blk_out = which == 3 || which == 4;
+    if (blk_out) GL_REQUIRE(h->have_mech, "mechanics operators not assembled");
+    dvec<double> xin, yout;
+    xin.alloc_zero((size_t)h->n_nodes * (blk_in ? d : 1), h->st);
+    yout.alloc_zero((size_t)h->n_nodes * (blk_out ? d : 1), h->st);
+    to_device_perm(h, x, xin.p, blk_in ? d : 1);
+    const bool saved_mload = h->have_mload;
+    h->have_mload = false;
+    GL_HIP(hipEventRecord(h->ev_a, h->st));
+    for (int r = 0; r < reps; ++r) {
+      if (which <= 2)
+        gl_spmv_scalar(h, which == 0 ? h->vA.p : which == 1 ? h->vS.p : h->vM.p, xin.p, yout.p, false);
+      else if (which == 3)
+        gl_spmv_block(h, xin.p, yout.p, false);
+      else
+        gl_apply_G(h, xin.p, yout.p);
+    }
+    GL_HIP(hipEventRecord(h->ev_b, h->st));
+    GL_HIP(hipEventSynchronize(h->ev_b));
+    h->have_mload = saved_mload;
+    float ms = 0.f;
+    GL_HIP(hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
+    if (ms_total) *ms_total = ms;
+    h->stats.ms_spmv += ms;
+    from_device_perm(h, yout.p, y, blk_out ? d : 1, h->n_own);
+    return GLIMS_OK;
+  });
+}
+
+int glims_rd_residual(glims_ctx* h, const double* c, const double* c_prev, double* R) {
+  return guarded(h, [&]() {
+    GL_REQUIRE(h->is_setup, "glims_rd_residual before glims_setup");
+    GL_REQUIRE(c && c_prev, "null vectors");
+    dvec<double> dc, dcp;
+    dc.alloc_zero((size_t)h->n_nodes, h->st);
+    dcp.alloc_zero((size_t)h->n_nodes, h->st);
+    to_device_perm(h, c, dc.p, 1);
+    to_device_perm(h, c_prev, dcp.p, 1);
+    gl_launch_spmv(h, h->st, h->pat.n_slices, nullptr, h->vM.p, dcp.p, h->b.p, nullptr,
+                   h->have_load_rd ? h->load_rd.p : nullptr, nullptr, nullptr, 0, nullptr);
+    gl_rd_assemble(h, dc.p, h->b.p, h->cg_r.p, h->partials.p);
+    GL_HIP(hipStreamSynchronize(h->st));
+    if (R) {
+      from_device_perm(h, h->cg_r.p, R, 1, h->n_own);
+      for (int64_t i = 0; i < h->n_nodes; ++i) R[i] = -R[i];   // the kernel stores -R (the Newton right-hand side)
+    }
+    return GLIMS_OK;
+  });
+}
+
+int glims_comm_unique_id(char id[GLIMS_UNIQUE_ID_BYTES]) {
+  static_assert(GLIMS_UNIQUE_ID_BYTES >= 2 * sizeof(ncclUniqueId), "unique id buffer too small");
+  if (!id) return GLIMS_E_USAGE;
+  ncclUniqueId a, b;
+  if (ncclGetUniqueId(&a) != ncclSuccess || ncclGetUniqueId(&b) != ncclSuccess) return GLIMS_E_RCCL;
+  std::memset(id, 0, GLIMS_UNIQUE_ID_BYTES);
+  std::memcpy(id, &a, sizeof(a));
+  std::memcpy(id + sizeof(a), &b, sizeof(b));
+  return GLIMS_OK;
+}
+
+int glims_comm_init(glims_ctx* h, int rank, int world, const char id[GLIMS_UNIQUE_ID_BYTES]) {
+  return guarded(h, [&]() {
+    GL_REQUIRE(world >= 1 && rank >= 0 && rank < world && id, "bad communicator arguments");
+    gl_comm_destroy(h);
+    h->rank = rank;
+    h->world = world;
+    if (world > 1) {
+      ncclUniqueId a, b;
+      std::memcpy(&a, id, sizeof(a));
+      std::memcpy(&b, id + sizeof(a), sizeof(b));
+      // two communicators: halo send/recv run on the communication stream, the scalar all-reduce on the compute
+      // stream; a communicator must not be driven from two streams at once
+      GL_NCCL(ncclCommInitRank(&h->comm_halo, world, a, rank));
+      GL_NCCL(ncclCommInitRank(&h->comm_red, world, b, rank));
+    }
+    return GLIMS_OK;
+  });
+}
+
+int glims_set_halo(glims_ctx* h, int n_peers, const int32_t* peer_rank, const int64_t* send_ptr,
+                   const int32_t* send_idx, const int64_t* recv_count) {
+  return guarded(h, [&]() {
+    GL_REQUIRE(n_peers >= 0, "negative peer count");
+    h->n_peers = n_peers;
+    h->peer_rank.assign(peer_rank, peer_rank + n_peers);
+    h->send_ptr.assign(send_ptr, send_ptr + n_peers + 1);
+    h->recv_ptr.assign(n_peers + 1, 0);
+    for (int p = 0; p < n_peers; ++p) {
+      GL_REQUIRE(peer_rank[p] >= 0 && peer_rank[p] < h->world && peer_rank[p] != h->rank, "bad peer rank");
+      GL_REQUIRE(recv_count[p] >= 0 && send_ptr[p + 1] >= send_ptr[p], "bad halo counts");
+      h->recv_ptr[p + 1] = h->recv_ptr[p] + recv_count[p];
+    }
+    GL_REQUIRE(h->recv_ptr[n_peers] == h->n_nodes - h->n_own, "ghost count does not match the halo plan");
+    h->n_send = send_ptr[n_peers];
+    std::vector<int32_t> idx(h->n_send);
+    for (int64_t k = 0; k < h->n_send; ++k) {
+      GL_REQUIRE(send_idx[k] >= 0 && send_idx[k] < h->n_own, "send index is not an owned node");
+      idx[k] = h->old2new[send_idx[k]];
+    }
+    h->send_idx.upload(idx, h->st);
+    h->sendbuf.alloc_zero((size_t)std::max<int64_t>(h->n_send, 1) * h->dim, h->st);
+    GL_HIP(hipStreamSynchronize(h->st));
+    return GLIMS_OK;
+  });
+}
+
+}  // extern "C"

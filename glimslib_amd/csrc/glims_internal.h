@@ -1,0 +1,174 @@
+// Internal declarations of libglimship.so (gfx950 only; no CPU fallback, no portability layer).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <stdexcept>
+#include "../../include/glims_hip.h"
+
+#define GL_WAVE 64                 // wavefront width of CDNA4; SELL slice height
+#define GL_SIGMA 4096              // sigma window (rows) of the SELL-C-sigma row sort
+#define GL_MAX_LABELS 256
+
+struct glims_error : std::runtime_error {
+  int code;
+  glims_error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define GL_HIP(expr)                                                                            \
+  do {                                                                                          \
+    hipError_t _e = (expr);                                                                     \
+    if (_e != hipSuccess)                                                                       \
+      throw glims_error(GLIMS_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e) + " (" + \
+                                         __FILE__ + ":" + std::to_string(__LINE__) + ")");      \
+  } while (0)
+
+#define GL_NCCL(expr)                                                                              \
+  do {                                                                                             \
+    ncclResult_t _r = (expr);                                                                      \
+    if (_r != ncclSuccess)                                                                         \
+      throw glims_error(GLIMS_E_RCCL, std::string(#expr) + ": " + ncclGetErrorString(_r) + " (" + \
+                                          __FILE__ + ":" + std::to_string(__LINE__) + ")");        \
+  } while (0)
+
+#define GL_REQUIRE(cond, msg)                                  \
+  do {                                                         \
+    if (!(cond)) throw glims_error(GLIMS_E_USAGE, (msg));      \
+  } while (0)
+
+// Device array with explicit lifetime (no implicit copies).
+template <class T>
+struct dvec {
+  T* p = nullptr;
+  size_t n = 0;
+  dvec() = default;
+  dvec(const dvec&) = delete;
+  dvec& operator=(const dvec&) = delete;
+  ~dvec() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  void alloc(size_t count) {
+    if (count == n && p) return;
+    release();
+    if (count) GL_HIP(hipMalloc((void**)&p, count * sizeof(T)));
+    n = count;
+  }
+  void alloc_zero(size_t count, hipStream_t s) {
+    alloc(count);
+    if (count) GL_HIP(hipMemsetAsync(p, 0, count * sizeof(T), s));
+  }
+  void upload(const T* h, size_t count, hipStream_t s) {
+    alloc(count);
+    if (count) GL_HIP(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, s));
+  }
+  void upload(const std::vector<T>& h, hipStream_t s) { upload(h.data(), h.size(), s); }
+};
+
+// Host-side result of the symbolic phase (setup_host.cpp).
+struct HostPattern {
+  int dim = 0, nv = 0;
+  int64_t n_nodes = 0, n_own = 0, n_cells = 0;
+  std::vector<int32_t> old2new, new2old;   // node renumbering (ghosts keep their place)
+  int32_t n_slices = 0;                    // ceil(n_own / 64)
+  std::vector<int64_t> slice_ptr;          // [n_slices+1] offsets into cols (multiples of 64)
+  std::vector<int32_t> cols;               // SELL-64 column indices (new numbering), padded with the row itself
+  std::vector<uint8_t> diag_k;             // [n_slices*64] slot of the diagonal in each row
+  std::vector<uint8_t> row_len;            // [n_slices*64] structural length of each row (0 for pad rows)
+  std::vector<int64_t> cslice_ptr;         // [n_slices+1] offsets into the (row, cell) incidence arrays
+  std::vector<uint32_t> cslots;            // 4 x uint8: slot (within the row) of each vertex of the cell
+  std::vector<int32_t> celem;              // cell id, -1 = padding
+  std::vector<int32_t> interior_slices, boundary_slices;   // boundary = references a ghost column
+  int max_len = 0, max_clen = 0;
+  int64_t nnz = 0, n_corners = 0;
+};
+
+void build_host_pattern(HostPattern& hp, int dim, int64_t n_nodes, int64_t n_own, int64_t n_cells,
+                        const double* xyz, const int32_t* cells);
+
+// Device-resident SELL-64 sparsity + incidence lists.
+struct DevPattern {
+  int32_t n_slices = 0;
+  int max_len = 0, max_clen = 0;
+  dvec<int64_t> slice_ptr;
+  dvec<int32_t> cols;
+  dvec<uint8_t> diag_k;
+  dvec<int64_t> cslice_ptr;
+  dvec<uint32_t> cslots;
+  dvec<int32_t> celem;
+  dvec<double> cw;                         // per-incidence reaction weight rho_T |T| d!/(d+3)!
+  dvec<int32_t> interior_slices, boundary_slices;
+  int32_t n_interior = 0, n_boundary = 0;
+  int64_t total_entries = 0, total_corners = 0;
+};
+
+// scalar slots of the Krylov recurrence (device array `scal`)
+enum { SC_ALPHA = 0, SC_BETA, SC_GAMMA, SC_IT, SC_RR, SC_DELTA, SC_COUNT = 8 };
+
+struct glims_ctx {
+  int dim = 0, nv = 0, device = 0;
+  int64_t n_nodes = 0, n_own = 0, n_cells = 0;
+  hipStream_t st = nullptr, st_comm = nullptr;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_pack = nullptr, ev_halo = nullptr;
+
+  std::vector<int32_t> old2new, new2old;
+  dvec<int32_t> d_old2new;
+  DevPattern pat;
+  int64_t nnz = 0, n_corners = 0;
+
+  dvec<uint8_t> label;
+  dvec<double> egeo;                       // per cell: |T|, grad(lambda_a) [nv][dim]
+  dvec<double> mat;                        // [5][GL_MAX_LABELS]: D, rho, gamma, mu, lambda
+  bool have_materials = false, is_setup = false, have_mech = false, have_state = false;
+
+  glims_options opt;
+  glims_stats stats;
+
+  // scalar operator planes (SELL-64 layout) and block planes
+  dvec<double> vM, vS, vA, vKel, vG;
+  // vectors (internal numbering; length n_nodes unless noted)
+  dvec<double> c, c_old, b, load_rd, dinv;
+  dvec<double> cg_p, cg_s, cg_u, cg_w, cg_r;                // scalar CG work vectors
+  dvec<double> U, mload, m_rhs, m_x, m_p, m_s, m_u, m_w, m_r, m_dinv, m_uD;   // mechanics, [n_nodes*dim]
+  dvec<uint8_t> fixed_c, fixed_u;
+  dvec<double> cD;
+  bool have_fixed_c = false, have_fixed_u = false, have_load_rd = false, have_mload = false;
+  dvec<double> stage;                      // staging for host<->device permuted transfers [n_nodes*dim]
+
+  dvec<double> partials;                   // per-block partial sums
+  dvec<double> red;                        // [4] reduced sums
+  dvec<double> scal;                       // [SC_COUNT] recurrence scalars
+  dvec<int> done;                          // [1] 0 running, 1 converged, 2 non-finite, 3 breakdown
+  double* h_pinned = nullptr;              // pinned host mirror (16 doubles)
+  int n_partial_blocks = 0;
+
+  // multi-GPU
+  int rank = 0, world = 1;
+  ncclComm_t comm_halo = nullptr, comm_red = nullptr;
+  int n_peers = 0;
+  std::vector<int32_t> peer_rank;
+  std::vector<int64_t> send_ptr, recv_ptr;
+  dvec<int32_t> send_idx;
+  dvec<double> sendbuf;
+  int64_t n_send = 0;
+
+  std::string err;
+};
+
+// kernels.hip ---------------------------------------------------------------------------------------
+void gl_compute_egeo(glims_ctx* h, const double* d_xyz, const int32_t* d_cells);
+void gl_assemble_static(glims_ctx* h, int with_mechanics);
+void gl_rd_assemble(glims_ctx* h, const double* c, const double* b, double* r_out, double* red_out /*dev [1]*/);
+void gl_spmv_scalar(glims_ctx* h, const double* vals, const double* x, double* y, bool masked);
+void gl_apply_G(glims_ctx* h, const double* c, double* y);
+void gl_spmv_block(glims_ctx* h, const double* x, double* y, bool masked);
+
+// solver.hip ----------------------------------------------------------------------------------------
+int gl_step(glims_ctx* h, int n_steps);
+int gl_solve_mechanics(glims_ctx* h);
+void gl_halo_exchange(glims_ctx* h, double* vec, int bs);   // blocking w.r.t. h->st (no overlap)
+void gl_comm_destroy(glims_ctx* h);

@@ -1,0 +1,537 @@
+// HIP kernels for gfx950 (CDNA4, wave64).  No MFMA: nothing here is a dense contraction; every kernel is
+// bound by HBM / L2 gather bandwidth, so the design goal is unit-stride streams + no atomics.
+//
+// Row ownership model: one lane = one matrix row, one wavefront = one SELL-64 slice.  Lane l of slice s reads
+// entry k of its row at  base(s) + k*64 + l  -> every wave-level load of values / columns / corner records is a
+// contiguous 512 B / 256 B segment.  Element ("corner") contributions are accumulated by the owning lane in its
+// private LDS column acc[slot*64 + lane] (bank = lane -> conflict-free for any slot), so the segmented scatter-add
+// of FEM assembly needs neither atomics nor colouring and is bitwise reproducible.
+#include "glims_internal.h"
+
+namespace {
+
+__device__ __forceinline__ int xcd_remap(int b, int nb) {
+  // Blocks are dealt round-robin over the 8 XCDs; give each XCD one contiguous range of logical blocks so that
+  // neighbouring slices (which gather overlapping x entries) share one L2.  Bijective for any nb.
+  const int xcd = b & 7, q = nb >> 3, r = nb & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// per-cell geometry: |T| and grad(lambda_a)
+// ---------------------------------------------------------------------------------------------------
+template <int D>
+__global__ void k_egeo(int64_t n_cells, const double* __restrict__ xyz, const int32_t* __restrict__ cells,
+                       double* __restrict__ egeo) {
+  constexpr int NV = D + 1, GE = 1 + NV * D;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_cells) return;
+  double X[NV][D];
+#pragma unroll
+  for (int m = 0; m < NV; ++m) {
+    const int64_t v = cells[e * NV + m];
+#pragma unroll
+    for (int a = 0; a < D; ++a) X[m][a] = xyz[v * D + a];
+  }
+  double* g = egeo + e * GE;
+  if constexpr (D == 2) {
+    const double a = X[1][0] - X[0][0], b = X[1][1] - X[0][1];
+    const double c = X[2][0] - X[0][0], d = X[2][1] - X[0][1];
+    const double det = a * d - b * c, inv = 1.0 / det;
+    const double g1x = d * inv, g1y = -c * inv, g2x = -b * inv, g2y = a * inv;
+    g[0] = fabs(det) * 0.5;
+    g[1] = -(g1x + g2x);
+    g[2] = -(g1y + g2y);
+    g[3] = g1x;
+    g[4] = g1y;
+    g[5] = g2x;
+    g[6] = g2y;
+  } else {
+    double r[3][3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int a = 0; a < 3; ++a) r[m][a] = X[m + 1][a] - X[0][a];
+    double c12[3] = {r[1][1] * r[2][2] - r[1][2] * r[2][1], r[1][2] * r[2][0] - r[1][0] * r[2][2],
+                     r[1][0] * r[2][1] - r[1][1] * r[2][0]};
+    double c20[3] = {r[2][1] * r[0][2] - r[2][2] * r[0][1], r[2][2] * r[0][0] - r[2][0] * r[0][2],
+                     r[2][0] * r[0][1] - r[2][1] * r[0][0]};
+    double c01[3] = {r[0][1] * r[1][2] - r[0][2] * r[1][1], r[0][2] * r[1][0] - r[0][0] * r[1][2],
+                     r[0][0] * r[1][1] - r[0][1] * r[1][0]};
+    const double det = r[0][0] * c12[0] + r[0][1] * c12[1] + r[0][2] * c12[2];
+    const double inv = 1.0 / det;
+    g[0] = fabs(det) * (1.0 / 6.0);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double g1 = c12[a] * inv, g2 = c20[a] * inv, g3 = c01[a] * inv;
+      g[1 + 0 * 3 + a] = -(g1 + g2 + g3);
+      g[1 + 1 * 3 + a] = g1;
+      g[1 + 2 * 3 + a] = g2;
+      g[1 + 3 * 3 + a] = g3;
+    }
+  }
+}
+
+// reaction weight of each (row, cell) incidence: rho_T |T| d!/(d+3)!
+template <int D>
+__global__ void k_corner_weights(int64_t n, const int32_t* __restrict__ celem, const uint8_t* __restrict__ label,
+                                 const double* __restrict__ egeo, const double* __restrict__ mat,
+                                 double* __restrict__ cw) {
+  constexpr int GE = 1 + (D + 1) * D;
+  constexpr double fact = D == 2 ? 1.0 / 60.0 : 1.0 / 120.0;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t e = celem[i];
+  cw[i] = e < 0 ? 0.0 : mat[1 * GL_MAX_LABELS + label[e]] * egeo[(int64_t)e * GE] * fact;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// static assembly: one scalar plane of one operator per launch (setup path, not timed per step)
+// ---------------------------------------------------------------------------------------------------
+enum { MODE_M = 0, MODE_S = 1, MODE_KEL = 2, MODE_G = 3 };
+
+template <int D>
+__global__ __launch_bounds__(GL_WAVE) void k_assemble_static(
+    int mode, int ca, int cb, int64_t n_own, const int64_t* __restrict__ slice_ptr,
+    const int64_t* __restrict__ cslice_ptr, const uint32_t* __restrict__ cslots,
+    const int32_t* __restrict__ celem, const uint8_t* __restrict__ diag_k, const double* __restrict__ egeo,
+    const uint8_t* __restrict__ label, const double* __restrict__ mat, double dt, double* __restrict__ out,
+    int ostride, int ooff) {
+  constexpr int NV = D + 1, GE = 1 + NV * D;
+  constexpr double mfac = 1.0 / ((D + 1) * (D + 2));
+  extern __shared__ double acc[];
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const int64_t row = (int64_t)s * GL_WAVE + lane;
+  const int64_t base = slice_ptr[s], cbase = cslice_ptr[s];
+  const int len = (int)((slice_ptr[s + 1] - base) >> 6), clen = (int)((cslice_ptr[s + 1] - cbase) >> 6);
+  for (int k = 0; k < len; ++k) acc[k * GL_WAVE + lane] = 0.0;
+  const int dk = diag_k[row];
+  for (int q = 0; q < clen; ++q) {
+    const int64_t ci = cbase + (int64_t)q * GL_WAVE + lane;
+    const int32_t e = celem[ci];
+    if (e < 0) continue;
+    const uint32_t slots = cslots[ci];
+    const double* g = egeo + (int64_t)e * GE;
+    const double vol = g[0];
+    const int lab = label[e];
+    int li = 0;
+#pragma unroll
+    for (int m = 0; m < NV; ++m)
+      if ((int)((slots >> (8 * m)) & 255u) == dk) li = m;
+    double gi[D];
+#pragma unroll
+    for (int a = 0; a < D; ++a) gi[a] = g[1 + li * D + a];
+    const double Dc = mat[0 * GL_MAX_LABELS + lab], rho = mat[1 * GL_MAX_LABELS + lab],
+                 gam = mat[2 * GL_MAX_LABELS + lab], mu = mat[3 * GL_MAX_LABELS + lab],
+                 lam = mat[4 * GL_MAX_LABELS + lab];
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+      const int k = (int)((slots >> (8 * m)) & 255u);
+      double gm[D], gg = 0.0;
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        gm[a] = g[1 + m * D + a];
+        gg += gi[a] * gm[a];
+      }
+      double v;
+      if (mode == MODE_M)
+        v = vol * mfac * (m == li ? 2.0 : 1.0);
+      else if (mode == MODE_S)
+        v = (1.0 - dt * rho) * vol * mfac * (m == li ? 2.0 : 1.0) + dt * Dc * vol * gg;
+      else if (mode == MODE_KEL)
+        v = vol * (lam * gi[ca] * gm[cb] + mu * gi[cb] * gm[ca] + (ca == cb ? mu * gg : 0.0));
+      else
+        v = gam * (2.0 * mu + D * lam) * vol * (1.0 / (D + 1)) * gi[ca];
+      acc[k * GL_WAVE + lane] += v;
+    }
+  }
+  for (int k = 0; k < len; ++k)
+    out[(base + (int64_t)k * GL_WAVE) * ostride + ooff + lane] = acc[k * GL_WAVE + lane];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// hot: RD Jacobian + Newton residual in one sweep
+//   A(c) = S + 2 dt N(c),  N(c)_ij = sum_T w_T (c_i + c_j + s_T)  (i != j),  N_ii = sum_T w_T (4 c_i + 2 s_T),
+//   s_T = sum of c over the cell's vertices, w_T = rho_T |T| d!/(d+3)!   [exact integral of rho c_h phi_i phi_j]
+//   -R = b - 1/2 (A + S) c,   b = M c_prev + load
+// ---------------------------------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
+    int64_t n_own, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ cols,
+    const int64_t* __restrict__ cslice_ptr, const uint32_t* __restrict__ cslots, const double* __restrict__ cw,
+    const uint8_t* __restrict__ diag_k, const double* __restrict__ vS, double* __restrict__ vA,
+    const double* __restrict__ c, const double* __restrict__ b, double* __restrict__ r_out,
+    double* __restrict__ dinv, const uint8_t* __restrict__ fixed, double two_dt, double* __restrict__ partials,
+    int max_len) {
+  extern __shared__ double lds[];
+  double* acc = lds;
+  double* cn = lds + (size_t)max_len * GL_WAVE;
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const int64_t row = (int64_t)s * GL_WAVE + lane;
+  const int64_t base = slice_ptr[s], cbase = cslice_ptr[s];
+  const int len = (int)((slice_ptr[s + 1] - base) >> 6), clen = (int)((cslice_ptr[s + 1] - cbase) >> 6);
+  const int32_t* cc = cols + base + lane;
+#pragma unroll 4
+  for (int k = 0; k < len; ++k) {
+    cn[k * GL_WAVE + lane] = c[cc[(int64_t)k * GL_WAVE]];
+    acc[k * GL_WAVE + lane] = 0.0;
+  }
+  const int dk = diag_k[row];
+  const double ci = cn[dk * GL_WAVE + lane];
+  const uint32_t* sl = cslots + cbase + lane;
+  const double* wp = cw + cbase + lane;
+#pragma unroll 2
+  for (int q = 0; q < clen; ++q) {
+    const double w = wp[(int64_t)q * GL_WAVE];
+    const uint32_t slots = sl[(int64_t)q * GL_WAVE];
+    if (w == 0.0) continue;   // padding, or a cell without proliferation: contributes nothing to N(c)
+    int k[NV];
+    double cv[NV], st = 0.0;
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+      k[m] = (int)((slots >> (8 * m)) & 255u);
+      cv[m] = cn[k[m] * GL_WAVE + lane];
+      st += cv[m];
+    }
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+      const double v = (k[m] == dk) ? w * (4.0 * ci + 2.0 * st) : w * (ci + cv[m] + st);
+      acc[k[m] * GL_WAVE + lane] += v;
+    }
+  }
+  const double* sv = vS + base + lane;
+  double* av = vA + base + lane;
+  double r = 0.0, d = 1.0;
+#pragma unroll 4
+  for (int k = 0; k < len; ++k) {
+    const double Sv = sv[(int64_t)k * GL_WAVE];
+    const double Av = Sv + two_dt * acc[k * GL_WAVE + lane];
+    av[(int64_t)k * GL_WAVE] = Av;
+    r += 0.5 * (Av + Sv) * cn[k * GL_WAVE + lane];
+    if (k == dk) d = Av;
+  }
+  double rr = 0.0;
+  if (row < n_own) {
+    const bool fx = fixed && fixed[row];
+    const double res = fx ? 0.0 : b[row] - r;
+    r_out[row] = res;
+    dinv[row] = fx ? 1.0 : 1.0 / d;
+    rr = res * res;
+  }
+  rr = wave_sum(rr);
+  if (lane == 0) partials[s] = rr;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// hot: SELL-64 SpMV  y = A x  (+ addv), optional Dirichlet row mask, optional fused dot products
+//   partials[b] = ( r.x , y.x , r.r ) over the rows of logical block b   (x plays the role of u = Dinv r)
+// ---------------------------------------------------------------------------------------------------
+template <int DOTS>
+__global__ __launch_bounds__(256) void k_spmv(int n_launch, const int32_t* __restrict__ slice_list, int64_t n_own,
+                                               const int64_t* __restrict__ slice_ptr,
+                                               const int32_t* __restrict__ cols, const double* __restrict__ vals,
+                                               const double* __restrict__ x, double* __restrict__ y,
+                                               const uint8_t* __restrict__ fixed, const double* __restrict__ addv,
+                                               const double* __restrict__ r, double* __restrict__ partials,
+                                               int partial_off, const int* __restrict__ done, int remap) {
+  if (done && *done) return;
+  const int b = remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int si = b * 4 + wid;
+  double pg = 0.0, pd = 0.0, pr = 0.0;
+  if (si < n_launch) {
+    const int s = slice_list ? slice_list[si] : si;
+    const int64_t row = (int64_t)s * GL_WAVE + lane;
+    const int64_t base = slice_ptr[s];
+    const int len = (int)((slice_ptr[s + 1] - base) >> 6);
+    const double* v = vals + base + lane;
+    const int32_t* cc = cols + base + lane;
+    double acc = 0.0;
+    int k = 0;
+    for (; k + 4 <= len; k += 4) {
+      const int32_t c0 = cc[(int64_t)(k + 0) * GL_WAVE], c1 = cc[(int64_t)(k + 1) * GL_WAVE],
+                    c2 = cc[(int64_t)(k + 2) * GL_WAVE], c3 = cc[(int64_t)(k + 3) * GL_WAVE];
+      const double v0 = v[(int64_t)(k + 0) * GL_WAVE], v1 = v[(int64_t)(k + 1) * GL_WAVE],
+                   v2 = v[(int64_t)(k + 2) * GL_WAVE], v3 = v[(int64_t)(k + 3) * GL_WAVE];
+      const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+      acc += v0 * x0;
+      acc += v1 * x1;
+      acc += v2 * x2;
+      acc += v3 * x3;
+    }
+    for (; k < len; ++k) acc += v[(int64_t)k * GL_WAVE] * x[cc[(int64_t)k * GL_WAVE]];
+    if (row < n_own) {
+      if (fixed && fixed[row]) acc = 0.0;
+      if (addv) acc += addv[row];
+      y[row] = acc;
+      if (DOTS) {
+        const double ri = r[row], ui = x[row];
+        pg = ri * ui;
+        pd = acc * ui;
+        pr = ri * ri;
+      }
+    }
+  }
+  if (DOTS) {
+    __shared__ double red[4][3];
+    pg = wave_sum(pg);
+    pd = wave_sum(pd);
+    pr = wave_sum(pr);
+    if (lane == 0) {
+      red[wid][0] = pg;
+      red[wid][1] = pd;
+      red[wid][2] = pr;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+      const int q = threadIdx.x;
+      partials[(size_t)(partial_off + b) * 3 + q] = red[0][q] + red[1][q] + red[2][q] + red[3][q];
+    }
+  }
+}
+
+// block version (mechanics): BS x BS blocks stored as BS*BS slot-major planes per slice entry
+template <int BS, int DOTS>
+__global__ __launch_bounds__(256) void k_spmv_block(int n_launch, const int32_t* __restrict__ slice_list,
+                                                     int64_t n_own, const int64_t* __restrict__ slice_ptr,
+                                                     const int32_t* __restrict__ cols,
+                                                     const double* __restrict__ vals, const double* __restrict__ x,
+                                                     double* __restrict__ y, const uint8_t* __restrict__ fixed,
+                                                     const double* __restrict__ r, double* __restrict__ partials,
+                                                     int partial_off, const int* __restrict__ done, int remap) {
+  if (done && *done) return;
+  constexpr int B2 = BS * BS;
+  const int b = remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int si = b * 4 + wid;
+  double pg = 0.0, pd = 0.0, pr = 0.0;
+  if (si < n_launch) {
+    const int s = slice_list ? slice_list[si] : si;
+    const int64_t row = (int64_t)s * GL_WAVE + lane;
+    const int64_t base = slice_ptr[s];
+    const int len = (int)((slice_ptr[s + 1] - base) >> 6);
+    const int32_t* cc = cols + base + lane;
+    double acc[BS];
+#pragma unroll
+    for (int a = 0; a < BS; ++a) acc[a] = 0.0;
+#pragma unroll 2
+    for (int k = 0; k < len; ++k) {
+      const int64_t col = cc[(int64_t)k * GL_WAVE];
+      const double* v = vals + (base + (int64_t)k * GL_WAVE) * B2 + lane;
+      double xj[BS];
+#pragma unroll
+      for (int bb = 0; bb < BS; ++bb) xj[bb] = x[col * BS + bb];
+#pragma unroll
+      for (int a = 0; a < BS; ++a)
+#pragma unroll
+        for (int bb = 0; bb < BS; ++bb) acc[a] += v[(a * BS + bb) * GL_WAVE] * xj[bb];
+    }
+    if (row < n_own) {
+#pragma unroll
+      for (int a = 0; a < BS; ++a) {
+        double v = acc[a];
+        if (fixed && fixed[row * BS + a]) v = 0.0;
+        y[row * BS + a] = v;
+        if (DOTS) {
+          const double ri = r[row * BS + a], ui = x[row * BS + a];
+          pg += ri * ui;
+          pd += v * ui;
+          pr += ri * ri;
+        }
+      }
+    }
+  }
+  if (DOTS) {
+    __shared__ double red[4][3];
+    pg = wave_sum(pg);
+    pd = wave_sum(pd);
+    pr = wave_sum(pr);
+    if (lane == 0) {
+      red[wid][0] = pg;
+      red[wid][1] = pd;
+      red[wid][2] = pr;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+      const int q = threadIdx.x;
+      partials[(size_t)(partial_off + b) * 3 + q] = red[0][q] + red[1][q] + red[2][q] + red[3][q];
+    }
+  }
+}
+
+// y[(row,a)] = sum_k G[(row,a),col_k] c[col_k]
+template <int BS>
+__global__ __launch_bounds__(256) void k_apply_G(int n_slices, int64_t n_own, const int64_t* __restrict__ slice_ptr,
+                                                  const int32_t* __restrict__ cols, const double* __restrict__ vG,
+                                                  const double* __restrict__ c, const double* __restrict__ addv,
+                                                  double* __restrict__ y) {
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int s = blockIdx.x * 4 + wid;
+  if (s >= n_slices) return;
+  const int64_t row = (int64_t)s * GL_WAVE + lane;
+  const int64_t base = slice_ptr[s];
+  const int len = (int)((slice_ptr[s + 1] - base) >> 6);
+  double acc[BS];
+#pragma unroll
+  for (int a = 0; a < BS; ++a) acc[a] = 0.0;
+  for (int k = 0; k < len; ++k) {
+    const double cj = c[cols[base + (int64_t)k * GL_WAVE + lane]];
+    const double* v = vG + (base + (int64_t)k * GL_WAVE) * BS + lane;
+#pragma unroll
+    for (int a = 0; a < BS; ++a) acc[a] += v[a * GL_WAVE] * cj;
+  }
+  if (row < n_own)
+#pragma unroll
+    for (int a = 0; a < BS; ++a) y[row * BS + a] = acc[a] + (addv ? addv[row * BS + a] : 0.0);
+}
+
+}  // namespace
+
+// ===================================================================================================
+// launchers
+// ===================================================================================================
+template <class K>
+static void set_lds(K kern, size_t bytes) {
+  if (bytes > 48 * 1024)
+    GL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+}
+
+void gl_compute_egeo(glims_ctx* h, const double* d_xyz, const int32_t* d_cells) {
+  const int GE = 1 + h->nv * h->dim;
+  h->egeo.alloc((size_t)h->n_cells * GE);
+  const int bs = 256;
+  const unsigned grid = (unsigned)((h->n_cells + bs - 1) / bs);
+  if (h->dim == 2)
+    hipLaunchKernelGGL(k_egeo<2>, dim3(grid), dim3(bs), 0, h->st, h->n_cells, d_xyz, d_cells, h->egeo.p);
+  else
+    hipLaunchKernelGGL(k_egeo<3>, dim3(grid), dim3(bs), 0, h->st, h->n_cells, d_xyz, d_cells, h->egeo.p);
+  GL_HIP(hipGetLastError());
+}
+
+template <int D>
+static void assemble_plane(glims_ctx* h, int mode, int ca, int cb, double* out, int ostride, int ooff) {
+  const DevPattern& p = h->pat;
+  const size_t lds = (size_t)p.max_len * GL_WAVE * sizeof(double);
+  set_lds(k_assemble_static<D>, lds);
+  hipLaunchKernelGGL(k_assemble_static<D>, dim3(p.n_slices), dim3(GL_WAVE), lds, h->st, mode, ca, cb, h->n_own,
+                     p.slice_ptr.p, p.cslice_ptr.p, p.cslots.p, p.celem.p, p.diag_k.p, h->egeo.p, h->label.p,
+                     h->mat.p, h->opt.dt, out, ostride, ooff);
+  GL_HIP(hipGetLastError());
+}
+
+template <int D>
+static void assemble_static_t(glims_ctx* h, int with_mechanics) {
+  DevPattern& p = h->pat;
+  const size_t ne = (size_t)p.total_entries;
+  h->vM.alloc(ne);
+  h->vS.alloc(ne);
+  h->vA.alloc(ne);
+  assemble_plane<D>(h, MODE_M, 0, 0, h->vM.p, 1, 0);
+  assemble_plane<D>(h, MODE_S, 0, 0, h->vS.p, 1, 0);
+  GL_HIP(hipMemcpyAsync(h->vA.p, h->vS.p, ne * sizeof(double), hipMemcpyDeviceToDevice, h->st));
+  p.cw.alloc((size_t)p.total_corners);
+  {
+    const int bs = 256;
+    const unsigned grid = (unsigned)((p.total_corners + bs - 1) / bs);
+    hipLaunchKernelGGL(k_corner_weights<D>, dim3(grid), dim3(bs), 0, h->st, p.total_corners, p.celem.p, h->label.p,
+                       h->egeo.p, h->mat.p, p.cw.p);
+    GL_HIP(hipGetLastError());
+  }
+  if (with_mechanics) {
+    h->vKel.alloc(ne * D * D);
+    h->vG.alloc(ne * D);
+    for (int a = 0; a < D; ++a)
+      for (int b = 0; b < D; ++b) assemble_plane<D>(h, MODE_KEL, a, b, h->vKel.p, D * D, (a * D + b) * GL_WAVE);
+    for (int a = 0; a < D; ++a) assemble_plane<D>(h, MODE_G, a, 0, h->vG.p, D, a * GL_WAVE);
+  }
+}
+
+void gl_assemble_static(glims_ctx* h, int with_mechanics) {
+  if (h->dim == 2)
+    assemble_static_t<2>(h, with_mechanics);
+  else
+    assemble_static_t<3>(h, with_mechanics);
+}
+
+void gl_rd_assemble(glims_ctx* h, const double* c, const double* b, double* r_out, double* partials) {
+  const DevPattern& p = h->pat;
+  const size_t lds = (size_t)2 * p.max_len * GL_WAVE * sizeof(double);
+  const uint8_t* fx = h->have_fixed_c ? h->fixed_c.p : nullptr;
+  if (h->nv == 3) {
+    set_lds(k_rd_assemble<3>, lds);
+    hipLaunchKernelGGL(k_rd_assemble<3>, dim3(p.n_slices), dim3(GL_WAVE), lds, h->st, h->n_own, p.slice_ptr.p,
+                       p.cols.p, p.cslice_ptr.p, p.cslots.p, p.cw.p, p.diag_k.p, h->vS.p, h->vA.p, c, b, r_out,
+                       h->dinv.p, fx, 2.0 * h->opt.dt, partials, p.max_len);
+  } else {
+    set_lds(k_rd_assemble<4>, lds);
+    hipLaunchKernelGGL(k_rd_assemble<4>, dim3(p.n_slices), dim3(GL_WAVE), lds, h->st, h->n_own, p.slice_ptr.p,
+                       p.cols.p, p.cslice_ptr.p, p.cslots.p, p.cw.p, p.diag_k.p, h->vS.p, h->vA.p, c, b, r_out,
+                       h->dinv.p, fx, 2.0 * h->opt.dt, partials, p.max_len);
+  }
+  GL_HIP(hipGetLastError());
+}
+
+// Generic entry used by the solver: slice subset + fused dots.
+void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* slice_list, const double* vals,
+                    const double* x, double* y, const uint8_t* fixed, const double* addv, const double* r,
+                    double* partials, int partial_off, const int* done) {
+  if (n_launch <= 0) return;
+  const DevPattern& p = h->pat;
+  const unsigned grid = (unsigned)((n_launch + 3) / 4);
+  const int remap = slice_list ? 0 : 1;
+  if (r)
+    hipLaunchKernelGGL(k_spmv<1>, dim3(grid), dim3(256), 0, st, n_launch, slice_list, h->n_own, p.slice_ptr.p,
+                       p.cols.p, vals, x, y, fixed, addv, r, partials, partial_off, done, remap);
+  else
+    hipLaunchKernelGGL(k_spmv<0>, dim3(grid), dim3(256), 0, st, n_launch, slice_list, h->n_own, p.slice_ptr.p,
+                       p.cols.p, vals, x, y, fixed, addv, r, partials, partial_off, done, remap);
+  GL_HIP(hipGetLastError());
+}
+
+void gl_launch_spmv_block(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* slice_list, const double* x,
+                          double* y, const uint8_t* fixed, const double* r, double* partials, int partial_off,
+                          const int* done) {
+  if (n_launch <= 0) return;
+  const DevPattern& p = h->pat;
+  const unsigned grid = (unsigned)((n_launch + 3) / 4);
+  const int remap = slice_list ? 0 : 1;
+#define GL_BLK(BS, DOTS)                                                                                         \
+  hipLaunchKernelGGL((k_spmv_block<BS, DOTS>), dim3(grid), dim3(256), 0, st, n_launch, slice_list, h->n_own,      \
+                     p.slice_ptr.p, p.cols.p, h->vKel.p, x, y, fixed, r, partials, partial_off, done, remap)
+  if (h->dim == 2) {
+    if (r) GL_BLK(2, 1); else GL_BLK(2, 0);
+  } else {
+    if (r) GL_BLK(3, 1); else GL_BLK(3, 0);
+  }
+#undef GL_BLK
+  GL_HIP(hipGetLastError());
+}
+
+void gl_spmv_scalar(glims_ctx* h, const double* vals, const double* x, double* y, bool masked) {
+  gl_launch_spmv(h, h->st, h->pat.n_slices, nullptr, vals, x, y,
+                 masked && h->have_fixed_c ? h->fixed_c.p : nullptr, nullptr, nullptr, nullptr, 0, nullptr);
+}
+
+void gl_spmv_block(glims_ctx* h, const double* x, double* y, bool masked) {
+  gl_launch_spmv_block(h, h->st, h->pat.n_slices, nullptr, x, y,
+                       masked && h->have_fixed_u ? h->fixed_u.p : nullptr, nullptr, nullptr, 0, nullptr);
+}
+
+void gl_apply_G(glims_ctx* h, const double* c, double* y) {
+  const DevPattern& p = h->pat;
+  const unsigned grid = (unsigned)((p.n_slices + 3) / 4);
+  const double* addv = h->have_mload ? h->mload.p : nullptr;
+  if (h->dim == 2)
+    hipLaunchKernelGGL(k_apply_G<2>, dim3(grid), dim3(256), 0, h->st, p.n_slices, h->n_own, p.slice_ptr.p, p.cols.p,
+                       h->vG.p, c, addv, y);
+  else
+    hipLaunchKernelGGL(k_apply_G<3>, dim3(grid), dim3(256), 0, h->st, p.n_slices, h->n_own, p.slice_ptr.p, p.cols.p,
+                       h->vG.p, c, addv, y);
+  GL_HIP(hipGetLastError());
+}

@@ -1,0 +1,245 @@
+// Symbolic phase (host, OpenMP): node renumbering, SELL-64 sparsity and (row, cell) incidence lists.
+//
+// What it replaces in the reference: nothing in-tree -- DOLFIN builds the dofmap and the PETSc AIJ sparsity
+// when fenics.FunctionSpace / NonlinearVariationalProblem are constructed
+// (glimslib/simulation_helpers/helper_classes.py:271-282, glimslib/simulation/simulation_tumor_growth.py:126).
+//
+// Layout decisions (MI355X):
+//   * rows are renumbered along a Morton curve of their coordinates so that the x-gather of a 64-row slice
+//     stays inside a compact neighbourhood (L1/L2 hits), then sorted by length inside windows of GL_SIGMA rows
+//     (SELL-C-sigma) so that a slice is padded only to the longest of 64 similar rows;
+//   * a slice is 64 rows = one wavefront, entries stored slot-major ([slot][lane]) so that lane l of a wave
+//     reads address base + slot*64 + l: every value/column stream is a unit-stride 512 B / 256 B access;
+//   * the (row, cell) incidences ("corners") use the same slot-major layout.  A corner stores, for each vertex
+//     of its cell, the slot of that vertex inside the row -- everything an element contribution needs to be
+//     added to its row without atomics, and without reading the cell's connectivity again.
+#include "glims_internal.h"
+
+#include <omp.h>
+#include <parallel/algorithm>
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+namespace {
+
+inline uint64_t spread3(uint64_t x) {   // 21 bits -> every third bit
+  x &= 0x1fffffULL;
+  x = (x | x << 32) & 0x1f00000000ffffULL;
+  x = (x | x << 16) & 0x1f0000ff0000ffULL;
+  x = (x | x << 8) & 0x100f00f00f00f00fULL;
+  x = (x | x << 4) & 0x10c30c30c30c30c3ULL;
+  x = (x | x << 2) & 0x1249249249249249ULL;
+  return x;
+}
+inline uint64_t spread2(uint64_t x) {   // 31 bits -> every second bit
+  x &= 0x7fffffffULL;
+  x = (x | x << 16) & 0x0000ffff0000ffffULL;
+  x = (x | x << 8) & 0x00ff00ff00ff00ffULL;
+  x = (x | x << 4) & 0x0f0f0f0f0f0f0f0fULL;
+  x = (x | x << 2) & 0x3333333333333333ULL;
+  x = (x | x << 1) & 0x5555555555555555ULL;
+  return x;
+}
+
+struct KeyIdx {
+  uint64_t key;
+  int32_t idx;
+  bool operator<(const KeyIdx& o) const { return key < o.key || (key == o.key && idx < o.idx); }
+};
+
+}  // namespace
+
+void build_host_pattern(HostPattern& hp, int dim, int64_t n_nodes, int64_t n_own, int64_t n_cells,
+                        const double* xyz, const int32_t* cells) {
+  GL_REQUIRE(dim == 2 || dim == 3, "dim must be 2 or 3");
+  GL_REQUIRE(n_own > 0 && n_own <= n_nodes, "need 0 < n_own <= n_nodes");
+  GL_REQUIRE(n_nodes < (int64_t(1) << 31) - 64, "too many nodes for 32-bit local indices");
+  GL_REQUIRE(n_cells > 0 && n_cells * (dim + 1) < (int64_t(1) << 31), "cell count out of range");
+  const int nv = dim + 1;
+  hp.dim = dim;
+  hp.nv = nv;
+  hp.n_nodes = n_nodes;
+  hp.n_own = n_own;
+  hp.n_cells = n_cells;
+
+  for (int64_t i = 0; i < n_cells * nv; ++i)
+    GL_REQUIRE(cells[i] >= 0 && cells[i] < n_nodes, "cell vertex index out of range");
+
+  // ---- 1. node -> cell adjacency of owned nodes (cells ascending inside each list) ------------------
+  std::vector<int64_t> adj_ptr(n_own + 1, 0);
+  for (int64_t e = 0; e < n_cells; ++e)
+    for (int m = 0; m < nv; ++m) {
+      int32_t v = cells[e * nv + m];
+      if (v < n_own) adj_ptr[v + 1]++;
+    }
+  for (int64_t i = 0; i < n_own; ++i) adj_ptr[i + 1] += adj_ptr[i];
+  const int64_t n_corners = adj_ptr[n_own];
+  std::vector<int32_t> adj(n_corners);
+  {
+    std::vector<int64_t> fill(adj_ptr.begin(), adj_ptr.end() - 1);
+    for (int64_t e = 0; e < n_cells; ++e)
+      for (int m = 0; m < nv; ++m) {
+        int32_t v = cells[e * nv + m];
+        if (v < n_own) adj[fill[v]++] = (int32_t)e;
+      }
+  }
+  for (int64_t i = 0; i < n_own; ++i)
+    GL_REQUIRE(adj_ptr[i + 1] > adj_ptr[i], "owned node " + std::to_string(i) + " belongs to no cell (orphaned vertex)");
+
+  // ---- 2. neighbour lists (old numbering, sorted, diagonal included) ---------------------------------
+  std::vector<int64_t> nbr_ptr(n_own + 1, 0);
+  auto collect = [&](int64_t i, int32_t* buf) -> int {
+    int cnt = 0;
+    for (int64_t q = adj_ptr[i]; q < adj_ptr[i + 1]; ++q) {
+      const int32_t* cv = cells + (int64_t)adj[q] * nv;
+      for (int m = 0; m < nv; ++m) buf[cnt++] = cv[m];
+    }
+    std::sort(buf, buf + cnt);
+    return (int)(std::unique(buf, buf + cnt) - buf);
+  };
+  int64_t max_adj = 0;
+  for (int64_t i = 0; i < n_own; ++i) max_adj = std::max(max_adj, adj_ptr[i + 1] - adj_ptr[i]);
+#pragma omp parallel
+  {
+    std::vector<int32_t> buf(max_adj * nv + 4);
+#pragma omp for schedule(static)
+    for (int64_t i = 0; i < n_own; ++i) nbr_ptr[i + 1] = collect(i, buf.data());
+  }
+  for (int64_t i = 0; i < n_own; ++i) nbr_ptr[i + 1] += nbr_ptr[i];
+  hp.nnz = nbr_ptr[n_own];
+  hp.n_corners = n_corners;
+  std::vector<int32_t> nbr(hp.nnz);
+#pragma omp parallel
+  {
+    std::vector<int32_t> buf(max_adj * nv + 4);
+#pragma omp for schedule(static)
+    for (int64_t i = 0; i < n_own; ++i) {
+      int len = collect(i, buf.data());
+      std::memcpy(nbr.data() + nbr_ptr[i], buf.data(), sizeof(int32_t) * len);
+    }
+  }
+
+  // ---- 3. renumbering: Morton order, then length sort inside sigma windows ---------------------------
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  for (int64_t i = 0; i < n_nodes; ++i)
+    for (int a = 0; a < dim; ++a) {
+      double v = xyz[i * dim + a];
+      GL_REQUIRE(std::isfinite(v), "non-finite coordinate");
+      lo[a] = std::min(lo[a], v);
+      hi[a] = std::max(hi[a], v);
+    }
+  const double qmax = dim == 3 ? 2097151.0 : 2147483647.0;
+  double sc[3];
+  for (int a = 0; a < dim; ++a) sc[a] = hi[a] > lo[a] ? qmax / (hi[a] - lo[a]) : 0.0;
+  std::vector<KeyIdx> keys(n_own);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n_own; ++i) {
+    uint64_t q[3] = {0, 0, 0};
+    for (int a = 0; a < dim; ++a) q[a] = (uint64_t)((xyz[i * dim + a] - lo[a]) * sc[a]);
+    keys[i].key = dim == 3 ? (spread3(q[0]) | spread3(q[1]) << 1 | spread3(q[2]) << 2)
+                           : (spread2(q[0]) | spread2(q[1]) << 1);
+    keys[i].idx = (int32_t)i;
+  }
+  __gnu_parallel::sort(keys.begin(), keys.end());
+  hp.new2old.resize(n_nodes);
+  hp.old2new.resize(n_nodes);
+  {
+    const int64_t nwin = (n_own + GL_SIGMA - 1) / GL_SIGMA;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t w = 0; w < nwin; ++w) {
+      int64_t a = w * GL_SIGMA, b = std::min<int64_t>(n_own, a + GL_SIGMA);
+      std::stable_sort(keys.begin() + a, keys.begin() + b, [&](const KeyIdx& x, const KeyIdx& y) {
+        return (nbr_ptr[x.idx + 1] - nbr_ptr[x.idx]) > (nbr_ptr[y.idx + 1] - nbr_ptr[y.idx]);
+      });
+    }
+  }
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n_own; ++i) {
+    hp.new2old[i] = keys[i].idx;
+    hp.old2new[keys[i].idx] = (int32_t)i;
+  }
+  for (int64_t i = n_own; i < n_nodes; ++i) hp.new2old[i] = hp.old2new[i] = (int32_t)i;   // ghosts stay
+  keys.clear();
+  keys.shrink_to_fit();
+
+  // ---- 4. SELL-64 matrix pattern + corner lists ------------------------------------------------------
+  const int32_t n_slices = (int32_t)((n_own + GL_WAVE - 1) / GL_WAVE);
+  hp.n_slices = n_slices;
+  hp.slice_ptr.assign(n_slices + 1, 0);
+  hp.cslice_ptr.assign(n_slices + 1, 0);
+  int max_len = 0, max_clen = 0;
+#pragma omp parallel for schedule(static) reduction(max : max_len, max_clen)
+  for (int32_t s = 0; s < n_slices; ++s) {
+    int64_t len = 0, clen = 0;
+    for (int l = 0; l < GL_WAVE; ++l) {
+      int64_t r = (int64_t)s * GL_WAVE + l;
+      if (r >= n_own) break;
+      int32_t o = hp.new2old[r];
+      len = std::max(len, nbr_ptr[o + 1] - nbr_ptr[o]);
+      clen = std::max(clen, adj_ptr[o + 1] - adj_ptr[o]);
+    }
+    hp.slice_ptr[s + 1] = len * GL_WAVE;
+    hp.cslice_ptr[s + 1] = clen * GL_WAVE;
+    max_len = std::max(max_len, (int)len);
+    max_clen = std::max(max_clen, (int)clen);
+  }
+  GL_REQUIRE(max_len <= 255, "a mesh node has more than 255 neighbours; not supported");
+  for (int32_t s = 0; s < n_slices; ++s) {
+    hp.slice_ptr[s + 1] += hp.slice_ptr[s];
+    hp.cslice_ptr[s + 1] += hp.cslice_ptr[s];
+  }
+  GL_REQUIRE(hp.slice_ptr[n_slices] * (int64_t)(dim * dim) < (int64_t(1) << 40), "operator too large");
+  hp.max_len = max_len;
+  hp.max_clen = max_clen;
+  hp.cols.resize(hp.slice_ptr[n_slices]);
+  hp.diag_k.assign((size_t)n_slices * GL_WAVE, 0);
+  hp.row_len.assign((size_t)n_slices * GL_WAVE, 0);
+  hp.cslots.assign(hp.cslice_ptr[n_slices], 0u);
+  hp.celem.assign(hp.cslice_ptr[n_slices], -1);
+  std::vector<uint8_t> is_boundary(n_slices, 0);
+
+#pragma omp parallel
+  {
+    std::vector<int32_t> row(256);
+#pragma omp for schedule(dynamic, 64)
+    for (int32_t s = 0; s < n_slices; ++s) {
+      const int64_t base = hp.slice_ptr[s], cbase = hp.cslice_ptr[s];
+      const int len = (int)((hp.slice_ptr[s + 1] - base) / GL_WAVE);
+      bool bnd = false;
+      for (int l = 0; l < GL_WAVE; ++l) {
+        const int64_t r = (int64_t)s * GL_WAVE + l;
+        if (r >= n_own) {   // padding row: points at an existing column with zero value
+          for (int k = 0; k < len; ++k) hp.cols[base + (int64_t)k * GL_WAVE + l] = 0;
+          continue;
+        }
+        const int32_t o = hp.new2old[r];
+        const int rl = (int)(nbr_ptr[o + 1] - nbr_ptr[o]);
+        for (int k = 0; k < rl; ++k) row[k] = hp.old2new[nbr[nbr_ptr[o] + k]];
+        std::sort(row.begin(), row.begin() + rl);
+        hp.row_len[r] = (uint8_t)rl;
+        for (int k = 0; k < rl; ++k) {
+          hp.cols[base + (int64_t)k * GL_WAVE + l] = row[k];
+          if (row[k] == (int32_t)r) hp.diag_k[r] = (uint8_t)k;
+          if (row[k] >= n_own) bnd = true;
+        }
+        for (int k = rl; k < len; ++k) hp.cols[base + (int64_t)k * GL_WAVE + l] = (int32_t)r;
+        int q = 0;
+        for (int64_t a = adj_ptr[o]; a < adj_ptr[o + 1]; ++a, ++q) {
+          const int32_t e = adj[a];
+          uint32_t packed = 0;
+          for (int m = 0; m < nv; ++m) {
+            const int32_t vn = hp.old2new[cells[(int64_t)e * nv + m]];
+            const int k = (int)(std::lower_bound(row.begin(), row.begin() + rl, vn) - row.begin());
+            packed |= (uint32_t)k << (8 * m);
+          }
+          hp.celem[cbase + (int64_t)q * GL_WAVE + l] = e;
+          hp.cslots[cbase + (int64_t)q * GL_WAVE + l] = packed;
+        }
+      }
+      is_boundary[s] = bnd;
+    }
+  }
+  for (int32_t s = 0; s < n_slices; ++s) (is_boundary[s] ? hp.boundary_slices : hp.interior_slices).push_back(s);
+}

@@ -1,0 +1,507 @@
+// Time stepping on the device: Newton on the RD block, single-reduction (Chronopoulos-Gear) Jacobi-PCG for
+// the linear solves, block-Jacobi PCG for the (linear, decoupled) mechanics block, RCCL halo exchange.
+//
+// Replaces, per time step, `self.solver.solve()` of the reference (simulation_base.py:302): DOLFIN residual and
+// Jacobian assembly + PETSc SNES with a sparse LU of the monolithic (d+1)N system
+// (simulation_tumor_growth.py:124-130).  The concentration block does not depend on the displacement
+// (simulation_tumor_growth.py:115-120), so the monolithic Newton iteration and "Newton on c, then one linear
+// solve for u" have the same fixed point; tests/ checks that claim against the monolithic oracle.
+//
+// Host/device protocol: the host never reads a scalar inside a Krylov iteration.  alpha/beta live in `scal`,
+// a device-side `done` word turns the remaining enqueued kernels of a batch into no-ops, and the host polls it
+// once per `check_every` iterations.  In a partitioned run every rank enqueues the same kernel/collective
+// sequence; the decision words are computed from all-reduced values and are therefore identical on all ranks.
+#include "glims_internal.h"
+
+#include <cmath>
+#include <cstring>
+
+void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* slice_list, const double* vals,
+                    const double* x, double* y, const uint8_t* fixed, const double* addv, const double* r,
+                    double* partials, int partial_off, const int* done);
+void gl_launch_spmv_block(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* slice_list, const double* x,
+                          double* y, const uint8_t* fixed, const double* r, double* partials, int partial_off,
+                          const int* done);
+
+namespace {
+
+template <int BS>
+__global__ void k_cg_init(int64_t n_own, const double* __restrict__ r, const double* __restrict__ dinv,
+                          double* __restrict__ u, double* __restrict__ p, double* __restrict__ s) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_own; i += stride) {
+    if constexpr (BS == 1) {
+      u[i] = dinv[i] * r[i];
+      p[i] = 0.0;
+      s[i] = 0.0;
+    } else {
+      double rv[BS];
+#pragma unroll
+      for (int a = 0; a < BS; ++a) rv[a] = r[i * BS + a];
+#pragma unroll
+      for (int a = 0; a < BS; ++a) {
+        double v = 0.0;
+#pragma unroll
+        for (int b = 0; b < BS; ++b) v += dinv[i * BS * BS + a * BS + b] * rv[b];
+        u[i * BS + a] = v;
+        p[i * BS + a] = 0.0;
+        s[i * BS + a] = 0.0;
+      }
+    }
+  }
+}
+
+// p = u + beta p;  s = w + beta s;  x += alpha p;  r -= alpha s;  u = Dinv r      (one pass over 7 vectors)
+template <int BS>
+__global__ void k_cg_update(int64_t n_own, const double* __restrict__ scal, const int* __restrict__ done,
+                            double* __restrict__ p, double* __restrict__ s, double* __restrict__ x,
+                            double* __restrict__ r, double* __restrict__ u, const double* __restrict__ w,
+                            const double* __restrict__ dinv) {
+  if (*done) return;
+  const double alpha = scal[SC_ALPHA], beta = scal[SC_BETA];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_own; i += stride) {
+    if constexpr (BS == 1) {
+      const double pi = u[i] + beta * p[i];
+      const double si = w[i] + beta * s[i];
+      p[i] = pi;
+      s[i] = si;
+      x[i] += alpha * pi;
+      const double ri = r[i] - alpha * si;
+      r[i] = ri;
+      u[i] = dinv[i] * ri;
+    } else {
+      double rv[BS];
+#pragma unroll
+      for (int a = 0; a < BS; ++a) {
+        const int64_t j = i * BS + a;
+        const double pi = u[j] + beta * p[j];
+        const double si = w[j] + beta * s[j];
+        p[j] = pi;
+        s[j] = si;
+        x[j] += alpha * pi;
+        rv[a] = r[j] - alpha * si;
+        r[j] = rv[a];
+      }
+#pragma unroll
+      for (int a = 0; a < BS; ++a) {
+        double v = 0.0;
+#pragma unroll
+        for (int b = 0; b < BS; ++b) v += dinv[i * BS * BS + a * BS + b] * rv[b];
+        u[i * BS + a] = v;
+      }
+    }
+  }
+}
+
+// red[q] = sum_b partials[b*nq + q], fixed order -> bitwise reproducible
+__global__ __launch_bounds__(256) void k_reduce(int n, int nq, const double* __restrict__ partials,
+                                                 double* __restrict__ red, const int* __restrict__ done) {
+  if (done && *done) return;
+  __shared__ double sm[256];
+  for (int q = 0; q < nq; ++q) {
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) v += partials[(size_t)i * nq + q];
+    sm[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) red[q] = sm[0];
+    __syncthreads();
+  }
+}
+
+// Chronopoulos-Gear recurrence scalars.  red = (gamma = r.u, delta = w.u, rr = r.r), already global sums.
+__global__ void k_cg_scalars(const double* __restrict__ red, double* __restrict__ scal, int* __restrict__ done,
+                             double tol2) {
+  if (*done) return;
+  const double gamma = red[0], delta = red[1], rr = red[2];
+  scal[SC_RR] = rr;
+  if (!(isfinite(gamma) && isfinite(delta) && isfinite(rr))) {
+    *done = 2;
+    return;
+  }
+  if (rr <= tol2) {
+    *done = 1;
+    return;
+  }
+  const double it = scal[SC_IT];
+  double beta = 0.0, denom = delta;
+  if (it > 0.0) {
+    beta = gamma / scal[SC_GAMMA];
+    denom = delta - beta * gamma / scal[SC_ALPHA];
+  }
+  if (!(denom > 0.0)) {   // operator not SPD on this Krylov space (or exact breakdown)
+    *done = 3;
+    return;
+  }
+  scal[SC_ALPHA] = gamma / denom;
+  scal[SC_BETA] = beta;
+  scal[SC_GAMMA] = gamma;
+  scal[SC_DELTA] = delta;
+  scal[SC_IT] = it + 1.0;
+}
+
+__global__ void k_pack(int64_t n, int bs, const int32_t* __restrict__ idx, const double* __restrict__ vec,
+                       double* __restrict__ buf) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * bs) return;
+  const int64_t k = i / bs;
+  const int a = (int)(i - k * bs);
+  buf[i] = vec[(int64_t)idx[k] * bs + a];
+}
+
+__global__ void k_sub(int64_t n, double* __restrict__ y, const double* __restrict__ a, const double* __restrict__ b,
+                      const uint8_t* __restrict__ fixed) {   // y = a - b, 0 on fixed dofs
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = (fixed && fixed[i]) ? 0.0 : a[i] - b[i];
+}
+
+__global__ void k_mask_assign(int64_t n, double* __restrict__ y, const uint8_t* __restrict__ fixed,
+                              const double* __restrict__ vals) {   // y[fixed] = vals ? vals[i] : 0
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && fixed[i]) y[i] = vals ? vals[i] : 0.0;
+}
+
+__global__ void k_extrapolate(int64_t n, double* __restrict__ c, double* __restrict__ c_old,
+                              const uint8_t* __restrict__ fixed, int have_old) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double cur = c[i], old = c_old[i];
+  c_old[i] = cur;
+  if (have_old && !(fixed && fixed[i])) c[i] = 2.0 * cur - old;
+}
+
+__global__ __launch_bounds__(256) void k_dot_partials(int64_t n, const double* __restrict__ a,
+                                                       const double* __restrict__ b, double* __restrict__ partials) {
+  __shared__ double sm[4];
+  double v = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) v += a[i] * b[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// inverse of the (Dirichlet-modified) diagonal BS x BS blocks of K_el
+template <int BS>
+__global__ void k_block_dinv(int64_t n_own, const int64_t* __restrict__ slice_ptr, const uint8_t* __restrict__ diag_k,
+                             const double* __restrict__ vKel, const uint8_t* __restrict__ fixed,
+                             double* __restrict__ dinv) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n_own) return;
+  const int64_t s = row >> 6;
+  const int lane = (int)(row & 63);
+  const double* v = vKel + (slice_ptr[s] + (int64_t)diag_k[row] * GL_WAVE) * (BS * BS) + lane;
+  double A[BS][BS];
+#pragma unroll
+  for (int a = 0; a < BS; ++a)
+#pragma unroll
+    for (int b = 0; b < BS; ++b) {
+      double x = v[(a * BS + b) * GL_WAVE];
+      if (fixed && (fixed[row * BS + a] || fixed[row * BS + b])) x = (a == b) ? 1.0 : 0.0;
+      A[a][b] = x;
+    }
+  double* o = dinv + row * BS * BS;
+  if constexpr (BS == 2) {
+    const double inv = 1.0 / (A[0][0] * A[1][1] - A[0][1] * A[1][0]);
+    o[0] = A[1][1] * inv;
+    o[1] = -A[0][1] * inv;
+    o[2] = -A[1][0] * inv;
+    o[3] = A[0][0] * inv;
+  } else {
+    const double c00 = A[1][1] * A[2][2] - A[1][2] * A[2][1];
+    const double c01 = A[1][2] * A[2][0] - A[1][0] * A[2][2];
+    const double c02 = A[1][0] * A[2][1] - A[1][1] * A[2][0];
+    const double inv = 1.0 / (A[0][0] * c00 + A[0][1] * c01 + A[0][2] * c02);
+    o[0] = c00 * inv;
+    o[1] = (A[0][2] * A[2][1] - A[0][1] * A[2][2]) * inv;
+    o[2] = (A[0][1] * A[1][2] - A[0][2] * A[1][1]) * inv;
+    o[3] = c01 * inv;
+    o[4] = (A[0][0] * A[2][2] - A[0][2] * A[2][0]) * inv;
+    o[5] = (A[0][2] * A[1][0] - A[0][0] * A[1][2]) * inv;
+    o[6] = c02 * inv;
+    o[7] = (A[0][1] * A[2][0] - A[0][0] * A[2][1]) * inv;
+    o[8] = (A[0][0] * A[1][1] - A[0][1] * A[1][0]) * inv;
+  }
+}
+
+inline unsigned grid_for(int64_t n, int bs = 256, int64_t cap = 256 * 16) {
+  int64_t g = (n + bs - 1) / bs;
+  if (g < 1) g = 1;
+  if (cap > 0 && g > cap) g = cap;
+  return (unsigned)g;
+}
+inline unsigned grid_exact(int64_t n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
+
+}  // namespace
+
+// ===================================================================================================
+// halo exchange (RCCL grouped send/recv on the communication stream)
+// ===================================================================================================
+static void halo_start(glims_ctx* h, double* vec, int bs) {
+  if (h->world <= 1 || h->n_peers == 0) return;
+  if (h->n_send > 0) {
+    hipLaunchKernelGGL(k_pack, dim3(grid_exact(h->n_send * bs)), dim3(256), 0, h->st, h->n_send, bs,
+                       h->send_idx.p, vec, h->sendbuf.p);
+    GL_HIP(hipGetLastError());
+  }
+  GL_HIP(hipEventRecord(h->ev_pack, h->st));
+  GL_HIP(hipStreamWaitEvent(h->st_comm, h->ev_pack, 0));
+  GL_NCCL(ncclGroupStart());
+  for (int p = 0; p < h->n_peers; ++p) {
+    const int64_t ns = h->send_ptr[p + 1] - h->send_ptr[p], nr = h->recv_ptr[p + 1] - h->recv_ptr[p];
+    if (ns > 0)
+      GL_NCCL(ncclSend(h->sendbuf.p + h->send_ptr[p] * bs, (size_t)ns * bs, ncclDouble, h->peer_rank[p],
+                       h->comm_halo, h->st_comm));
+    if (nr > 0)
+      GL_NCCL(ncclRecv(vec + (h->n_own + h->recv_ptr[p]) * bs, (size_t)nr * bs, ncclDouble, h->peer_rank[p],
+                       h->comm_halo, h->st_comm));
+  }
+  GL_NCCL(ncclGroupEnd());
+  GL_HIP(hipEventRecord(h->ev_halo, h->st_comm));
+}
+static void halo_finish(glims_ctx* h) {
+  if (h->world <= 1 || h->n_peers == 0) return;
+  GL_HIP(hipStreamWaitEvent(h->st, h->ev_halo, 0));
+}
+void gl_halo_exchange(glims_ctx* h, double* vec, int bs) {
+  halo_start(h, vec, bs);
+  halo_finish(h);
+}
+static void allreduce_sum(glims_ctx* h, double* dev, int n) {
+  if (h->world > 1) GL_NCCL(ncclAllReduce(dev, dev, (size_t)n, ncclDouble, ncclSum, h->comm_red, h->st));
+}
+void gl_comm_destroy(glims_ctx* h) {
+  if (h->comm_halo) (void)ncclCommDestroy(h->comm_halo);
+  if (h->comm_red) (void)ncclCommDestroy(h->comm_red);
+  h->comm_halo = h->comm_red = nullptr;
+}
+
+static void poll(glims_ctx* h, int* done, double* scal8) {
+  // one small D2H of the decision word + recurrence scalars, then the only host sync of a batch
+  GL_HIP(hipMemcpyAsync(h->h_pinned, h->scal.p, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->st));
+  GL_HIP(hipMemcpyAsync(h->h_pinned + SC_COUNT, h->done.p, sizeof(int), hipMemcpyDeviceToHost, h->st));
+  GL_HIP(hipStreamSynchronize(h->st));
+  std::memcpy(scal8, h->h_pinned, SC_COUNT * sizeof(double));
+  std::memcpy(done, h->h_pinned + SC_COUNT, sizeof(int));
+}
+
+static double read_red0(glims_ctx* h) {
+  GL_HIP(hipMemcpyAsync(h->h_pinned, h->red.p, sizeof(double), hipMemcpyDeviceToHost, h->st));
+  GL_HIP(hipStreamSynchronize(h->st));
+  return h->h_pinned[0];
+}
+
+// ===================================================================================================
+// single-reduction PCG.  On entry: r = residual of the current x (owned rows), x = current iterate.
+// ===================================================================================================
+struct CgVecs {
+  double *x, *r, *u, *w, *p, *s;
+  const double* dinv;
+  const double* vals;       // scalar operator plane; nullptr -> K_el blocks
+  const uint8_t* fixed;
+  int bs;
+};
+
+static void apply_with_halo(glims_ctx* h, const CgVecs& v) {
+  const DevPattern& p = h->pat;
+  const bool split = h->world > 1 && h->n_peers > 0;
+  if (!split) {
+    if (v.vals)
+      gl_launch_spmv(h, h->st, p.n_slices, nullptr, v.vals, v.u, v.w, v.fixed, nullptr, v.r, h->partials.p, 0,
+                     h->done.p);
+    else
+      gl_launch_spmv_block(h, h->st, p.n_slices, nullptr, v.u, v.w, v.fixed, v.r, h->partials.p, 0, h->done.p);
+    return;
+  }
+  // interior slices overlap with the xGMI transfer; boundary slices run once the ghosts have landed
+  halo_start(h, v.u, v.bs);
+  const int nbi = (p.n_interior + 3) / 4;
+  if (v.vals)
+    gl_launch_spmv(h, h->st, p.n_interior, p.interior_slices.p, v.vals, v.u, v.w, v.fixed, nullptr, v.r,
+                   h->partials.p, 0, h->done.p);
+  else
+    gl_launch_spmv_block(h, h->st, p.n_interior, p.interior_slices.p, v.u, v.w, v.fixed, v.r, h->partials.p, 0,
+                         h->done.p);
+  halo_finish(h);
+  if (v.vals)
+    gl_launch_spmv(h, h->st, p.n_boundary, p.boundary_slices.p, v.vals, v.u, v.w, v.fixed, nullptr, v.r,
+                   h->partials.p, nbi, h->done.p);
+  else
+    gl_launch_spmv_block(h, h->st, p.n_boundary, p.boundary_slices.p, v.u, v.w, v.fixed, v.r, h->partials.p, nbi,
+                         h->done.p);
+}
+
+static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, int64_t* its_out, double* res_out) {
+  const DevPattern& p = h->pat;
+  const bool split = h->world > 1 && h->n_peers > 0;
+  const int nblocks = split ? (p.n_interior + 3) / 4 + (p.n_boundary + 3) / 4 : (p.n_slices + 3) / 4;
+  const int64_t n = h->n_own;
+  GL_HIP(hipMemsetAsync(h->scal.p, 0, SC_COUNT * sizeof(double), h->st));
+  GL_HIP(hipMemsetAsync(h->done.p, 0, sizeof(int), h->st));
+  const unsigned g = grid_for(n);
+#define GL_VEC(K, ...)                                                                  \
+  do {                                                                                  \
+    if (v.bs == 1) hipLaunchKernelGGL(K<1>, dim3(g), dim3(256), 0, h->st, __VA_ARGS__); \
+    else if (v.bs == 2) hipLaunchKernelGGL(K<2>, dim3(g), dim3(256), 0, h->st, __VA_ARGS__); \
+    else hipLaunchKernelGGL(K<3>, dim3(g), dim3(256), 0, h->st, __VA_ARGS__);           \
+    GL_HIP(hipGetLastError());                                                          \
+  } while (0)
+  GL_VEC(k_cg_init, n, v.r, v.dinv, v.u, v.p, v.s);
+  const double tol2 = tol_abs * tol_abs;
+  int done = 0;
+  double sc[SC_COUNT];
+  const int batch = h->opt.check_every > 0 ? h->opt.check_every : 8;
+  int enq = 0;
+  while (enq < maxit + 1) {
+    const int nb = std::min(batch, maxit + 1 - enq);
+    for (int j = 0; j < nb; ++j) {
+      apply_with_halo(h, v);
+      hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, h->st, nblocks, 3, h->partials.p, h->red.p, h->done.p);
+      allreduce_sum(h, h->red.p, 3);
+      hipLaunchKernelGGL(k_cg_scalars, dim3(1), dim3(1), 0, h->st, h->red.p, h->scal.p, h->done.p, tol2);
+      GL_VEC(k_cg_update, n, h->scal.p, h->done.p, v.p, v.s, v.x, v.r, v.u, v.w, v.dinv);
+    }
+    enq += nb;
+    poll(h, &done, sc);
+    if (done) break;
+  }
+#undef GL_VEC
+  *its_out = (int64_t)sc[SC_IT];
+  *res_out = std::sqrt(sc[SC_RR]);
+  if (done == 1) return GLIMS_OK;
+  if (done == 2) return GLIMS_NAN;
+  return GLIMS_NOT_CONVERGED;
+}
+
+// ===================================================================================================
+// RD time stepping
+// ===================================================================================================
+int gl_step(glims_ctx* h, int n_steps) {
+  GL_REQUIRE(h->is_setup, "glims_step before glims_setup");
+  GL_REQUIRE(h->have_state, "glims_step before glims_set_state");
+  const DevPattern& p = h->pat;
+  const int64_t n = h->n_own;
+  const glims_options& o = h->opt;
+  int status = GLIMS_OK;
+  GL_HIP(hipEventRecord(h->ev_a, h->st));
+  for (int step = 0; step < n_steps && status == GLIMS_OK; ++step) {
+    // b = M c^n + load          ('u_previous1 * v1 * dx', simulation_tumor_growth.py:117)
+    gl_launch_spmv(h, h->st, p.n_slices, nullptr, h->vM.p, h->c.p, h->b.p, nullptr,
+                   h->have_load_rd ? h->load_rd.p : nullptr, nullptr, nullptr, 0, nullptr);
+    bool ghosts_valid = true;
+    if (o.flags & GLIMS_FLAG_EXTRAPOLATE_GUESS) {
+      hipLaunchKernelGGL(k_extrapolate, dim3(grid_exact(n)), dim3(256), 0, h->st, n, h->c.p, h->c_old.p,
+                         h->have_fixed_c ? h->fixed_c.p : nullptr, h->stats.steps > 0 ? 1 : 0);
+      ghosts_valid = false;
+    }
+    double r0 = 0.0, target = 0.0, nr = 0.0;
+    int it = 0;
+    for (;; ++it) {
+      if (!ghosts_valid) gl_halo_exchange(h, h->c.p, 1);
+      gl_rd_assemble(h, h->c.p, h->b.p, h->cg_r.p, h->partials.p);
+      hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, h->st, p.n_slices, 1, h->partials.p, h->red.p,
+                         (const int*)nullptr);
+      allreduce_sum(h, h->red.p, 1);
+      nr = std::sqrt(read_red0(h));
+      h->stats.rd_assemblies++;
+      if (!std::isfinite(nr)) {
+        status = GLIMS_NAN;
+        break;
+      }
+      if (it == 0) {
+        r0 = nr;
+        target = std::max(o.newton_atol, o.newton_rtol * r0);
+      }
+      if (nr <= target) break;
+      if (it >= o.newton_maxit) {
+        status = GLIMS_NOT_CONVERGED;
+        break;
+      }
+      // A(c_k) delta = -R(c_k);  the update is accumulated straight into c (x0 = 0  <=>  x = c_k)
+      const double tol_lin = std::max(std::max(o.cg_atol, 0.1 * target), o.cg_rtol * nr);
+      CgVecs v{h->c.p, h->cg_r.p, h->cg_u.p, h->cg_w.p, h->cg_p.p, h->cg_s.p,
+               h->dinv.p, h->vA.p, h->have_fixed_c ? h->fixed_c.p : nullptr, 1};
+      int64_t its = 0;
+      double res = 0.0;
+      const int cs = cg_solve(h, v, tol_lin, o.cg_maxit, &its, &res);
+      h->stats.cg_its += its;
+      h->stats.newton_its++;
+      h->stats.last_cg_res = res;
+      ghosts_valid = false;
+      if (cs != GLIMS_OK) {
+        status = cs;
+        break;
+      }
+    }
+    if (!ghosts_valid) gl_halo_exchange(h, h->c.p, 1);   // invariant: ghosts of c are current between steps
+    h->stats.last_newton_res = nr;
+    h->stats.steps++;
+  }
+  GL_HIP(hipEventRecord(h->ev_b, h->st));
+  GL_HIP(hipEventSynchronize(h->ev_b));
+  float ms = 0.f;
+  GL_HIP(hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
+  h->stats.ms_steps += ms;
+  return status;
+}
+
+// ===================================================================================================
+// mechanics:  K_el u = G c + f,  Dirichlet dofs eliminated symmetrically (projected operator P K P)
+// ===================================================================================================
+int gl_solve_mechanics(glims_ctx* h) {
+  GL_REQUIRE(h->is_setup && h->have_mech, "glims_solve_mechanics needs glims_setup(with_mechanics=1)");
+  GL_REQUIRE(h->have_state, "glims_solve_mechanics before glims_set_state");
+  const DevPattern& p = h->pat;
+  const int bs = h->dim;
+  const int64_t nd = h->n_own * bs;
+  const uint8_t* fx = h->have_fixed_u ? h->fixed_u.p : nullptr;
+  // block-Jacobi preconditioner of the constrained operator
+  if (bs == 2)
+    hipLaunchKernelGGL(k_block_dinv<2>, dim3(grid_exact(h->n_own)), dim3(256), 0, h->st, h->n_own, p.slice_ptr.p,
+                       p.diag_k.p, h->vKel.p, fx, h->m_dinv.p);
+  else
+    hipLaunchKernelGGL(k_block_dinv<3>, dim3(grid_exact(h->n_own)), dim3(256), 0, h->st, h->n_own, p.slice_ptr.p,
+                       p.diag_k.p, h->vKel.p, fx, h->m_dinv.p);
+  GL_HIP(hipGetLastError());
+  // rhs = G c + f - K u_D, zero on constrained dofs
+  gl_apply_G(h, h->c.p, h->m_rhs.p);
+  if (fx) {
+    gl_halo_exchange(h, h->m_uD.p, bs);
+    gl_spmv_block(h, h->m_uD.p, h->m_w.p, false);
+    hipLaunchKernelGGL(k_sub, dim3(grid_exact(nd)), dim3(256), 0, h->st, nd, h->m_rhs.p, h->m_rhs.p, h->m_w.p, fx);
+  }
+  // ||rhs|| for the relative tolerance
+  const unsigned gd = grid_for(nd, 256, 1024);
+  hipLaunchKernelGGL(k_dot_partials, dim3(gd), dim3(256), 0, h->st, nd, h->m_rhs.p, h->m_rhs.p, h->partials.p);
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, h->st, (int)gd, 1, h->partials.p, h->red.p,
+                     (const int*)nullptr);
+  allreduce_sum(h, h->red.p, 1);
+  const double nb = std::sqrt(read_red0(h));
+  if (!std::isfinite(nb)) return GLIMS_NAN;
+  const double tol = std::max(h->opt.mech_atol, h->opt.mech_rtol * nb);
+  // warm start from the previous displacement: x = U on free dofs, 0 on constrained ones
+  if (fx) hipLaunchKernelGGL(k_mask_assign, dim3(grid_exact(nd)), dim3(256), 0, h->st, nd, h->U.p, fx,
+                             (const double*)nullptr);
+  gl_halo_exchange(h, h->U.p, bs);
+  gl_launch_spmv_block(h, h->st, p.n_slices, nullptr, h->U.p, h->m_w.p, fx, nullptr, nullptr, 0, nullptr);
+  hipLaunchKernelGGL(k_sub, dim3(grid_exact(nd)), dim3(256), 0, h->st, nd, h->m_r.p, h->m_rhs.p, h->m_w.p, fx);
+  GL_HIP(hipGetLastError());
+  CgVecs v{h->U.p, h->m_r.p, h->m_u.p, h->m_w.p, h->m_p.p, h->m_s.p, h->m_dinv.p, nullptr, fx, bs};
+  int64_t its = 0;
+  double res = 0.0;
+  int cs = cg_solve(h, v, tol, h->opt.mech_maxit, &its, &res);
+  h->stats.mech_cg_its += its;
+  h->stats.mech_solves++;
+  h->stats.last_mech_res = res;
+  if (fx) hipLaunchKernelGGL(k_mask_assign, dim3(grid_exact(nd)), dim3(256), 0, h->st, nd, h->U.p, fx,
+                             (const double*)h->m_uD.p);
+  gl_halo_exchange(h, h->U.p, bs);
+  GL_HIP(hipStreamSynchronize(h->st));
+  return cs;
+}

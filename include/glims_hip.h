@@ -1,0 +1,173 @@
+/*
+ * glims_hip.h -- C-ABI of libglimship.so, the MI355X (gfx950) backend of the forward time-stepping
+ * path of GlimSLib's TumorGrowth / TumorGrowthBrain models.
+ *
+ * The reference has no FFI of its own: its seam is the Python protocol of FenicsSimulation
+ * (glimslib/simulation/simulation_base.py:36-158), where run() (:236-317) only touches
+ * `self.solver.solve()` (:285/:302), `self.solution` and `u_previous.assign(self.solution)` (:312).
+ * This library replaces what sits behind `self.solver.solve()` -- DOLFIN assemble + PETSc SNES/LU,
+ * set up in glimslib/simulation/simulation_tumor_growth.py:78-140 and
+ * glimslib/simulation/simulation_tumor_growth_brain.py:24-125 -- and the surrounding n-step loop.
+ * Each entry point below names the reference interface it stands in for.
+ *
+ * Conventions
+ *   - plain C, opaque handle, caller-owned host buffers (row-major, contiguous), no global state;
+ *   - every function returns a status: GLIMS_OK (0), GLIMS_NOT_CONVERGED (1), GLIMS_NAN (2),
+ *     or a negative GLIMS_E_* code; glims_last_error() gives the message of the last failure;
+ *   - one handle = one device + its own HIP streams; a handle is not thread-safe, distinct handles are;
+ *   - node/cell indices are 0-based and local to the handle (rank-local in a partitioned run);
+ *   - displacement dofs are node-major interleaved: dof = node*dim + component
+ *     (the reference's mixed space W = [P1^dim, P1], simulation_tumor_growth.py:67-72);
+ *   - all floating point is IEEE fp64.
+ */
+#ifndef GLIMS_HIP_H
+#define GLIMS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GLIMS_ABI_VERSION 1
+
+enum {
+  GLIMS_OK = 0,
+  GLIMS_NOT_CONVERGED = 1,   /* Newton or Krylov hit its iteration cap (reference: exception from solver.solve(),
+                                swallowed at simulation_base.py:303-305 -> "warn, stop, return last solution") */
+  GLIMS_NAN = 2,             /* non-finite residual */
+  GLIMS_E_USAGE = -1,        /* bad argument / wrong call order */
+  GLIMS_E_HIP = -2,          /* HIP runtime error */
+  GLIMS_E_RCCL = -3,         /* RCCL error */
+  GLIMS_E_NO_DEVICE = -4     /* no usable gfx950 device: the library has no CPU fallback */
+};
+
+typedef struct glims_ctx glims_ctx;
+
+/* Solver options.  The reference hard-codes 'snes' with DOLFIN defaults (simulation_tumor_growth.py:126-130:
+ * SNES rtol 1e-9, atol 1e-10, max_it 50, linear_solver 'default' = sparse LU); this backend replaces LU by
+ * Jacobi-preconditioned CG and therefore converges *tighter* than those defaults. */
+typedef struct glims_options {
+  double dt;              /* params.sim_time_step (simulation_tumor_growth.py:108) */
+  double newton_rtol;     /* ||R_k||_2 <= max(newton_atol, newton_rtol*||R_0||_2);            default 1e-10 */
+  double newton_atol;     /*                                                               default 1e-13 */
+  int    newton_maxit;    /*                                                               default 50    */
+  double cg_rtol;         /* RD linear solve: ||r||_2 <= max(cg_atol, cg_rtol*||R_k||_2,
+                             0.1*newton target)                                            default 1e-6  */
+  double cg_atol;         /*                                                               default 0     */
+  int    cg_maxit;        /*                                                               default 5000  */
+  double mech_rtol;       /* mechanics PCG: ||r||_2 <= max(mech_atol, mech_rtol*||b||_2)    default 1e-10 */
+  double mech_atol;       /*                                                               default 0     */
+  int    mech_maxit;      /*                                                               default 200000*/
+  int    check_every;     /* Krylov iterations enqueued between host convergence polls      default 8     */
+  int    flags;           /* GLIMS_FLAG_* */
+} glims_options;
+
+#define GLIMS_FLAG_EXTRAPOLATE_GUESS 1  /* Newton guess c^n + (c^n - c^{n-1}) instead of c^n (reference: c^n) */
+
+typedef struct glims_stats {
+  int64_t steps;            /* implicit time steps taken */
+  int64_t newton_its;       /* Newton linear solves (RD) */
+  int64_t rd_assemblies;    /* Jacobian+residual assembly sweeps */
+  int64_t cg_its;           /* RD Krylov iterations = SpMV applications of A(c) */
+  int64_t mech_solves;
+  int64_t mech_cg_its;
+  double  last_newton_res;  /* ||R||_2 at exit of the last step */
+  double  last_cg_res;
+  double  last_mech_res;
+  double  ms_steps;         /* device time of glims_step calls (HIP events on the handle's stream) */
+  double  ms_spmv;          /* accumulated by glims_spmv / glims_bench_* only */
+  int64_t n_rows;           /* owned rows */
+  int64_t nnz;              /* structural nonzeros of the scalar operator (unpadded) */
+  int64_t nnz_padded;       /* stored SELL-64 entries */
+  int64_t n_corners;        /* (row, cell) incidences */
+} glims_stats;
+
+/* ---- lifetime -------------------------------------------------------------------------------------- */
+
+/* Builds the device-resident discretisation for one mesh (rank-local sub-mesh in a partitioned run):
+ * renumbering, SELL-64 sparsity, (row, cell) incidence lists, per-cell geometry.
+ * Stands in for FenicsSimulation.__init__ + _setup_functionspace (simulation_base.py:91-109,
+ * simulation_tumor_growth.py:67-72) and the cell-subdomain MeshFunction (helper_classes.py:402-444).
+ *   dim        2 (triangles) or 3 (tetrahedra);  cells are [n_cells][dim+1] vertex indices
+ *   n_own      nodes [0, n_own) are owned rows; nodes [n_own, n_nodes) are ghosts (single GPU: n_own == n_nodes)
+ *   cell_label tissue id per cell, 0 <= label < 256
+ *   device     HIP device ordinal */
+int glims_create(glims_ctx** out, int dim, int64_t n_nodes, int64_t n_own, int64_t n_cells,
+                 const double* xyz, const int32_t* cells, const int32_t* cell_label, int device);
+int glims_destroy(glims_ctx* h);
+const char* glims_last_error(const glims_ctx* h);   /* h may be NULL: error of the last failed glims_create */
+int glims_abi_version(void);
+
+/* ---- model data ------------------------------------------------------------------------------------ */
+
+/* Per-label coefficient tables (what DiscontinuousScalar.eval_cell looks up per cell, helper_classes.py:47-58,
+ * or TumorGrowthBrain's per-tissue constants, simulation_tumor_growth_brain.py:29-39,82-104).
+ * All arrays have n_labels entries; label l of glims_create indexes them. */
+int glims_set_materials(glims_ctx* h, int n_labels, const double* D, const double* rho,
+                        const double* gamma, const double* E, const double* nu);
+int glims_options_default(glims_options* opt);
+int glims_set_options(glims_ctx* h, const glims_options* opt);
+
+/* Dirichlet data (fenics.DirichletBC lists built at helper_classes.py:632-723).  n == 0 clears. */
+int glims_set_dirichlet_u(glims_ctx* h, int64_t n, const int64_t* dof_ids, const double* values);
+int glims_set_dirichlet_c(glims_ctx* h, int64_t n, const int64_t* node_ids, const double* values);
+
+/* Load vectors already integrated by the host (NULL clears):
+ *   rd_load[n_nodes]        = dt*( int s phi_i dx + oint g D phi_i ds )   (simulation_tumor_growth.py:119-120)
+ *   mech_load[n_nodes*dim]  = int f.v dx + oint g.v ds                    (simulation_tumor_growth.py:112-113) */
+int glims_set_rd_load(glims_ctx* h, const double* rd_load);
+int glims_set_mech_load(glims_ctx* h, const double* mech_load);
+
+/* (Re)assembles the time-independent operators for the current materials and dt:
+ * M, S = (1 - dt rho) M + dt K_D, the per-incidence reaction weights, and -- if with_mechanics --
+ * K_el (dim x dim blocks) and the coupling operator G.  Stands in for _setup_problem
+ * (simulation_tumor_growth.py:78-140); cheap enough to call again after a parameter change
+ * (run_for_adjoint, :142-155). */
+int glims_setup(glims_ctx* h, int with_mechanics);
+
+/* ---- state + time stepping --------------------------------------------------------------------------- */
+
+/* c[n_nodes], u[n_nodes*dim] (u may be NULL = zero).  create_initial_value_function (helper_classes.py:983-986). */
+int glims_set_state(glims_ctx* h, const double* c, const double* u);
+int glims_get_state(glims_ctx* h, double* c, double* u);   /* either may be NULL */
+
+/* n_steps backward-Euler steps of the concentration equation, entirely on the device
+ * (the `while` loop body solver.solve() + u_previous.assign, simulation_base.py:297-312, for the F_rd block). */
+int glims_step(glims_ctx* h, int n_steps);
+
+/* Solves K_el u = G c + f for the current concentration (the F_m block; it is linear in u and does not
+ * feed back into c, simulation_tumor_growth.py:110-120, so it is only needed at recorded steps). */
+int glims_solve_mechanics(glims_ctx* h);
+
+int glims_get_stats(const glims_ctx* h, glims_stats* st);
+int glims_reset_stats(glims_ctx* h);
+
+/* ---- operator hooks (tests, roofline) ---------------------------------------------------------------- */
+
+/* y = Op x, repeated `reps` times on the handle's stream and timed with HIP events (ms_total out, may be NULL).
+ * which: 0 = current RD Jacobian A(c), 1 = S, 2 = M (scalar, [n_nodes]);  3 = K_el, ([n_nodes*dim], unconstrained);
+ *        4 = G (x [n_nodes] -> y [n_nodes*dim]).  Ghost rows of y are returned as 0. */
+int glims_apply(glims_ctx* h, int which, const double* x, double* y, int reps, double* ms_total);
+
+/* Assembles A(c) and the Newton residual R(c; c_prev) for host vectors (ghost rows 0):
+ *   R = 1/2 (A(c) + S) c - M c_prev - rd_load.  R may be NULL. */
+int glims_rd_residual(glims_ctx* h, const double* c, const double* c_prev, double* R);
+
+/* ---- single-node multi-GPU (one process per GPU, RCCL over xGMI) ------------------------------------- */
+
+#define GLIMS_UNIQUE_ID_BYTES 256   /* two RCCL unique ids: halo communicator + reduction communicator */
+int glims_comm_unique_id(char id[GLIMS_UNIQUE_ID_BYTES]);           /* rank 0; broadcast by the host program */
+int glims_comm_init(glims_ctx* h, int rank, int world, const char id[GLIMS_UNIQUE_ID_BYTES]);
+
+/* Halo plan: for peer p (rank peer_rank[p]) this rank sends the values of its owned nodes
+ * send_idx[send_ptr[p] .. send_ptr[p+1]) and receives recv_count[p] values into consecutive ghost slots;
+ * ghost slots are laid out peer after peer in the order of peer_rank[], starting at node n_own, and the
+ * k-th ghost of a peer is the k-th entry of that peer's send list for this rank.  Must precede glims_setup. */
+int glims_set_halo(glims_ctx* h, int n_peers, const int32_t* peer_rank,
+                   const int64_t* send_ptr, const int32_t* send_idx, const int64_t* recv_count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLIMS_HIP_H */
