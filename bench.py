@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""
+bench.py -- DoF-updates/s of the implicit reaction-diffusion time step on a 3-D brain-extent mesh, plus the
+HBM roofline fraction of the diffusion SpMV and a CPU baseline, as ONE JSON line on rank 0.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c3|c2] [--n CELLS_PER_EDGE]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one backward-Euler step of the concentration equation (Newton + Jacobi-PCG) over the whole mesh.
+N > 1: the SAME mesh is partitioned over N GPUs (strong scaling), halo exchange + all-reduce over RCCL.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(budget_s=20.0):
+    """
+    The CPU oracle (numpy/scipy restatement, oracle/glims_oracle.py) timed on this box's host cores on a bounded
+    sample of the same workload: the brain-extent box at n=40 cells/edge (68 921 DoF), as many implicit steps as fit
+    in ~budget_s seconds (at least 2).  kind = "port": FEniCS itself is not installed here.
+    """
+    from oracle.glims_oracle import OracleTumorGrowth
+    from glimslib_amd import workloads
+    w = workloads.config_c3(n=40)
+    t0 = time.perf_counter()
+    o = OracleTumorGrowth(w.mesh.points, w.mesh.cells, w.per_cell('D'), w.per_cell('rho'), w.per_cell('gamma'),
+                          w.per_cell('E'), w.per_cell('nu'), w.dt)
+    t_setup = time.perf_counter() - t0
+    c = w.c0.copy()
+    c, _ = o.rd_step(c, rtol=1e-10, atol=1e-13, linear='cg')      # warm-up step (not timed)
+    steps = 0
+    t0 = time.perf_counter()
+    while True:
+        c, _ = o.rd_step(c, rtol=1e-10, atol=1e-13, linear='cg')
+        steps += 1
+        el = time.perf_counter() - t0
+        if steps >= 2 and el > budget_s or steps >= 50:
+            break
+    n = w.mesh.num_vertices()
+    return {"value": n * steps / el, "unit": "DoF-updates/s", "cores": 1, "kind": "port",
+            "sample": "oracle (numpy/scipy Newton + Jacobi-CG, fp64, 1 thread) on the same brain-extent box at "
+                      "n=40 (%d DoF), %d implicit steps in %.1f s (setup %.1f s excluded)" % (n, steps, el, t_setup)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default=os.environ.get("GLIMS_BENCH_WORKLOAD", "c4"))
+    ap.add_argument("--n", type=int, default=0, help="cells per edge (overrides the workload's size)")
+    ap.add_argument("--spmv-reps", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extrapolate", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            log("bench.py: --gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+            sys.exit(2)
+        args.gpus = world
+
+    import torch
+    if not torch.cuda.is_available():
+        log("bench.py: no GPU visible -- the HIP backend has no CPU fallback")
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    from glimslib_amd import workloads
+    from glimslib_amd._backend import Handle, GLIMS_OK, FLAG_EXTRAPOLATE_GUESS
+    from glimslib_amd.partition import partition_mesh
+
+    t0 = time.perf_counter()
+    w = workloads.by_name(args.workload, args.n or None)
+    n_global = w.mesh.num_vertices()
+    if rank == 0:
+        log("[bench] workload %s: %d nodes, %d cells (mesh built in %.1f s)" %
+            (w.name, n_global, w.mesh.num_cells(), time.perf_counter() - t0))
+
+    t0 = time.perf_counter()
+    if world > 1:
+        part = partition_mesh(w.mesh.points, w.mesh.cells, world, rank)
+        h = Handle(part.points, part.cells, w.cell_label[part.cell_ids], n_own=part.n_own, device=local_rank)
+        uid = [Handle.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        h.comm_init(rank, world, uid[0])
+        h.set_halo(part.peer_rank, part.send_ptr, part.send_idx, part.recv_count)
+        c0 = w.c0[part.global_ids]
+    else:
+        part = None
+        h = Handle(w.mesh.points, w.mesh.cells, w.cell_label, device=local_rank)
+        c0 = w.c0
+    t = w.tables
+    h.set_materials(t['D'], t['rho'], t['gamma'], t['E'], t['nu'])
+    h.set_options(dt=w.dt, flags=FLAG_EXTRAPOLATE_GUESS if args.extrapolate else 0)
+    h.setup(with_mechanics=False)
+    h.set_state(c0)
+    st0 = h.stats()
+    if rank == 0:
+        log("[bench] setup %.1f s; rows/rank %d, nnz %d (padded %d, +%.1f%%), corners %d" %
+            (time.perf_counter() - t0, st0['n_rows'], st0['nnz'], st0['nnz_padded'],
+             100.0 * (st0['nnz_padded'] / st0['nnz'] - 1.0), st0['n_corners']))
+    w.mesh = None   # free host memory
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up, then EXACTLY K timed steps ---------------------------------------------------------
+    status = h.step(args.warmup) if args.warmup > 0 else GLIMS_OK
+    h.reset_stats()
+    barrier()
+    t0 = time.perf_counter()
+    status |= h.step(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    st = h.stats()
+    if status != GLIMS_OK:
+        log("[bench] WARNING: solver status %d" % status)
+
+    # ---- roofline of the dominant kernel: SELL-64 SpMV with the RD Jacobian A(c) ------------------------
+    # algorithmic bytes per launch = 12*nnz + 20*rows of THIS rank's operator;
+    # duration = HIP events on the library's own stream around `reps` back-to-back launches (glims_apply).
+    x = np.random.default_rng(0).standard_normal(h.n_nodes)
+    h.apply(0, x, reps=5)
+    _, ms = h.apply(0, x, reps=args.spmv_reps)
+    t_spmv = ms * 1e-3 / args.spmv_reps
+    b_alg = workloads.b_spmv_bytes(st['nnz'], st['n_rows'])
+    achieved = b_alg / t_spmv / 1e9
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_spmv<0> (SELL-64, fp64 values, "
+                "int32 columns)", "algorithmic_bytes_per_launch": b_alg, "avg_launch_us": t_spmv * 1e6,
+                "launches_timed": args.spmv_reps}
+
+    if rank == 0:
+        out = {
+            "metric": "DoF-updates/s (implicit RD timestep) on 3D brain mesh",
+            "value": n_global * args.steps / elapsed,
+            "unit": "DoF-updates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": w.name, "dofs": n_global, "dt": w.dt,
+                       "partition": "morton-node x%d" % world if world > 1 else "single GPU",
+                       "newton_its_per_step": st['newton_its'] / max(1, args.steps),
+                       "cg_its_per_step": st['cg_its'] / max(1, args.steps),
+                       "assemblies_per_step": st['rd_assemblies'] / max(1, args.steps),
+                       "device_ms_per_step": st['ms_steps'] / max(1, args.steps),
+                       "solver_status": int(status)},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    h.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,132 @@
+"""
+Node-based mesh partition for the single-node multi-GPU path (one process per GPU, RCCL halo exchange).
+
+The reference's only parallel mode is DOLFIN's MPI domain decomposition (README.md:142-183; glimslib contributes
+nothing but ``mesh.mpi_comm()`` handles).  This module produces the same kind of decomposition as plain arrays:
+
+  * nodes are ordered along a Morton curve and cut into ``n_parts`` contiguous, equally sized ranges (owner map);
+  * rank r keeps every cell that touches one of its nodes; the cells' foreign vertices are its ghosts;
+  * local numbering = [owned (ascending global id) | ghosts grouped by owner rank, ascending global id];
+  * the send list to peer p is "my owned nodes that share a cell with a node owned by p", ascending global id --
+    which is exactly p's ghost group for this rank, so both sides derive matching lists with no communication.
+
+Everything here is host-side numpy; the exchange itself is done by libglimship (``glims_set_halo``).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def _spread_bits(x, d):
+    x = x.astype(np.uint64)
+    if d == 3:
+        x &= np.uint64(0x1fffff)
+        x = (x | (x << np.uint64(32))) & np.uint64(0x1f00000000ffff)
+        x = (x | (x << np.uint64(16))) & np.uint64(0x1f0000ff0000ff)
+        x = (x | (x << np.uint64(8))) & np.uint64(0x100f00f00f00f00f)
+        x = (x | (x << np.uint64(4))) & np.uint64(0x10c30c30c30c30c3)
+        x = (x | (x << np.uint64(2))) & np.uint64(0x1249249249249249)
+    else:
+        x &= np.uint64(0x7fffffff)
+        x = (x | (x << np.uint64(16))) & np.uint64(0x0000ffff0000ffff)
+        x = (x | (x << np.uint64(8))) & np.uint64(0x00ff00ff00ff00ff)
+        x = (x | (x << np.uint64(4))) & np.uint64(0x0f0f0f0f0f0f0f0f)
+        x = (x | (x << np.uint64(2))) & np.uint64(0x3333333333333333)
+        x = (x | (x << np.uint64(1))) & np.uint64(0x5555555555555555)
+    return x
+
+
+def morton_keys(points):
+    points = np.asarray(points, dtype=np.float64)
+    d = points.shape[1]
+    lo, hi = points.min(axis=0), points.max(axis=0)
+    qmax = 2097151.0 if d == 3 else 2147483647.0
+    scale = np.where(hi > lo, qmax / np.where(hi > lo, hi - lo, 1.0), 0.0)
+    key = np.zeros(len(points), dtype=np.uint64)
+    for a in range(d):
+        q = ((points[:, a] - lo[a]) * scale[a]).astype(np.uint64)
+        key |= _spread_bits(q, d) << np.uint64(a)
+    return key
+
+
+def node_owners(points, n_parts):
+    """owner[node] in [0, n_parts): contiguous equal-count ranges of the Morton order."""
+    n = len(points)
+    if n_parts == 1:
+        return np.zeros(n, dtype=np.int32)
+    order = np.argsort(morton_keys(points), kind='stable')
+    owner = np.empty(n, dtype=np.int32)
+    bounds = (np.arange(n_parts + 1, dtype=np.int64) * n) // n_parts
+    for r in range(n_parts):
+        owner[order[bounds[r]:bounds[r + 1]]] = r
+    return owner
+
+
+class LocalPart:
+    """Rank-local sub-mesh + halo plan (all index arrays are int64/int32 numpy)."""
+
+    def __init__(self, rank, n_parts, points, cells, cell_ids, global_ids, n_own, peer_rank, send_ptr, send_idx,
+                 recv_count):
+        self.rank = rank
+        self.n_parts = n_parts
+        self.points = points            # [n_local, d]
+        self.cells = cells              # [m_local, d+1] local vertex ids
+        self.cell_ids = cell_ids        # [m_local] global cell ids
+        self.global_ids = global_ids    # [n_local] global node id of each local node (owned first)
+        self.n_own = n_own
+        self.peer_rank = peer_rank
+        self.send_ptr = send_ptr
+        self.send_idx = send_idx        # local (owned) indices
+        self.recv_count = recv_count
+
+    @property
+    def n_local(self):
+        return len(self.global_ids)
+
+    @property
+    def owned_global(self):
+        return self.global_ids[:self.n_own]
+
+
+def build_local_part(points, cells, owner, rank, n_parts):
+    points = np.asarray(points)
+    cells = np.asarray(cells)
+    own_c = owner[cells]                                     # [M, nv]
+    mine = own_c == rank
+    cell_mask = mine.any(axis=1)
+    cell_ids = np.flatnonzero(cell_mask)
+    lc = cells[cell_ids]
+    lo = own_c[cell_ids]
+    owned = np.flatnonzero(owner == rank)                    # ascending global id
+    verts = np.unique(lc)
+    ghosts = verts[owner[verts] != rank]
+    g_owner = owner[ghosts]
+    gorder = np.lexsort((ghosts, g_owner))                   # by owner, then global id
+    ghosts = ghosts[gorder]
+    g_owner = g_owner[gorder]
+    global_ids = np.concatenate([owned, ghosts]).astype(np.int64)
+    n_own = len(owned)
+    # global -> local (only for nodes present here)
+    g2l = np.full(len(points), -1, dtype=np.int64)
+    g2l[global_ids] = np.arange(len(global_ids))
+    local_cells = g2l[lc].astype(np.int32)
+    peers, recv_count = np.unique(g_owner, return_counts=True)
+    send_idx, send_ptr = [], [0]
+    for p in peers:
+        touch = (lo == p).any(axis=1)                        # my local cells that contain a node owned by p
+        cand = lc[touch][(lo[touch] == rank)]
+        s = np.unique(cand)                                  # ascending global id == p's ghost order for me
+        send_idx.append(g2l[s])
+        send_ptr.append(send_ptr[-1] + len(s))
+    send_idx = np.concatenate(send_idx).astype(np.int32) if send_idx else np.zeros(0, dtype=np.int32)
+    return LocalPart(rank, n_parts, np.ascontiguousarray(points[global_ids]), local_cells, cell_ids, global_ids,
+                     n_own, peers.astype(np.int32), np.asarray(send_ptr, dtype=np.int64), send_idx,
+                     recv_count.astype(np.int64))
+
+
+def partition_mesh(points, cells, n_parts, rank=None):
+    """Returns the LocalPart of ``rank`` (or the list of all parts when rank is None)."""
+    owner = node_owners(points, n_parts)
+    if rank is not None:
+        return build_local_part(points, cells, owner, rank, n_parts)
+    return [build_local_part(points, cells, owner, r, n_parts) for r in range(n_parts)]
