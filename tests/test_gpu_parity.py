@@ -1,0 +1,243 @@
+"""
+GPU parity tests: the HIP path (through the C-ABI, ctypes) against the CPU oracle on the same inputs, against the
+committed golden fixtures, and through size-independent properties at BASELINE.json's full sizes.
+Tolerance stated by north_star: concentration within 1e-6 rel-L2; these tests hold the HIP path to <= 1e-8.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from glimslib_amd import workloads
+from glimslib_amd.mesh import BoxMesh, RectangleMesh
+from oracle.glims_oracle import OracleTumorGrowth, rel_l2, boundary_facets
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+TABS = dict(D=[0.0, 0.1, 0.02, 0.0], rho=[0.0, 0.1, 0.05, 0.0], gamma=[0.0, 0.2, 0.1, 0.3],
+            E=[1.0, 1e-3, 3e-3, 2e-3], nu=[0.3, 0.40, 0.45, 0.1])
+
+
+def _case(dim, ragged=False):
+    if dim == 3:
+        mesh = BoxMesh((0, 0, 0), (1.0, 1.2, 0.9), 7, 6, 5) if not ragged else BoxMesh((0, 0, 0), (1, 1, 1), 3, 2, 1)
+    else:
+        mesh = RectangleMesh((-5, -5), (5, 5), 20, 17) if not ragged else RectangleMesh((0, 0), (1, 1), 2, 1)
+    mid = mesh.cell_midpoints()
+    lab = (1 + (mid[:, 0] > mesh.points[:, 0].mean()) + (mid[:, 1] > np.percentile(mesh.points[:, 1], 80))).astype(np.int32)
+    return mesh, lab
+
+
+def _handle(backend, mesh, lab, dt, tabs=TABS, mechanics=True, **opts):
+    h = backend.Handle(mesh.points, mesh.cells, lab)
+    h.set_materials(tabs['D'], tabs['rho'], tabs['gamma'], tabs['E'], tabs['nu'])
+    h.set_options(dt=dt, **opts)
+    h.setup(mechanics)
+    return h
+
+
+def _oracle(mesh, lab, dt, tabs=TABS, **kw):
+    per = {k: np.asarray(v)[lab] for k, v in tabs.items()}
+    return OracleTumorGrowth(mesh.points, mesh.cells, per['D'], per['rho'], per['gamma'], per['E'], per['nu'], dt, **kw)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+@pytest.mark.parametrize("ragged", [False, True])
+def test_operators_match_oracle(backend, dim, ragged):
+    """M, S, A(c), K_el, G and the Newton residual, incl. tiny meshes whose only slice is mostly padding."""
+    rng = np.random.default_rng(dim)
+    mesh, lab = _case(dim, ragged)
+    n = mesh.num_vertices()
+    dt = 0.7
+    h = _handle(backend, mesh, lab, dt)
+    o = _oracle(mesh, lab, dt)
+    x, xu = rng.standard_normal(n), rng.standard_normal(n * dim)
+    Kel, G = o._mech_setup()
+    assert rel_l2(h.apply(2, x)[0], o.M @ x) < 1e-14
+    assert rel_l2(h.apply(1, x)[0], o.S @ x) < 1e-14
+    assert rel_l2(h.apply(3, xu)[0], Kel @ xu) < 1e-14
+    assert rel_l2(h.apply(4, x)[0], G @ x) < 1e-14
+    c, cp = rng.random(n), rng.random(n)
+    assert rel_l2(h.rd_residual(c, cp), o.rd_residual(c, cp)) < 1e-13
+    assert rel_l2(h.apply(0, x)[0], o.rd_jacobian(c) @ x) < 1e-14
+    st = h.stats()
+    assert st['n_rows'] == n and st['nnz'] == o.S.nnz and st['n_corners'] == mesh.cells.size
+    h.close()
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_time_stepping_matches_oracle_split_and_monolithic(backend, dim):
+    mesh, lab = _case(dim)
+    n = mesh.num_vertices()
+    dt = 0.7
+    bf, _ = boundary_facets(mesh.cells)
+    bn = np.unique(bf)
+    dofs = (bn[:, None] * dim + np.arange(dim)).ravel()
+    vals = 0.01 * np.sin(np.arange(len(dofs)))                    # inhomogeneous Dirichlet data
+    ctr = mesh.points.mean(0)
+    c0 = np.exp(-8 * ((mesh.points - ctr) ** 2).sum(1) / np.ptp(mesh.points[:, 0]) ** 2)
+    o = _oracle(mesh, lab, dt, dirichlet_u=(dofs, vals))
+    uo, co = o.run(c0, 5 * dt)
+    um, cm = o.run(c0, 5 * dt, monolithic=True)                   # what the reference's SNES+LU iterates on
+    h = _handle(backend, mesh, lab, dt)
+    h.set_dirichlet_u(dofs, vals)
+    h.set_state(c0)
+    assert h.step(5) == backend.GLIMS_OK and h.solve_mechanics() == backend.GLIMS_OK
+    c, u = h.get_state()
+    assert rel_l2(c, co) < 1e-9 and rel_l2(u, uo) < 1e-8
+    assert rel_l2(c, cm) < 1e-9 and rel_l2(u, um) < 1e-8
+    st = h.stats()
+    assert st['steps'] == 5 and st['newton_its'] >= 5 and st['mech_solves'] == 1
+    h.close()
+
+
+def test_golden_fixture_box3d(backend):
+    g = np.load(os.path.join(GOLD, "oracle_box3d.npz"))
+    mesh = BoxMesh((0.0, 0.0, 0.0), (8.0, 9.0, 7.0), 9, 8, 7)
+    tabs = dict(D=[0.0, 0.1, 0.02], rho=[0.0, 0.1, 0.05], gamma=[0.0, 0.2, 0.1], E=[1.0, 1e-3, 3e-3],
+                nu=[0.3, 0.40, 0.45])
+    f = mesh.facets()
+    bn = np.unique(f['vertices'][f['exterior']])
+    dofs = (bn[:, None] * 3 + np.arange(3)).ravel()
+    h = _handle(backend, mesh, g['label'].astype(np.int32), 1.0, tabs)
+    h.set_dirichlet_u(dofs, np.zeros(len(dofs)))
+    h.set_state(g['c0'])
+    assert h.step(int(g['n_steps'])) == 0 and h.solve_mechanics() == 0
+    c, u = h.get_state()
+    assert rel_l2(c, g['c']) < 1e-9 and rel_l2(u, g['u']) < 1e-8
+    h.close()
+
+
+def test_K1_uniform_field_recurrence_and_K2_mass_conservation(backend):
+    mesh, lab = _case(3)
+    n = mesh.num_vertices()
+    tabs = dict(D=[0, .3, .3, .3], rho=[0, .1, .1, .1], gamma=[0] * 4, E=[1] * 4, nu=[.3] * 4)
+    h = _handle(backend, mesh, lab, 1.0, tabs, mechanics=False)
+    h.set_state(np.full(n, 0.3))
+    cn = 0.3
+    for _ in range(4):
+        assert h.step(1) == 0
+        cn = (-(1 - .1) + np.sqrt((1 - .1) ** 2 + 4 * .1 * cn)) / (2 * .1)
+        c, _ = h.get_state(want_u=False)
+        assert np.abs(c - cn).max() < 1e-11
+    h.close()
+    tabs = dict(D=[0, .05, .2, 0.0], rho=[0] * 4, gamma=[0] * 4, E=[1] * 4, nu=[.3] * 4)
+    h = _handle(backend, mesh, lab, 0.5, tabs, mechanics=False)
+    c0 = np.exp(-4 * ((mesh.points - mesh.points.mean(0)) ** 2).sum(1))
+    h.set_state(c0)
+    m0 = h.apply(2, c0)[0].sum()
+    assert h.step(6) == 0
+    c, _ = h.get_state(want_u=False)
+    assert abs(h.apply(2, c)[0].sum() - m0) < 1e-11 * abs(m0)
+    h.close()
+
+
+def test_dirichlet_concentration_source_and_neumann_loads(backend):
+    mesh, lab = _case(2)
+    n = mesh.num_vertices()
+    rng = np.random.default_rng(5)
+    dt = 0.5
+    left = np.flatnonzero(mesh.points[:, 0] == mesh.points[:, 0].min())
+    cD = 0.4 + 0.1 * rng.random(len(left))
+    load = dt * 0.01 * rng.random(n)
+    mload = 1e-5 * rng.standard_normal(n * 2)
+    bottom = np.flatnonzero(mesh.points[:, 1] == mesh.points[:, 1].min())
+    dofs = (bottom[:, None] * 2 + np.arange(2)).ravel()
+    o = _oracle(mesh, lab, dt, dirichlet_c=(left, cD), dirichlet_u=(dofs, np.zeros(len(dofs))), rd_load=load,
+                mech_load=mload)
+    c0 = 0.2 * rng.random(n)
+    c0[left] = cD
+    uo, co = o.run(c0, 4 * dt)
+    h = _handle(backend, mesh, lab, dt)
+    h.set_dirichlet_c(left, cD)
+    h.set_dirichlet_u(dofs, np.zeros(len(dofs)))
+    h.set_rd_load(load)
+    h.set_mech_load(mload)
+    h.set_state(c0)
+    assert h.step(4) == 0 and h.solve_mechanics() == 0
+    c, u = h.get_state()
+    assert np.array_equal(c[left], cD)
+    assert rel_l2(c, co) < 1e-9 and rel_l2(u, uo) < 1e-8
+    h.close()
+
+
+def test_bitwise_reproducible_and_guess_option(backend):
+    mesh, lab = _case(3)
+    c0 = np.exp(-4 * ((mesh.points - mesh.points.mean(0)) ** 2).sum(1))
+    outs = []
+    for flags in (0, 0, backend.FLAG_EXTRAPOLATE_GUESS):
+        h = _handle(backend, mesh, lab, 1.0, mechanics=False, flags=flags)
+        h.set_state(c0)
+        assert h.step(6) == 0
+        outs.append(h.get_state(want_u=False)[0])
+        h.close()
+    assert np.array_equal(outs[0], outs[1])                      # no atomics anywhere: same bits every run
+    assert rel_l2(outs[2], outs[0]) < 1e-9                       # a different Newton guess, the same fixed point
+
+
+def test_failure_semantics_and_usage_errors(backend):
+    mesh, lab = _case(2)
+    h = backend.Handle(mesh.points, mesh.cells, lab)
+    with pytest.raises(backend.BackendError):
+        h.setup(True)                                             # materials not set
+    h.set_materials(TABS['D'], TABS['rho'], TABS['gamma'], TABS['E'], TABS['nu'])
+    h.set_options(dt=1.0, newton_maxit=0)
+    h.setup(False)
+    with pytest.raises(backend.BackendError):
+        h.step(1)                                                 # no state
+    h.set_state(np.random.default_rng(0).random(mesh.num_vertices()))
+    assert h.step(3) == backend.GLIMS_NOT_CONVERGED               # iteration cap -> status, not an exception
+    assert h.stats()['steps'] == 1                                # stops at the failing step
+    with pytest.raises(backend.BackendError):
+        h.solve_mechanics()                                       # mechanics operators were not assembled
+    with pytest.raises(backend.BackendError):
+        backend.Handle(mesh.points, mesh.cells, lab + 300)        # label outside [0, 256)
+    bad = mesh.cells.copy()
+    bad[0, 0] = 10 ** 6
+    with pytest.raises(backend.BackendError):
+        backend.Handle(mesh.points, bad, lab)
+    h.close()
+
+
+# ---- full-size properties (BASELINE configs C2 / C3) ---------------------------------------------------------------
+def test_full_size_c2_properties(backend):
+    """C2 (103 823 DoF): oracle-free checks -- K1 recurrence on a uniform field, mass conservation for rho = 0,
+    linearity of the operator hook, symmetry x.Ay == y.Ax."""
+    w = workloads.config_c2()
+    n = w.mesh.num_vertices()
+    rng = np.random.default_rng(2)
+    h = _handle(backend, w.mesh, w.cell_label, w.dt, w.tables, mechanics=False)
+    h.set_state(np.full(n, 0.25))
+    assert h.step(2) == 0
+    cn = 0.25
+    for _ in range(2):
+        cn = (-(1 - .1) + np.sqrt((1 - .1) ** 2 + 4 * .1 * cn)) / (2 * .1)
+    assert np.abs(h.get_state(want_u=False)[0] - cn).max() < 1e-11
+    x, y = rng.standard_normal(n), rng.standard_normal(n)
+    Ax, Ay = h.apply(0, x)[0], h.apply(0, y)[0]
+    assert abs(x @ Ay - y @ Ax) < 1e-11 * abs(x @ Ay)
+    assert rel_l2(h.apply(0, 2 * x - 3 * y)[0], 2 * Ax - 3 * Ay) < 1e-14
+    h.close()
+    tabs = dict(w.tables)
+    tabs['rho'] = [0.0, 0.0]
+    h = _handle(backend, w.mesh, w.cell_label, w.dt, tabs, mechanics=False)
+    h.set_state(w.c0)
+    m0 = h.apply(2, w.c0)[0].sum()
+    assert h.step(3) == 0
+    assert abs(h.apply(2, h.get_state(want_u=False)[0])[0].sum() - m0) < 1e-11 * m0
+    h.close()
+
+
+def test_c2_sized_step_matches_oracle_cg(backend):
+    """C2 mesh at n=24 (15 625 DoF): oracle with its own CG at 1e-13 finishes in seconds."""
+    w = workloads.config_c2(24)
+    o = OracleTumorGrowth(w.mesh.points, w.mesh.cells, w.per_cell('D'), w.per_cell('rho'), 0.0, 1.0, 0.3, w.dt)
+    c = w.c0.copy()
+    for _ in range(3):
+        c, _ = o.rd_step(c, linear='cg')
+    h = _handle(backend, w.mesh, w.cell_label, w.dt, w.tables, mechanics=False)
+    h.set_state(w.c0)
+    assert h.step(3) == 0
+    assert rel_l2(h.get_state(want_u=False)[0], c) < 1e-9
+    h.close()

@@ -1,0 +1,244 @@
+"""
+Host-side helper classes against the structural assertions of the reference's own unit tests
+(glimslib/simulation_helpers/test_unit_subDomains.py, test_unit_boundaryConditions.py,
+test_unit_simulationParameters.py) -- same fixtures, same expected counts.  No GPU needed.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from glimslib_amd import fenics_local as fenics
+from glimslib_amd.simulation_helpers.helper_classes import (SubDomains, FunctionSpace, BoundaryConditions, Parameters,
+                                                            Results, TimeSeriesMultiData, DiscontinuousScalar)
+
+
+class Boundary(fenics.SubDomain):
+    def inside(self, x, on_boundary):
+        return on_boundary
+
+
+class BoundaryPos(fenics.SubDomain):
+    def inside(self, x, on_boundary):
+        return on_boundary and x[1] > 0
+
+
+class BoundaryNeg(fenics.SubDomain):
+    def inside(self, x, on_boundary):
+        return on_boundary and x[1] < 0
+
+
+def _mixed_space(mesh):
+    fs = FunctionSpace(mesh)
+    fs.init_function_space({0: mesh.dim, 1: 1}, {0: 'displacement', 1: 'concentration'})
+    return fs
+
+
+# ---- test_unit_subDomains.py:10-90 ------------------------------------------------------------------------
+@pytest.fixture
+def sd5():
+    mesh = fenics.RectangleMesh(fenics.Point(-2, -2), fenics.Point(2, 2), 5, 5)
+    labels = fenics.Expression('(x[0]>=0) ? (1.0) : (2.0)', degree=1)
+    tmap = {0: 'outside', 1: 'tissue', 2: 'tumor'}
+    return mesh, SubDomains(mesh), labels, tmap
+
+
+def test_setup_subdomains(sd5):
+    mesh, sd, labels, tmap = sd5
+    sd.setup_subdomains(label_function=labels)
+    assert set(np.unique(sd.subdomains.array())) == {1, 2}                         # :45-48
+    sd.setup_subdomains(replace=True)
+    assert set(np.unique(sd.subdomains.array())) == {0}                            # :49-51
+
+
+def test_setup_boundaries_and_measures(sd5):
+    mesh, sd, labels, tmap = sd5
+    sd.setup_subdomains(label_function=labels)
+    sd.setup_boundaries(tissue_map=tmap, boundary_fct_dict={'boundary_1': Boundary()})
+    assert set(np.unique(sd.subdomain_boundaries.array())) == {2, 3}               # :59-60
+    assert set(sd.subdomain_boundaries_id_dict.values()) == {0, 1, 2, 3}           # :61-62
+    sd.setup_measures()
+    tid = sd.subdomain_boundaries_id_dict['tissue_tumor']
+    assert (sd.ds.subdomain_data().array() == tid).sum() == 5                      # :81-82  (== ny)
+    bid = sd.named_boundaries_id_dict['boundary_1']
+    assert (sd.dsn.subdomain_data().array() == bid).sum() == 2 * (5 + 5)           # :84-85
+    # the label rule int(label(midpoint)) puts the interface on the grid line x = -0.4
+    f = mesh.facets()
+    xs = mesh.points[f['vertices'][sd.subdomain_boundaries.array() == tid]][:, :, 0]
+    assert np.allclose(xs, -0.4)
+    assert sd.get_subdomain_id('tissue') == 1                                      # :96-99
+
+
+def test_label_function_variants_agree(sd5):
+    mesh, sd, labels, tmap = sd5
+    sd.setup_subdomains(label_function=labels)
+    a = sd.subdomains.array().copy()
+    nodal = np.where(mesh.points[:, 0] >= 0, 1.0, 2.0)
+    sd.setup_subdomains(label_function=nodal, replace=True)
+    assert (sd.subdomains.array() == a).all()
+    sd.setup_subdomains(label_function=nodal[mesh.cells], replace=True)             # DG1 vertex values
+    assert (sd.subdomains.array() == a).all()
+    sd.setup_subdomains(subdomains=a, replace=True)
+    assert (sd.subdomains.array() == a).all()
+
+
+def test_discontinuous_scalar_is_indexed_by_tissue_id_whatever_the_dict_order():
+    mesh = fenics.RectangleMesh((0, 0), (4, 1), 4, 1)
+    sd = SubDomains(mesh)
+    lab = np.array([1, 1, 3, 3, 2, 2, 4, 4])
+    sd.setup_subdomains(subdomains=lab)
+    # literal order of test_case_comparison_3D_atlas.py:46-49
+    sd.setup_boundaries(tissue_map={1: 'CSF', 3: 'WM', 2: 'GM', 4: 'Ventricles'})
+    ds = sd.create_discontinuous_scalar_from_parameter_map({'CSF': 0.0, 'WM': 0.05, 'GM': 0.01, 'Ventricles': 0.0}, 'D')
+    np.testing.assert_array_equal(ds.cell_values(), [0, 0, .05, .05, .01, .01, 0, 0])
+    # interface names follow ascending ids: CSF_GM, CSF_WM, CSF_Ventricles, GM_WM, GM_Ventricles, WM_Ventricles
+    assert list(sd.subdomain_boundaries_id_dict) == ['CSF_GM', 'CSF_WM', 'CSF_Ventricles', 'GM_WM', 'GM_Ventricles',
+                                                     'WM_Ventricles', 'no_boundary']
+    ids = sd.subdomain_boundaries.array()
+    assert (ids == sd.subdomain_boundaries_id_dict['GM_WM']).sum() == 1            # pair (3,2) is found (q4)
+    assert (ids == sd.subdomain_boundaries_id_dict['CSF_WM']).sum() == 1
+    assert (ids == sd.subdomain_boundaries_id_dict['GM_Ventricles']).sum() == 1
+
+
+# ---- test_unit_boundaryConditions.py:17-108 -----------------------------------------------------------------
+@pytest.fixture
+def bc10():
+    mesh = fenics.RectangleMesh(fenics.Point(-2, -2), fenics.Point(2, 2), 10, 10)
+    fs = _mixed_space(mesh)
+    sd = SubDomains(mesh)
+    sd.setup_subdomains(label_function=fenics.Expression('(x[0]>=0) ? (1.0) : (2.0)', degree=1))
+    sd.setup_boundaries(tissue_map={0: 'outside', 1: 'tissue', 2: 'tumor'},
+                        boundary_fct_dict={'boundary_pos': BoundaryPos(), 'boundary_neg': BoundaryNeg()})
+    sd.setup_measures()
+    return mesh, fs, sd, BoundaryConditions(fs, sd)
+
+
+def test_dirichlet_and_neumann_counts(bc10):
+    mesh, fs, sd, bcs = bc10
+    zero = fenics.Constant((0.0, 0.0))
+    bcs.setup_dirichlet_boundary_conditions({
+        'clamped_0': {'bc_value': zero, 'boundary': BoundaryPos(), 'subspace_id': 0},
+        'clamped_1': {'bc_value': zero, 'subdomain_boundary': 'tissue_tumor', 'subspace_id': 0},
+        'clamped_pos': {'bc_value': zero, 'named_boundary': 'boundary_pos', 'subspace_id': 0},
+        'clamped_neg': {'bc_value': zero, 'named_boundary': 'boundary_neg', 'subspace_id': 0}})
+    assert len(bcs.dirichlet_bcs) == 4                                             # :80-83
+    bcs.setup_von_neumann_boundary_conditions({
+        'flux_boundary_pos': {'bc_value': fenics.Constant(1.0), 'named_boundary': 'boundary_pos', 'subspace_id': 1},
+        'flux_boundary_neg': {'bc_value': fenics.Constant(-5.0), 'named_boundary': 'boundary_neg', 'subspace_id': 1}})
+    assert len(bcs.von_neumann_bcs) == 2                                           # :85-88
+    # :90-108 -- assembled Neumann functional for c = 1, param = 1; analytic value 1*7.2 - 5*7.2
+    load = bcs.implement_von_neumann_bc(None, subspace_id=1)
+    assert abs(load.sum() - (-28.8)) < 1e-12
+    dofs, vals = bcs.dirichlet_dofs(0)
+    assert len(dofs) == len(set(dofs)) and (vals == 0).all() and len(dofs) > 40
+
+
+def test_stale_bc_keys_are_skipped_like_in_the_reference(bc10, caplog):
+    mesh, fs, sd, bcs = bc10
+    # test_case_simulation_tumor_growth_3D_atlas.py:54 uses 'boundary_name', which _construct_dirichlet_bc ignores (q3)
+    bcs.setup_dirichlet_boundary_conditions({'clamped': {'bc_value': fenics.Constant((0., 0.)),
+                                                         'boundary_name': 'boundary_pos', 'subspace_id': 0}})
+    assert bcs.dirichlet_bcs == []
+    assert any('incomplete' in r.message for r in caplog.records)
+    bcs.setup_dirichlet_boundary_conditions(None)                                   # q5: None / {} = no BCs
+    bcs.setup_dirichlet_boundary_conditions({})
+    assert bcs.dirichlet_bcs == []
+
+
+# ---- test_unit_simulationParameters.py ----------------------------------------------------------------------
+def test_parameters_bookkeeping():
+    mesh = fenics.RectangleMesh((-2, -2), (2, 2), 5, 5)
+    fs = _mixed_space(mesh)
+    sd = SubDomains(mesh)
+    sd.setup_subdomains(label_function=fenics.Expression('(x[0]>=0) ? (1.0) : (2.0)', degree=1))
+    sd.setup_boundaries(tissue_map={0: 'outside', 1: 'tissue', 2: 'tumor'})
+    p = Parameters(fs, sd, time_dependent=True)
+    p.set_initial_value_expressions({0: fenics.Constant((0., 0.)), 1: fenics.Expression('x[0] > 0 ? 1.0 : 0.0', degree=1)})
+    assert p.get_iv_map() == {0: 'iv_displacement', 1: 'iv_concentration'}
+    p.define_required_params(['a', 'b'])
+    p.define_optional_params(['c'])
+    assert set(p.params_required) == {'a', 'b', 'sim_time', 'sim_time_step'}
+    assert not p.init_parameters({'a': 1.0})                                       # incomplete -> warning, nothing set
+    assert not hasattr(p, 'a')
+    assert p.init_parameters({'a': 1.0, 'b': {'outside': 0., 'tissue': 1.0, 'tumor': 0.1}, 'sim_time': 10,
+                              'sim_time_step': 1, 'zzz': 5})
+    assert p.a == 1.0 and isinstance(p.b, DiscontinuousScalar) and p.b_dict['tumor'] == 0.1 and not hasattr(p, 'zzz')
+    u0 = p.create_initial_value_function()
+    assert u0.components[0].shape == (36, 2) and set(np.unique(u0.components[1])) == {0.0, 1.0}
+    p.time_update_parameters(3.0)
+
+
+def test_expression_parser():
+    X = np.array([[2.5, 2.5], [0.0, 0.0], [2.6, 2.7], [-1.0, 4.0]])
+    e = fenics.Expression('sqrt(pow(x[0]-x0,2)+pow(x[1]-y0,2)) < 0.4 ? (1.0) : (0.0)', degree=1, x0=2.5, y0=2.5)
+    np.testing.assert_array_equal(e(X), [1, 0, 1, 0])
+    e.x0 = -1.0
+    e.y0 = 4.0
+    np.testing.assert_array_equal(e(X), [0, 0, 0, 1])
+    v = fenics.Expression(('x[0]*t', '2.0'), degree=1, t=0.0)
+    v.t = 2.0
+    np.testing.assert_allclose(v(X), np.stack([2 * X[:, 0], np.full(4, 2.0)], 1))
+    nested = fenics.Expression('x[0] > 0 ? (x[1] > 3 ? 2.0 : 1.0) : 0.0', degree=1)
+    np.testing.assert_array_equal(nested(X), [1, 0, 1, 0])
+    both = fenics.Expression('(x[0] > 0 && x[1] > 2.6) || x[0] < -0.5 ? 1.0 : 0.0', degree=1)
+    np.testing.assert_array_equal(both(X), [0, 0, 1, 1])
+
+
+def test_mesh_generators():
+    m = fenics.RectangleMesh((-5, -5), (5, 5), 50, 50)
+    assert m.num_vertices() == 2601 and m.num_cells() == 5000                      # BASELINE C1
+    assert abs(m.cell_volumes().sum() - 100.0) < 1e-10
+    np.testing.assert_array_equal(m.cells[0], [0, 1, 52])                          # DOLFIN 'right' diagonal
+    np.testing.assert_array_equal(m.cells[1], [0, 51, 52])
+    b = fenics.BoxMesh((0, 0, 0), (1, 2, 3), 3, 4, 5)
+    assert b.num_vertices() == 4 * 5 * 6 and b.num_cells() == 6 * 60
+    assert abs(b.cell_volumes().sum() - 6.0) < 1e-12
+    f = b.facets()
+    assert f['exterior'].sum() == 2 * 2 * (3 * 4 + 3 * 5 + 4 * 5)
+    from oracle.glims_oracle import box_mesh, rectangle_mesh
+    po, co = box_mesh((0, 0, 0), (1, 2, 3), 3, 4, 5)
+    assert np.array_equal(co, b.cells) and np.allclose(po, b.points)
+    po, co = rectangle_mesh((-5, -5), (5, 5), 50, 50)
+    assert np.array_equal(co, m.cells) and np.allclose(po, m.points)
+
+
+def test_results_roundtrip(tmp_path):
+    mesh = fenics.RectangleMesh((0, 0), (1, 1), 3, 3)
+    fs = _mixed_space(mesh)
+    res = Results(fs, output_dir=str(tmp_path))
+    f = fs.new_function()
+    for step in range(3):
+        f.components[1][:] = step
+        f.components[0][:, 0] = -step
+        res.add_to_results(float(step), step, step, f)
+    f.components[1][:] = 99                                                         # stored copies are deep (hc:1131)
+    assert res.get_recording_steps() == [0, 1, 2]
+    assert (res.get_solution_function(subspace_name='concentration', recording_step=1).values() == 1).all()
+    assert (res.get_solution_function(subspace_id=0).values()[:, 0] == -2).all()
+    path = res.save_solution_hdf5()
+    res2 = Results(fs, output_dir=str(tmp_path))
+    res2.data.load_from_hdf5(os.path.join(str(tmp_path), 'solution_timeseries.h5'))
+    assert res2.get_recording_steps() == [0, 1, 2]
+    assert (res2.get_solution_function(subspace_id=1, recording_step=2).values() == 2).all()
+    res.save_solution(2, 2.0, method='vtk')
+    txt = open(os.path.join(str(tmp_path), 'solution_00002.vtu')).read()
+    assert 'concentration' in txt and 'displacement' in txt and 'NumberOfPoints="16"' in txt
+
+
+def test_partition_plans_are_mutually_consistent():
+    from glimslib_amd.partition import partition_mesh
+    mesh = fenics.BoxMesh((0, 0, 0), (1, 1, 1), 6, 5, 4)
+    parts = partition_mesh(mesh.points, mesh.cells, 3)
+    owned = np.concatenate([p.owned_global for p in parts])
+    assert sorted(owned) == list(range(mesh.num_vertices()))                        # every node owned exactly once
+    for p in parts:
+        off = p.n_own
+        for q, cnt in zip(p.peer_rank, p.recv_count):
+            other = parts[q]
+            j = list(other.peer_rank).index(p.rank)
+            sent = other.global_ids[other.send_idx[other.send_ptr[j]:other.send_ptr[j + 1]]]
+            np.testing.assert_array_equal(sent, p.global_ids[off:off + cnt])        # k-th ghost == k-th sent value
+            off += cnt
+        assert off == p.n_local
+        # every cell touching an owned node is local, with consistent local numbering
+        np.testing.assert_array_equal(p.global_ids[p.cells], mesh.cells[p.cell_ids])
