@@ -2,6 +2,7 @@
 #include "glims_internal.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -10,6 +11,11 @@ void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* s
                     double* partials, int partial_off, const int* done);
 
 namespace {
+
+void read_tuning(glims_ctx* h) {
+  if (const char* e = getenv("GLIMS_SPMV_UNROLL")) h->tune_spmv_unroll = atoi(e);
+  if (const char* e = getenv("GLIMS_XCD_REMAP")) h->tune_xcd_remap = atoi(e);
+}
 
 std::mutex g_err_mu;
 std::string g_create_err;
@@ -120,6 +126,7 @@ int glims_create(glims_ctx** out, int dim, int64_t n_nodes, int64_t n_own, int64
     h->n_cells = n_cells;
     glims_options_default(&h->opt);
     std::memset(&h->stats, 0, sizeof(h->stats));
+    read_tuning(h);
     GL_HIP(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
     GL_HIP(hipStreamCreateWithFlags(&h->st_comm, hipStreamNonBlocking));
     GL_HIP(hipEventCreate(&h->ev_a));
@@ -179,9 +186,12 @@ int glims_create(glims_ctx** out, int dim, int64_t n_nodes, int64_t n_own, int64
     h->cg_u.alloc_zero(nn, h->st);
     h->cg_w.alloc_zero(nn, h->st);
     h->cg_r.alloc_zero(nn, h->st);
+    h->cg_r2.alloc_zero(nn, h->st);
+    h->b2.alloc_zero(nn, h->st);
     h->stage.alloc_zero(nd, h->st);
     h->mat.alloc_zero(5 * GL_MAX_LABELS, h->st);
     h->partials.alloc_zero((size_t)p.n_slices * 3 + 4096, h->st);
+    h->partials2.alloc_zero((size_t)(p.n_slices * 3 + 4096) / 1024 * 3 + 64, h->st);
     h->red.alloc_zero(4, h->st);
     h->scal.alloc_zero(SC_COUNT, h->st);
     h->done.alloc_zero(1, h->st);
@@ -248,6 +258,7 @@ int glims_set_materials(glims_ctx* h, int n_labels, const double* D, const doubl
     GL_HIP(hipStreamSynchronize(h->st));
     h->have_materials = true;
     h->is_setup = false;
+    h->pending = false;
     return GLIMS_OK;
   });
 }
@@ -259,12 +270,14 @@ int glims_set_options(glims_ctx* h, const glims_options* opt) {
     GL_REQUIRE(opt->newton_maxit >= 0 && opt->cg_maxit > 0 && opt->mech_maxit > 0, "bad iteration caps");
     if (opt->dt != h->opt.dt) h->is_setup = false;
     h->opt = *opt;
+    h->pending = false;
     return GLIMS_OK;
   });
 }
 
 int glims_set_dirichlet_c(glims_ctx* h, int64_t n, const int64_t* node_ids, const double* values) {
   return guarded(h, [&]() {
+    h->pending = false;
     if (n <= 0) {
       h->have_fixed_c = false;
       return GLIMS_OK;
@@ -314,6 +327,7 @@ int glims_set_dirichlet_u(glims_ctx* h, int64_t n, const int64_t* dof_ids, const
 
 int glims_set_rd_load(glims_ctx* h, const double* f) {
   return guarded(h, [&]() {
+    h->pending = false;
     if (!f) {
       h->have_load_rd = false;
       return GLIMS_OK;
@@ -355,6 +369,7 @@ int glims_setup(glims_ctx* h, int with_mechanics) {
       }
       if (!h->m_uD.p) h->m_uD.alloc_zero(nd, h->st);
     }
+    h->pending = false;
     gl_assemble_static(h, with_mechanics);
     GL_HIP(hipStreamSynchronize(h->st));
     h->is_setup = true;
@@ -366,6 +381,7 @@ int glims_setup(glims_ctx* h, int with_mechanics) {
 int glims_set_state(glims_ctx* h, const double* c, const double* u) {
   return guarded(h, [&]() {
     GL_REQUIRE(c, "null concentration");
+    h->pending = false;
     to_device_perm(h, c, h->c.p, 1);
     if (h->U.p) {
       if (u)
@@ -423,6 +439,7 @@ int glims_apply(glims_ctx* h, int which, const double* x, double* y, int reps, d
     GL_REQUIRE(h->is_setup, "glims_apply before glims_setup");
     GL_REQUIRE(x && y && reps >= 1, "bad arguments");
     GL_REQUIRE(which >= 0 && which <= 4, "unknown operator");
+    read_tuning(h);
     const int d = h->dim;
     const bool blk_in = which == 3, blk_out = which == 3 || which == 4;
     if (blk_out) GL_REQUIRE(h->have_mech, "mechanics operators not assembled");
@@ -464,7 +481,8 @@ int glims_rd_residual(glims_ctx* h, const double* c, const double* c_prev, doubl
     to_device_perm(h, c_prev, dcp.p, 1);
     gl_launch_spmv(h, h->st, h->pat.n_slices, nullptr, h->vM.p, dcp.p, h->b.p, nullptr,
                    h->have_load_rd ? h->load_rd.p : nullptr, nullptr, nullptr, 0, nullptr);
-    gl_rd_assemble(h, dc.p, h->b.p, h->cg_r.p, h->partials.p);
+    h->pending = false;
+    gl_rd_assemble(h, dc.p, h->b.p, nullptr, h->cg_r.p, h->cg_r2.p, h->partials.p);
     GL_HIP(hipStreamSynchronize(h->st));
     if (R) {
       from_device_perm(h, h->cg_r.p, R, 1, h->n_own);

@@ -127,19 +127,23 @@ struct glims_ctx {
 
   glims_options opt;
   glims_stats stats;
+  // tuning knobs (env GLIMS_SPMV_UNROLL = 2|4|8, GLIMS_XCD_REMAP = 0|1), read at glims_create and by glims_apply
+  int tune_spmv_unroll = 4, tune_xcd_remap = 1;
 
   // scalar operator planes (SELL-64 layout) and block planes
   dvec<double> vM, vS, vA, vKel, vG;
   // vectors (internal numbering; length n_nodes unless noted)
   dvec<double> c, c_old, b, load_rd, dinv;
-  dvec<double> cg_p, cg_s, cg_u, cg_w, cg_r;                // scalar CG work vectors
+  dvec<double> cg_p, cg_s, cg_u, cg_w, cg_r, cg_r2, b2;     // scalar CG work vectors; r2/b2: speculative next step
+  bool pending = false;                                      // cg_r / b / vA already hold the first assembly of the next step
+  double pending_r0 = 0.0;
   dvec<double> U, mload, m_rhs, m_x, m_p, m_s, m_u, m_w, m_r, m_dinv, m_uD;   // mechanics, [n_nodes*dim]
   dvec<uint8_t> fixed_c, fixed_u;
   dvec<double> cD;
   bool have_fixed_c = false, have_fixed_u = false, have_load_rd = false, have_mload = false;
   dvec<double> stage;                      // staging for host<->device permuted transfers [n_nodes*dim]
 
-  dvec<double> partials;                   // per-block partial sums
+  dvec<double> partials, partials2;        // per-block partial sums (stage 1 / stage 2 of the reduction)
   dvec<double> red;                        // [4] reduced sums
   dvec<double> scal;                       // [SC_COUNT] recurrence scalars
   dvec<int> done;                          // [1] 0 running, 1 converged, 2 non-finite, 3 breakdown
@@ -162,7 +166,10 @@ struct glims_ctx {
 // kernels.hip ---------------------------------------------------------------------------------------
 void gl_compute_egeo(glims_ctx* h, const double* d_xyz, const int32_t* d_cells);
 void gl_assemble_static(glims_ctx* h, int with_mechanics);
-void gl_rd_assemble(glims_ctx* h, const double* c, const double* b, double* r_out, double* red_out /*dev [1]*/);
+int gl_rd_grid(const glims_ctx* h);
+int gl_spmv_grid(int n_launch);
+void gl_rd_assemble(glims_ctx* h, const double* c, const double* b, const double* b2, double* r_out, double* r2_out,
+                    double* partials /*[gl_rd_grid][2]*/);
 void gl_spmv_scalar(glims_ctx* h, const double* vals, const double* x, double* y, bool masked);
 void gl_apply_G(glims_ctx* h, const double* c, double* y);
 void gl_spmv_block(glims_ctx* h, const double* x, double* y, bool masked);

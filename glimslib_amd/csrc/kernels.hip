@@ -8,6 +8,8 @@
 // of FEM assembly needs neither atomics nor colouring and is bitwise reproducible.
 #include "glims_internal.h"
 
+#include <algorithm>
+
 namespace {
 
 __device__ __forceinline__ int xcd_remap(int b, int nb) {
@@ -163,89 +165,147 @@ __global__ __launch_bounds__(GL_WAVE) void k_assemble_static(
 // ---------------------------------------------------------------------------------------------------
 template <int NV>
 __global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
-    int64_t n_own, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ cols,
+    int n_slices, int chunk, int64_t n_own, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ cols,
     const int64_t* __restrict__ cslice_ptr, const uint32_t* __restrict__ cslots, const double* __restrict__ cw,
     const uint8_t* __restrict__ diag_k, const double* __restrict__ vS, double* __restrict__ vA,
-    const double* __restrict__ c, const double* __restrict__ b, double* __restrict__ r_out,
-    double* __restrict__ dinv, const uint8_t* __restrict__ fixed, double two_dt, double* __restrict__ partials,
-    int max_len) {
+    const double* __restrict__ c, const double* __restrict__ b, const double* __restrict__ b2,
+    double* __restrict__ r_out, double* __restrict__ r2_out, double* __restrict__ dinv,
+    const uint8_t* __restrict__ fixed, double two_dt, double* __restrict__ partials, int max_len, int remap) {
   extern __shared__ double lds[];
   double* acc = lds;
   double* cn = lds + (size_t)max_len * GL_WAVE;
-  const int s = blockIdx.x, lane = threadIdx.x;
-  const int64_t row = (int64_t)s * GL_WAVE + lane;
-  const int64_t base = slice_ptr[s], cbase = cslice_ptr[s];
-  const int len = (int)((slice_ptr[s + 1] - base) >> 6), clen = (int)((cslice_ptr[s + 1] - cbase) >> 6);
-  const int32_t* cc = cols + base + lane;
-#pragma unroll 4
-  for (int k = 0; k < len; ++k) {
-    cn[k * GL_WAVE + lane] = c[cc[(int64_t)k * GL_WAVE]];
-    acc[k * GL_WAVE + lane] = 0.0;
-  }
-  const int dk = diag_k[row];
-  const double ci = cn[dk * GL_WAVE + lane];
-  const uint32_t* sl = cslots + cbase + lane;
-  const double* wp = cw + cbase + lane;
-#pragma unroll 2
-  for (int q = 0; q < clen; ++q) {
-    const double w = wp[(int64_t)q * GL_WAVE];
-    const uint32_t slots = sl[(int64_t)q * GL_WAVE];
-    if (w == 0.0) continue;   // padding, or a cell without proliferation: contributes nothing to N(c)
-    int k[NV];
-    double cv[NV], st = 0.0;
+  const int lane = threadIdx.x;
+  const int blk = remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int s_end = min(n_slices, (blk + 1) * chunk);
+  double rr = 0.0, rr2 = 0.0;
+  for (int s = blk * chunk; s < s_end; ++s) {
+    const int64_t row = (int64_t)s * GL_WAVE + lane;
+    const int64_t base = slice_ptr[s], cbase = cslice_ptr[s];
+    const int len = (int)((slice_ptr[s + 1] - base) >> 6), clen = (int)((cslice_ptr[s + 1] - cbase) >> 6);
+    const int32_t* cc = cols + base + lane;
+    // phase 1: gather the row's neighbour values of c into the lane's LDS column (same pattern as the SpMV gather)
+    {
+      int k = 0;
+      for (; k + 8 <= len; k += 8) {
+        int32_t ci8[8];
+        double x8[8];
 #pragma unroll
-    for (int m = 0; m < NV; ++m) {
-      k[m] = (int)((slots >> (8 * m)) & 255u);
-      cv[m] = cn[k[m] * GL_WAVE + lane];
-      st += cv[m];
-    }
+        for (int j = 0; j < 8; ++j) ci8[j] = cc[(int64_t)(k + j) * GL_WAVE];
 #pragma unroll
-    for (int m = 0; m < NV; ++m) {
-      const double v = (k[m] == dk) ? w * (4.0 * ci + 2.0 * st) : w * (ci + cv[m] + st);
-      acc[k[m] * GL_WAVE + lane] += v;
+        for (int j = 0; j < 8; ++j) x8[j] = c[ci8[j]];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          cn[(k + j) * GL_WAVE + lane] = x8[j];
+          acc[(k + j) * GL_WAVE + lane] = 0.0;
+        }
+      }
+      for (; k < len; ++k) {
+        cn[k * GL_WAVE + lane] = c[cc[(int64_t)k * GL_WAVE]];
+        acc[k * GL_WAVE + lane] = 0.0;
+      }
     }
-  }
-  const double* sv = vS + base + lane;
-  double* av = vA + base + lane;
-  double r = 0.0, d = 1.0;
-#pragma unroll 4
-  for (int k = 0; k < len; ++k) {
-    const double Sv = sv[(int64_t)k * GL_WAVE];
-    const double Av = Sv + two_dt * acc[k * GL_WAVE + lane];
-    av[(int64_t)k * GL_WAVE] = Av;
-    r += 0.5 * (Av + Sv) * cn[k * GL_WAVE + lane];
-    if (k == dk) d = Av;
-  }
-  double rr = 0.0;
-  if (row < n_own) {
-    const bool fx = fixed && fixed[row];
-    const double res = fx ? 0.0 : b[row] - r;
-    r_out[row] = res;
-    dinv[row] = fx ? 1.0 : 1.0 / d;
-    rr = res * res;
+    const int dk = diag_k[row];
+    const double ci = cn[dk * GL_WAVE + lane];
+    const uint32_t* sl = cslots + cbase + lane;
+    const double* wp = cw + cbase + lane;
+    // phase 2: element contributions, 4 incidences' records in flight per lane
+    auto corner = [&](double w, uint32_t slots) {
+      if (w == 0.0) return;   // padding, or a cell without proliferation: contributes nothing to N(c)
+      int k[NV];
+      double cv[NV], av[NV], st = 0.0;
+#pragma unroll
+      for (int m = 0; m < NV; ++m) {
+        k[m] = (int)((slots >> (8 * m)) & 255u);
+        cv[m] = cn[k[m] * GL_WAVE + lane];
+        av[m] = acc[k[m] * GL_WAVE + lane];   // the NV slots of one cell are distinct: read all, then write all
+      }
+#pragma unroll
+      for (int m = 0; m < NV; ++m) st += cv[m];
+#pragma unroll
+      for (int m = 0; m < NV; ++m)
+        acc[k[m] * GL_WAVE + lane] = av[m] + ((k[m] == dk) ? w * (4.0 * ci + 2.0 * st) : w * (ci + cv[m] + st));
+    };
+    {
+      int q = 0;
+      for (; q + 4 <= clen; q += 4) {
+        double w4[4];
+        uint32_t s4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          w4[j] = wp[(int64_t)(q + j) * GL_WAVE];
+          s4[j] = sl[(int64_t)(q + j) * GL_WAVE];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) corner(w4[j], s4[j]);
+      }
+      for (; q < clen; ++q) corner(wp[(int64_t)q * GL_WAVE], sl[(int64_t)q * GL_WAVE]);
+    }
+    // phase 3: A = S + 2 dt N(c), residual 1/2 (A + S) c, diagonal
+    const double* sv = vS + base + lane;
+    double* av = vA + base + lane;
+    double r = 0.0, d = 1.0;
+    {
+      int k = 0;
+      for (; k + 8 <= len; k += 8) {
+        double S8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) S8[j] = sv[(int64_t)(k + j) * GL_WAVE];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const double Av = S8[j] + two_dt * acc[(k + j) * GL_WAVE + lane];
+          av[(int64_t)(k + j) * GL_WAVE] = Av;
+          r += 0.5 * (Av + S8[j]) * cn[(k + j) * GL_WAVE + lane];
+          if (k + j == dk) d = Av;
+        }
+      }
+      for (; k < len; ++k) {
+        const double Sv = sv[(int64_t)k * GL_WAVE];
+        const double Av = Sv + two_dt * acc[k * GL_WAVE + lane];
+        av[(int64_t)k * GL_WAVE] = Av;
+        r += 0.5 * (Av + Sv) * cn[k * GL_WAVE + lane];
+        if (k == dk) d = Av;
+      }
+    }
+    if (row < n_own) {
+      const bool fx = fixed && fixed[row];
+      const double res = fx ? 0.0 : b[row] - r;
+      r_out[row] = res;
+      dinv[row] = fx ? 1.0 : 1.0 / d;
+      rr += res * res;
+      if (b2) {
+        const double res2 = fx ? 0.0 : b2[row] - r;
+        r2_out[row] = res2;
+        rr2 += res2 * res2;
+      }
+    }
   }
   rr = wave_sum(rr);
-  if (lane == 0) partials[s] = rr;
+  rr2 = wave_sum(rr2);
+  if (lane == 0) {
+    partials[(size_t)blk * 2 + 0] = rr;
+    partials[(size_t)blk * 2 + 1] = rr2;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // hot: SELL-64 SpMV  y = A x  (+ addv), optional Dirichlet row mask, optional fused dot products
 //   partials[b] = ( r.x , y.x , r.r ) over the rows of logical block b   (x plays the role of u = Dinv r)
 // ---------------------------------------------------------------------------------------------------
-template <int DOTS>
-__global__ __launch_bounds__(256) void k_spmv(int n_launch, const int32_t* __restrict__ slice_list, int64_t n_own,
-                                               const int64_t* __restrict__ slice_ptr,
+template <int DOTS, int UNR>
+__global__ __launch_bounds__(256) void k_spmv(int n_launch, int chunk, const int32_t* __restrict__ slice_list,
+                                               int64_t n_own, const int64_t* __restrict__ slice_ptr,
                                                const int32_t* __restrict__ cols, const double* __restrict__ vals,
                                                const double* __restrict__ x, double* __restrict__ y,
                                                const uint8_t* __restrict__ fixed, const double* __restrict__ addv,
                                                const double* __restrict__ r, double* __restrict__ partials,
                                                int partial_off, const int* __restrict__ done, int remap) {
   if (done && *done) return;
+  // block b owns the contiguous slice range [b*chunk, (b+1)*chunk); its 4 waves interleave inside that range
   const int b = remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int si = b * 4 + wid;
+  const int s_end = min(n_launch, (b + 1) * chunk);
   double pg = 0.0, pd = 0.0, pr = 0.0;
-  if (si < n_launch) {
+  for (int si = b * chunk + wid; si < s_end; si += 4) {
     const int s = slice_list ? slice_list[si] : si;
     const int64_t row = (int64_t)s * GL_WAVE + lane;
     const int64_t base = slice_ptr[s];
@@ -254,16 +314,18 @@ __global__ __launch_bounds__(256) void k_spmv(int n_launch, const int32_t* __res
     const int32_t* cc = cols + base + lane;
     double acc = 0.0;
     int k = 0;
-    for (; k + 4 <= len; k += 4) {
-      const int32_t c0 = cc[(int64_t)(k + 0) * GL_WAVE], c1 = cc[(int64_t)(k + 1) * GL_WAVE],
-                    c2 = cc[(int64_t)(k + 2) * GL_WAVE], c3 = cc[(int64_t)(k + 3) * GL_WAVE];
-      const double v0 = v[(int64_t)(k + 0) * GL_WAVE], v1 = v[(int64_t)(k + 1) * GL_WAVE],
-                   v2 = v[(int64_t)(k + 2) * GL_WAVE], v3 = v[(int64_t)(k + 3) * GL_WAVE];
-      const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
-      acc += v0 * x0;
-      acc += v1 * x1;
-      acc += v2 * x2;
-      acc += v3 * x3;
+    // UNR independent (column, value, gather) triples in flight per lane
+    for (; k + UNR <= len; k += UNR) {
+      int32_t cu[UNR];
+      double vu[UNR], xu[UNR];
+#pragma unroll
+      for (int j = 0; j < UNR; ++j) cu[j] = cc[(int64_t)(k + j) * GL_WAVE];
+#pragma unroll
+      for (int j = 0; j < UNR; ++j) vu[j] = v[(int64_t)(k + j) * GL_WAVE];
+#pragma unroll
+      for (int j = 0; j < UNR; ++j) xu[j] = x[cu[j]];
+#pragma unroll
+      for (int j = 0; j < UNR; ++j) acc += vu[j] * xu[j];
     }
     for (; k < len; ++k) acc += v[(int64_t)k * GL_WAVE] * x[cc[(int64_t)k * GL_WAVE]];
     if (row < n_own) {
@@ -272,9 +334,9 @@ __global__ __launch_bounds__(256) void k_spmv(int n_launch, const int32_t* __res
       y[row] = acc;
       if (DOTS) {
         const double ri = r[row], ui = x[row];
-        pg = ri * ui;
-        pd = acc * ui;
-        pr = ri * ri;
+        pg += ri * ui;
+        pd += acc * ui;
+        pr += ri * ri;
       }
     }
   }
@@ -298,8 +360,8 @@ __global__ __launch_bounds__(256) void k_spmv(int n_launch, const int32_t* __res
 
 // block version (mechanics): BS x BS blocks stored as BS*BS slot-major planes per slice entry
 template <int BS, int DOTS>
-__global__ __launch_bounds__(256) void k_spmv_block(int n_launch, const int32_t* __restrict__ slice_list,
-                                                     int64_t n_own, const int64_t* __restrict__ slice_ptr,
+__global__ __launch_bounds__(256) void k_spmv_block(int n_launch, int chunk,
+                                                     const int32_t* __restrict__ slice_list, int64_t n_own, const int64_t* __restrict__ slice_ptr,
                                                      const int32_t* __restrict__ cols,
                                                      const double* __restrict__ vals, const double* __restrict__ x,
                                                      double* __restrict__ y, const uint8_t* __restrict__ fixed,
@@ -309,9 +371,9 @@ __global__ __launch_bounds__(256) void k_spmv_block(int n_launch, const int32_t*
   constexpr int B2 = BS * BS;
   const int b = remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int si = b * 4 + wid;
+  const int s_end = min(n_launch, (b + 1) * chunk);
   double pg = 0.0, pd = 0.0, pr = 0.0;
-  if (si < n_launch) {
+  for (int si = b * chunk + wid; si < s_end; si += 4) {
     const int s = slice_list ? slice_list[si] : si;
     const int64_t row = (int64_t)s * GL_WAVE + lane;
     const int64_t base = slice_ptr[s];
@@ -459,23 +521,34 @@ void gl_assemble_static(glims_ctx* h, int with_mechanics) {
     assemble_static_t<3>(h, with_mechanics);
 }
 
-void gl_rd_assemble(glims_ctx* h, const double* c, const double* b, double* r_out, double* partials) {
+int gl_rd_grid(const glims_ctx* h) { return h->pat.n_slices; }
+
+// Assembles A(c) and the Newton right-hand side(s).  partials: [gl_rd_grid][2] = (|b - ..|^2, |b2 - ..|^2).
+void gl_rd_assemble(glims_ctx* h, const double* c, const double* b, const double* b2, double* r_out, double* r2_out,
+                    double* partials) {
   const DevPattern& p = h->pat;
   const size_t lds = (size_t)2 * p.max_len * GL_WAVE * sizeof(double);
   const uint8_t* fx = h->have_fixed_c ? h->fixed_c.p : nullptr;
+  const int grid = gl_rd_grid(h);
+  const int chunk = (p.n_slices + grid - 1) / grid;
   if (h->nv == 3) {
     set_lds(k_rd_assemble<3>, lds);
-    hipLaunchKernelGGL(k_rd_assemble<3>, dim3(p.n_slices), dim3(GL_WAVE), lds, h->st, h->n_own, p.slice_ptr.p,
-                       p.cols.p, p.cslice_ptr.p, p.cslots.p, p.cw.p, p.diag_k.p, h->vS.p, h->vA.p, c, b, r_out,
-                       h->dinv.p, fx, 2.0 * h->opt.dt, partials, p.max_len);
+    hipLaunchKernelGGL(k_rd_assemble<3>, dim3(grid), dim3(GL_WAVE), lds, h->st, p.n_slices, chunk, h->n_own,
+                       p.slice_ptr.p, p.cols.p, p.cslice_ptr.p, p.cslots.p, p.cw.p, p.diag_k.p, h->vS.p, h->vA.p, c, b,
+                       b2, r_out, r2_out, h->dinv.p, fx, 2.0 * h->opt.dt, partials, p.max_len, 1);
   } else {
     set_lds(k_rd_assemble<4>, lds);
-    hipLaunchKernelGGL(k_rd_assemble<4>, dim3(p.n_slices), dim3(GL_WAVE), lds, h->st, h->n_own, p.slice_ptr.p,
-                       p.cols.p, p.cslice_ptr.p, p.cslots.p, p.cw.p, p.diag_k.p, h->vS.p, h->vA.p, c, b, r_out,
-                       h->dinv.p, fx, 2.0 * h->opt.dt, partials, p.max_len);
+    hipLaunchKernelGGL(k_rd_assemble<4>, dim3(grid), dim3(GL_WAVE), lds, h->st, p.n_slices, chunk, h->n_own,
+                       p.slice_ptr.p, p.cols.p, p.cslice_ptr.p, p.cslots.p, p.cw.p, p.diag_k.p, h->vS.p, h->vA.p, c, b,
+                       b2, r_out, r2_out, h->dinv.p, fx, 2.0 * h->opt.dt, partials, p.max_len, 1);
   }
   GL_HIP(hipGetLastError());
 }
+
+// Blocks per SpMV launch: every block owns a contiguous chunk of slices and emits ONE partial-sum triple.
+// (one slice per wave: ~16x more blocks than fit on the chip, so the dispatcher balances the tail; equal-length
+// persistent blocks measured 25 % slower because 2048 blocks do not fit a residency of 7 blocks/CU in one round)
+int gl_spmv_grid(int n_launch) { return std::max(1, (n_launch + 3) / 4); }
 
 // Generic entry used by the solver: slice subset + fused dots.
 void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* slice_list, const double* vals,
@@ -483,14 +556,19 @@ void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* s
                     double* partials, int partial_off, const int* done) {
   if (n_launch <= 0) return;
   const DevPattern& p = h->pat;
-  const unsigned grid = (unsigned)((n_launch + 3) / 4);
-  const int remap = slice_list ? 0 : 1;
-  if (r)
-    hipLaunchKernelGGL(k_spmv<1>, dim3(grid), dim3(256), 0, st, n_launch, slice_list, h->n_own, p.slice_ptr.p,
-                       p.cols.p, vals, x, y, fixed, addv, r, partials, partial_off, done, remap);
-  else
-    hipLaunchKernelGGL(k_spmv<0>, dim3(grid), dim3(256), 0, st, n_launch, slice_list, h->n_own, p.slice_ptr.p,
-                       p.cols.p, vals, x, y, fixed, addv, r, partials, partial_off, done, remap);
+  const int grid = gl_spmv_grid(n_launch);
+  const int chunk = (n_launch + grid - 1) / grid;
+  const int remap = (slice_list || !h->tune_xcd_remap) ? 0 : 1;
+#define GL_SPMV(DOTS, UNR)                                                                                     \
+  hipLaunchKernelGGL((k_spmv<DOTS, UNR>), dim3(grid), dim3(256), 0, st, n_launch, chunk, slice_list, h->n_own, \
+                     p.slice_ptr.p, p.cols.p, vals, x, y, fixed, addv, r, partials, partial_off, done, remap)
+  const int unr = h->tune_spmv_unroll;
+  if (r) {
+    if (unr == 2) GL_SPMV(1, 2); else if (unr == 8) GL_SPMV(1, 8); else GL_SPMV(1, 4);
+  } else {
+    if (unr == 2) GL_SPMV(0, 2); else if (unr == 8) GL_SPMV(0, 8); else GL_SPMV(0, 4);
+  }
+#undef GL_SPMV
   GL_HIP(hipGetLastError());
 }
 
@@ -499,11 +577,12 @@ void gl_launch_spmv_block(glims_ctx* h, hipStream_t st, int n_launch, const int3
                           const int* done) {
   if (n_launch <= 0) return;
   const DevPattern& p = h->pat;
-  const unsigned grid = (unsigned)((n_launch + 3) / 4);
+  const int grid = gl_spmv_grid(n_launch);
+  const int chunk = (n_launch + grid - 1) / grid;
   const int remap = slice_list ? 0 : 1;
 #define GL_BLK(BS, DOTS)                                                                                         \
-  hipLaunchKernelGGL((k_spmv_block<BS, DOTS>), dim3(grid), dim3(256), 0, st, n_launch, slice_list, h->n_own,      \
-                     p.slice_ptr.p, p.cols.p, h->vKel.p, x, y, fixed, r, partials, partial_off, done, remap)
+  hipLaunchKernelGGL((k_spmv_block<BS, DOTS>), dim3(grid), dim3(256), 0, st, n_launch, chunk, slice_list,         \
+                     h->n_own, p.slice_ptr.p, p.cols.p, h->vKel.p, x, y, fixed, r, partials, partial_off, done, remap)
   if (h->dim == 2) {
     if (r) GL_BLK(2, 1); else GL_BLK(2, 0);
   } else {

@@ -94,7 +94,26 @@ __global__ void k_cg_update(int64_t n_own, const double* __restrict__ scal, cons
   }
 }
 
-// red[q] = sum_b partials[b*nq + q], fixed order -> bitwise reproducible
+// red[q] = sum_b partials[b*nq + q] in a fixed order -> bitwise reproducible.  Two stages: `nb1` blocks each sum a
+// contiguous range into tmp[blk*nq + q], then one block sums tmp (a single block over ~1e5 partials took 98 us).
+__global__ __launch_bounds__(256) void k_reduce_stage1(int n, int nq, int per_block,
+                                                        const double* __restrict__ partials,
+                                                        double* __restrict__ tmp, const int* __restrict__ done) {
+  if (done && *done) return;
+  __shared__ double sm[4];
+  const int lo = blockIdx.x * per_block, hi = min(n, lo + per_block);
+  for (int q = 0; q < nq; ++q) {
+    double v = 0.0;
+    for (int i = lo + threadIdx.x; i < hi; i += 256) v += partials[(size_t)i * nq + q];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) tmp[(size_t)blockIdx.x * nq + q] = sm[0] + sm[1] + sm[2] + sm[3];
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(256) void k_reduce(int n, int nq, const double* __restrict__ partials,
                                                  double* __restrict__ red, const int* __restrict__ done) {
   if (done && *done) return;
@@ -282,6 +301,18 @@ void gl_comm_destroy(glims_ctx* h) {
   h->comm_halo = h->comm_red = nullptr;
 }
 
+static void reduce_partials(glims_ctx* h, int n, int nq, const int* done) {
+  if (n > 2048) {
+    const int per_block = 1024, nb1 = (n + per_block - 1) / per_block;
+    hipLaunchKernelGGL(k_reduce_stage1, dim3(nb1), dim3(256), 0, h->st, n, nq, per_block, h->partials.p,
+                       h->partials2.p, done);
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, h->st, nb1, nq, h->partials2.p, h->red.p, done);
+  } else {
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, h->st, n, nq, h->partials.p, h->red.p, done);
+  }
+  GL_HIP(hipGetLastError());
+}
+
 static void poll(glims_ctx* h, int* done, double* scal8) {
   // one small D2H of the decision word + recurrence scalars, then the only host sync of a batch
   GL_HIP(hipMemcpyAsync(h->h_pinned, h->scal.p, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->st));
@@ -291,10 +322,15 @@ static void poll(glims_ctx* h, int* done, double* scal8) {
   std::memcpy(done, h->h_pinned + SC_COUNT, sizeof(int));
 }
 
-static double read_red0(glims_ctx* h) {
-  GL_HIP(hipMemcpyAsync(h->h_pinned, h->red.p, sizeof(double), hipMemcpyDeviceToHost, h->st));
+static void read_red(glims_ctx* h, int n, double* out) {
+  GL_HIP(hipMemcpyAsync(h->h_pinned, h->red.p, n * sizeof(double), hipMemcpyDeviceToHost, h->st));
   GL_HIP(hipStreamSynchronize(h->st));
-  return h->h_pinned[0];
+  for (int i = 0; i < n; ++i) out[i] = h->h_pinned[i];
+}
+static double read_red0(glims_ctx* h) {
+  double v;
+  read_red(h, 1, &v);
+  return v;
 }
 
 // ===================================================================================================
@@ -321,7 +357,7 @@ static void apply_with_halo(glims_ctx* h, const CgVecs& v) {
   }
   // interior slices overlap with the xGMI transfer; boundary slices run once the ghosts have landed
   halo_start(h, v.u, v.bs);
-  const int nbi = (p.n_interior + 3) / 4;
+  const int nbi = gl_spmv_grid(p.n_interior);
   if (v.vals)
     gl_launch_spmv(h, h->st, p.n_interior, p.interior_slices.p, v.vals, v.u, v.w, v.fixed, nullptr, v.r,
                    h->partials.p, 0, h->done.p);
@@ -340,7 +376,8 @@ static void apply_with_halo(glims_ctx* h, const CgVecs& v) {
 static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, int64_t* its_out, double* res_out) {
   const DevPattern& p = h->pat;
   const bool split = h->world > 1 && h->n_peers > 0;
-  const int nblocks = split ? (p.n_interior + 3) / 4 + (p.n_boundary + 3) / 4 : (p.n_slices + 3) / 4;
+  const int nblocks = split ? gl_spmv_grid(p.n_interior) + (p.n_boundary > 0 ? gl_spmv_grid(p.n_boundary) : 0)
+                            : gl_spmv_grid(p.n_slices);
   const int64_t n = h->n_own;
   GL_HIP(hipMemsetAsync(h->scal.p, 0, SC_COUNT * sizeof(double), h->st));
   GL_HIP(hipMemsetAsync(h->done.p, 0, sizeof(int), h->st));
@@ -362,7 +399,7 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
     const int nb = std::min(batch, maxit + 1 - enq);
     for (int j = 0; j < nb; ++j) {
       apply_with_halo(h, v);
-      hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, h->st, nblocks, 3, h->partials.p, h->red.p, h->done.p);
+      reduce_partials(h, nblocks, 3, h->done.p);
       allreduce_sum(h, h->red.p, 3);
       hipLaunchKernelGGL(k_cg_scalars, dim3(1), dim3(1), 0, h->st, h->red.p, h->scal.p, h->done.p, tol2);
       GL_VEC(k_cg_update, n, h->scal.p, h->done.p, v.p, v.s, v.x, v.r, v.u, v.w, v.dinv);
@@ -382,41 +419,55 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
 // ===================================================================================================
 // RD time stepping
 // ===================================================================================================
+// One sweep = Jacobian + right-hand side(s) + their norms.  With b2 the sweep also produces the first residual of
+// the NEXT time step (same operator part 1/2 (A+S) c, different b), so that the convergence check of step n and
+// the first assembly of step n+1 are one pass over the corner lists.
+static void rd_sweep(glims_ctx* h, const double* b2, double* norms /*[2]*/) {
+  gl_rd_assemble(h, h->c.p, h->b.p, b2, h->cg_r.p, h->cg_r2.p, h->partials.p);
+  reduce_partials(h, gl_rd_grid(h), 2, nullptr);
+  allreduce_sum(h, h->red.p, 2);
+  double r2[2];
+  read_red(h, 2, r2);
+  norms[0] = std::sqrt(r2[0]);
+  norms[1] = std::sqrt(r2[1]);
+  h->stats.rd_assemblies++;
+}
+
 int gl_step(glims_ctx* h, int n_steps) {
   GL_REQUIRE(h->is_setup, "glims_step before glims_setup");
   GL_REQUIRE(h->have_state, "glims_step before glims_set_state");
   const DevPattern& p = h->pat;
   const int64_t n = h->n_own;
   const glims_options& o = h->opt;
+  const bool extrapolate = (o.flags & GLIMS_FLAG_EXTRAPOLATE_GUESS) != 0;
+  const double* load = h->have_load_rd ? h->load_rd.p : nullptr;
   int status = GLIMS_OK;
   GL_HIP(hipEventRecord(h->ev_a, h->st));
   for (int step = 0; step < n_steps && status == GLIMS_OK; ++step) {
-    // b = M c^n + load          ('u_previous1 * v1 * dx', simulation_tumor_growth.py:117)
-    gl_launch_spmv(h, h->st, p.n_slices, nullptr, h->vM.p, h->c.p, h->b.p, nullptr,
-                   h->have_load_rd ? h->load_rd.p : nullptr, nullptr, nullptr, 0, nullptr);
-    bool ghosts_valid = true;
-    if (o.flags & GLIMS_FLAG_EXTRAPOLATE_GUESS) {
-      hipLaunchKernelGGL(k_extrapolate, dim3(grid_exact(n)), dim3(256), 0, h->st, n, h->c.p, h->c_old.p,
-                         h->have_fixed_c ? h->fixed_c.p : nullptr, h->stats.steps > 0 ? 1 : 0);
-      ghosts_valid = false;
+    double norms[2] = {0.0, 0.0};
+    double nr;
+    if (h->pending) {
+      // the sweep that verified the previous step already assembled A(c^n) and -R(c^n; c^n) for this one
+      nr = h->pending_r0;
+      h->pending = false;
+    } else {
+      // b = M c^n + load          ('u_previous1 * v1 * dx', simulation_tumor_growth.py:117)
+      gl_launch_spmv(h, h->st, p.n_slices, nullptr, h->vM.p, h->c.p, h->b.p, nullptr, load, nullptr, nullptr, 0,
+                     nullptr);
+      if (extrapolate) {
+        hipLaunchKernelGGL(k_extrapolate, dim3(grid_exact(n)), dim3(256), 0, h->st, n, h->c.p, h->c_old.p,
+                           h->have_fixed_c ? h->fixed_c.p : nullptr, h->stats.steps > 0 ? 1 : 0);
+        gl_halo_exchange(h, h->c.p, 1);
+      }
+      rd_sweep(h, nullptr, norms);
+      nr = norms[0];
     }
-    double r0 = 0.0, target = 0.0, nr = 0.0;
-    int it = 0;
-    for (;; ++it) {
-      if (!ghosts_valid) gl_halo_exchange(h, h->c.p, 1);
-      gl_rd_assemble(h, h->c.p, h->b.p, h->cg_r.p, h->partials.p);
-      hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, h->st, p.n_slices, 1, h->partials.p, h->red.p,
-                         (const int*)nullptr);
-      allreduce_sum(h, h->red.p, 1);
-      nr = std::sqrt(read_red0(h));
-      h->stats.rd_assemblies++;
+    const double r0 = nr;
+    const double target = std::max(o.newton_atol, o.newton_rtol * r0);
+    for (int it = 0;; ++it) {
       if (!std::isfinite(nr)) {
         status = GLIMS_NAN;
         break;
-      }
-      if (it == 0) {
-        r0 = nr;
-        target = std::max(o.newton_atol, o.newton_rtol * r0);
       }
       if (nr <= target) break;
       if (it >= o.newton_maxit) {
@@ -433,13 +484,28 @@ int gl_step(glims_ctx* h, int n_steps) {
       h->stats.cg_its += its;
       h->stats.newton_its++;
       h->stats.last_cg_res = res;
-      ghosts_valid = false;
+      gl_halo_exchange(h, h->c.p, 1);   // ghosts of c current again
       if (cs != GLIMS_OK) {
         status = cs;
         break;
       }
+      // Newton converges quadratically here (the nonlinearity is exactly quadratic): once the residual before the
+      // solve was below ~sqrt(rtol) of the initial one, the next sweep will almost surely only confirm convergence,
+      // so let it also assemble the next step (costs one extra mass SpMV, saves a whole sweep per step).
+      const bool speculate = !extrapolate && nr <= 1e-4 * std::sqrt(o.newton_rtol / 1e-10) * r0;
+      if (speculate)
+        gl_launch_spmv(h, h->st, p.n_slices, nullptr, h->vM.p, h->c.p, h->b2.p, nullptr, load, nullptr, nullptr, 0,
+                       nullptr);
+      rd_sweep(h, speculate ? h->b2.p : nullptr, norms);
+      nr = norms[0];
+      if (speculate && std::isfinite(nr) && nr <= target) {
+        std::swap(h->b.p, h->b2.p);
+        std::swap(h->cg_r.p, h->cg_r2.p);
+        h->pending = true;
+        h->pending_r0 = norms[1];
+        break;
+      }
     }
-    if (!ghosts_valid) gl_halo_exchange(h, h->c.p, 1);   // invariant: ghosts of c are current between steps
     h->stats.last_newton_res = nr;
     h->stats.steps++;
   }
@@ -479,8 +545,7 @@ int gl_solve_mechanics(glims_ctx* h) {
   // ||rhs|| for the relative tolerance
   const unsigned gd = grid_for(nd, 256, 1024);
   hipLaunchKernelGGL(k_dot_partials, dim3(gd), dim3(256), 0, h->st, nd, h->m_rhs.p, h->m_rhs.p, h->partials.p);
-  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, h->st, (int)gd, 1, h->partials.p, h->red.p,
-                     (const int*)nullptr);
+  reduce_partials(h, (int)gd, 1, nullptr);
   allreduce_sum(h, h->red.p, 1);
   const double nb = std::sqrt(read_red0(h));
   if (!std::isfinite(nb)) return GLIMS_NAN;

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""A/B of SpMV variants, interleaved rounds in ONE process (cdna_hip_programming.md section 5.4 rule 24)."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from glimslib_amd import workloads
+from glimslib_amd._backend import Handle
+
+w = workloads.by_name(sys.argv[1] if len(sys.argv) > 1 else 'c4')
+h = Handle(w.mesh.points, w.mesh.cells, w.cell_label)
+t = w.tables
+h.set_materials(t['D'], t['rho'], t['gamma'], t['E'], t['nu'])
+h.set_options(dt=w.dt)
+h.setup(False)
+st = h.stats()
+b_alg = workloads.b_spmv_bytes(st['nnz'], st['n_rows'])
+x = np.random.default_rng(0).standard_normal(h.n_nodes)
+variants = [("unroll2", dict(GLIMS_SPMV_UNROLL="2", GLIMS_XCD_REMAP="1")),
+            ("unroll4", dict(GLIMS_SPMV_UNROLL="4", GLIMS_XCD_REMAP="1")),
+            ("unroll8", dict(GLIMS_SPMV_UNROLL="8", GLIMS_XCD_REMAP="1")),
+            ("unroll4-noremap", dict(GLIMS_SPMV_UNROLL="4", GLIMS_XCD_REMAP="0"))]
+res = {n: [] for n, _ in variants}
+for rnd in range(6):
+    for name, env in variants:
+        os.environ.update(env)
+        _, ms = h.apply(0, x, reps=30)
+        if rnd > 0:
+            res[name].append(ms / 30 * 1e3)
+for name, v in res.items():
+    v = np.array(v)
+    print("%-18s median %7.1f us  min %7.1f us   -> %6.0f GB/s (median)" % (name, np.median(v), v.min(), b_alg / np.median(v) / 1e3))
