@@ -84,12 +84,20 @@ def main():
     if not torch.cuda.is_available():
         log("bench.py: no GPU visible -- the HIP backend has no CPU fallback")
         sys.exit(3)
+    # GLIMS_FORCE_DEVICE: rehearsal of the N>1 code path on a box with fewer GPUs than ranks (all ranks share one
+    # device, torch side on gloo); never set by the driver.
+    forced = os.environ.get("GLIMS_FORCE_DEVICE")
+    if forced is not None:
+        local_rank = int(forced)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if forced is not None:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
 
     from glimslib_amd import workloads
     from glimslib_amd._backend import Handle, GLIMS_OK, FLAG_EXTRAPOLATE_GUESS
@@ -141,7 +149,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if forced is not None else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     st = h.stats()

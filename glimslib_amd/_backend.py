@@ -74,7 +74,11 @@ SIGNATURES = {
     "glims_comm_unique_id": (C.c_int, [C.c_char_p]),
     "glims_comm_init": (C.c_int, [_h, C.c_int, C.c_int, C.c_char_p]),
     "glims_set_halo": (C.c_int, [_h, C.c_int, _i32p, _i64p, _i32p, _i64p]),
+    "glims_set_transport": (C.c_int, [_h, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
+
+HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, _i64p, C.c_void_p, _i64p, C.c_int, _i32p, C.c_int, C.c_void_p)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
 
 _lib = None
 
@@ -242,6 +246,12 @@ class Handle:
     def comm_init(self, rank, world, uid):
         assert len(uid) == GLIMS_UNIQUE_ID_BYTES
         self._check(self.lib.glims_comm_init(self._h, int(rank), int(world), uid))
+
+    def set_transport(self, rank, world, halo_cb, allreduce_cb):
+        """halo_cb / allreduce_cb: HALO_FN / ALLREDUCE_FN instances (kept alive by this handle)."""
+        self._transport_refs = (halo_cb, allreduce_cb)
+        self._check(self.lib.glims_set_transport(self._h, int(rank), int(world), C.cast(halo_cb, C.c_void_p),
+                                                 C.cast(allreduce_cb, C.c_void_p), None))
 
     def set_halo(self, peer_rank, send_ptr, send_idx, recv_count):
         pr = np.ascontiguousarray(peer_rank, dtype=np.int32)

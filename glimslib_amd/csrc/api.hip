@@ -522,6 +522,21 @@ int glims_comm_init(glims_ctx* h, int rank, int world, const char id[GLIMS_UNIQU
   });
 }
 
+int glims_set_transport(glims_ctx* h, int rank, int world, glims_halo_fn halo, glims_allreduce_fn allreduce,
+                        void* user) {
+  return guarded(h, [&]() {
+    GL_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank / world");
+    GL_REQUIRE(world == 1 || (halo && allreduce), "both transport callbacks are required");
+    gl_comm_destroy(h);
+    h->rank = rank;
+    h->world = world;
+    h->tr_halo = halo;
+    h->tr_allreduce = allreduce;
+    h->tr_user = user;
+    return GLIMS_OK;
+  });
+}
+
 int glims_set_halo(glims_ctx* h, int n_peers, const int32_t* peer_rank, const int64_t* send_ptr,
                    const int32_t* send_idx, const int64_t* recv_count) {
   return guarded(h, [&]() {

@@ -159,6 +159,9 @@ struct glims_ctx {
   dvec<int32_t> send_idx;
   dvec<double> sendbuf;
   int64_t n_send = 0;
+  glims_halo_fn tr_halo = nullptr;          // host-provided transport (tests / MPI hosts); RCCL when null
+  glims_allreduce_fn tr_allreduce = nullptr;
+  void* tr_user = nullptr;
 
   std::string err;
 };

@@ -269,8 +269,15 @@ static void halo_start(glims_ctx* h, double* vec, int bs) {
                        h->send_idx.p, vec, h->sendbuf.p);
     GL_HIP(hipGetLastError());
   }
+  if (h->tr_halo) {
+    const int rc = h->tr_halo(h->tr_user, h->sendbuf.p, h->send_ptr.data(), vec + h->n_own * bs, h->recv_ptr.data(),
+                              h->n_peers, h->peer_rank.data(), bs, (void*)h->st);
+    if (rc != 0) throw glims_error(GLIMS_E_RCCL, "transport halo callback failed (" + std::to_string(rc) + ")");
+    return;
+  }
   GL_HIP(hipEventRecord(h->ev_pack, h->st));
   GL_HIP(hipStreamWaitEvent(h->st_comm, h->ev_pack, 0));
+  GL_REQUIRE(h->comm_halo, "world > 1 but no communicator: call glims_comm_init or glims_set_transport");
   GL_NCCL(ncclGroupStart());
   for (int p = 0; p < h->n_peers; ++p) {
     const int64_t ns = h->send_ptr[p + 1] - h->send_ptr[p], nr = h->recv_ptr[p + 1] - h->recv_ptr[p];
@@ -285,7 +292,7 @@ static void halo_start(glims_ctx* h, double* vec, int bs) {
   GL_HIP(hipEventRecord(h->ev_halo, h->st_comm));
 }
 static void halo_finish(glims_ctx* h) {
-  if (h->world <= 1 || h->n_peers == 0) return;
+  if (h->world <= 1 || h->n_peers == 0 || h->tr_halo) return;
   GL_HIP(hipStreamWaitEvent(h->st, h->ev_halo, 0));
 }
 void gl_halo_exchange(glims_ctx* h, double* vec, int bs) {
@@ -293,7 +300,14 @@ void gl_halo_exchange(glims_ctx* h, double* vec, int bs) {
   halo_finish(h);
 }
 static void allreduce_sum(glims_ctx* h, double* dev, int n) {
-  if (h->world > 1) GL_NCCL(ncclAllReduce(dev, dev, (size_t)n, ncclDouble, ncclSum, h->comm_red, h->st));
+  if (h->world <= 1) return;
+  if (h->tr_allreduce) {
+    const int rc = h->tr_allreduce(h->tr_user, dev, n, (void*)h->st);
+    if (rc != 0) throw glims_error(GLIMS_E_RCCL, "transport allreduce callback failed (" + std::to_string(rc) + ")");
+    return;
+  }
+  GL_REQUIRE(h->comm_red, "world > 1 but no communicator: call glims_comm_init or glims_set_transport");
+  GL_NCCL(ncclAllReduce(dev, dev, (size_t)n, ncclDouble, ncclSum, h->comm_red, h->st));
 }
 void gl_comm_destroy(glims_ctx* h) {
   if (h->comm_halo) (void)ncclCommDestroy(h->comm_halo);

@@ -167,6 +167,21 @@ int glims_comm_init(glims_ctx* h, int rank, int world, const char id[GLIMS_UNIQU
 int glims_set_halo(glims_ctx* h, int n_peers, const int32_t* peer_rank,
                    const int64_t* send_ptr, const int32_t* send_idx, const int64_t* recv_count);
 
+/* Optional host-provided transport instead of RCCL (e.g. the reference's own MPI communicator, which DOLFIN hands
+ * around as mesh.mpi_comm(), helper_classes.py:1249-1267; also used by the 2-rank tests on a single GPU, where RCCL
+ * refuses two ranks per device).  Both callbacks are invoked from the calling thread with device pointers and the
+ * handle's HIP stream; they must return only when the exchange is complete and visible to later work on that stream
+ * (e.g. hipStreamSynchronize, staged copies, hipMemcpy back).  Return 0 on success.
+ *   halo:      sendbuf[(send_ptr[p] .. send_ptr[p+1]) * bs] goes to peer p; the values received from peer p must be
+ *              stored at ghosts[(recv_ptr[p] .. recv_ptr[p+1]) * bs]  (ghosts = first ghost slot of the vector).
+ *   allreduce: in-place sum of n doubles over all ranks.
+ * Replaces glims_comm_init (sets rank / world); glims_set_halo is still required. */
+typedef int (*glims_halo_fn)(void* user, const double* sendbuf_dev, const int64_t* send_ptr, double* ghosts_dev,
+                             const int64_t* recv_ptr, int n_peers, const int32_t* peer_rank, int bs, void* hip_stream);
+typedef int (*glims_allreduce_fn)(void* user, double* values_dev, int n, void* hip_stream);
+int glims_set_transport(glims_ctx* h, int rank, int world, glims_halo_fn halo, glims_allreduce_fn allreduce,
+                        void* user);
+
 #ifdef __cplusplus
 }
 #endif
