@@ -165,8 +165,18 @@ def main():
     t_spmv = ms * 1e-3 / args.spmv_reps
     b_alg = workloads.b_spmv_bytes(st['nnz'], st['n_rows'])
     achieved = b_alg / t_spmv / 1e9
+    # HBM-side bytes per launch from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate rocprofv3 runs,
+    # calibrated on kernels with exactly known byte counts): profiles/r01_pmc_c4.json.  Only reported when this
+    # run's operator is the one those passes measured.
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(HERE, "profiles", "r01_pmc_c4.json")))
+        if world == 1 and pmc["n_rows"] == st['n_rows'] and pmc["nnz"] == st['nnz']:
+            traffic = pmc["kernels"]["k_spmv<0, 4>"]["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_spmv<0> (SELL-64, fp64 values, "
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_spmv<0,4> (SELL-64, fp64 values, "
                 "int32 columns)", "algorithmic_bytes_per_launch": b_alg, "avg_launch_us": t_spmv * 1e6,
                 "launches_timed": args.spmv_reps}
 
