@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--spmv-reps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extrapolate", type=int, default=0)
+    ap.add_argument("--cg-rtol", type=float, default=None, help="override glims_options.cg_rtol (tuning runs only)")
+    ap.add_argument("--check-every", type=int, default=None)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -125,7 +127,12 @@ def main():
         c0 = w.c0
     t = w.tables
     h.set_materials(t['D'], t['rho'], t['gamma'], t['E'], t['nu'])
-    h.set_options(dt=w.dt, flags=FLAG_EXTRAPOLATE_GUESS if args.extrapolate else 0)
+    extra = {}
+    if args.cg_rtol is not None:
+        extra["cg_rtol"] = args.cg_rtol
+    if args.check_every is not None:
+        extra["check_every"] = args.check_every
+    h.set_options(dt=w.dt, flags=FLAG_EXTRAPOLATE_GUESS if args.extrapolate else 0, **extra)
     h.setup(with_mechanics=False)
     h.set_state(c0)
     st0 = h.stats()

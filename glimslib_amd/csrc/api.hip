@@ -15,6 +15,8 @@ namespace {
 void read_tuning(glims_ctx* h) {
   if (const char* e = getenv("GLIMS_SPMV_UNROLL")) h->tune_spmv_unroll = atoi(e);
   if (const char* e = getenv("GLIMS_XCD_REMAP")) h->tune_xcd_remap = atoi(e);
+  if (const char* e = getenv("GLIMS_SPMV_NT")) h->tune_spmv_nt = atoi(e);
+  if (const char* e = getenv("GLIMS_RD_NT")) h->tune_rd_nt = atoi(e);
 }
 
 std::mutex g_err_mu;
@@ -85,7 +87,7 @@ int glims_options_default(glims_options* o) {
   o->newton_rtol = 1e-10;
   o->newton_atol = 1e-13;
   o->newton_maxit = 50;
-  o->cg_rtol = 1e-6;
+  o->cg_rtol = 1e-3;
   o->cg_atol = 0.0;
   o->cg_maxit = 5000;
   o->mech_rtol = 1e-10;
@@ -193,7 +195,7 @@ int glims_create(glims_ctx** out, int dim, int64_t n_nodes, int64_t n_own, int64
     h->partials.alloc_zero((size_t)p.n_slices * 3 + 4096, h->st);
     h->partials2.alloc_zero((size_t)(p.n_slices * 3 + 4096) / 1024 * 3 + 64, h->st);
     h->red.alloc_zero(4, h->st);
-    h->scal.alloc_zero(SC_COUNT, h->st);
+    h->scal.alloc_zero(2 * SC_COUNT + 8, h->st);
     h->done.alloc_zero(1, h->st);
     GL_HIP(hipStreamSynchronize(h->st));
 
@@ -482,6 +484,7 @@ int glims_rd_residual(glims_ctx* h, const double* c, const double* c_prev, doubl
     gl_launch_spmv(h, h->st, h->pat.n_slices, nullptr, h->vM.p, dcp.p, h->b.p, nullptr,
                    h->have_load_rd ? h->load_rd.p : nullptr, nullptr, nullptr, 0, nullptr);
     h->pending = false;
+    read_tuning(h);
     gl_rd_assemble(h, dc.p, h->b.p, nullptr, h->cg_r.p, h->cg_r2.p, h->partials.p);
     GL_HIP(hipStreamSynchronize(h->st));
     if (R) {

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(GL_WAVE) void k_assemble_static(
 //   s_T = sum of c over the cell's vertices, w_T = rho_T |T| d!/(d+3)!   [exact integral of rho c_h phi_i phi_j]
 //   -R = b - 1/2 (A + S) c,   b = M c_prev + load
 // ---------------------------------------------------------------------------------------------------
-template <int NV>
+template <int NV, int NT>
 __global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
     int n_slices, int chunk, int64_t n_own, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ cols,
     const int64_t* __restrict__ cslice_ptr, const uint32_t* __restrict__ cslots, const double* __restrict__ cw,
@@ -190,7 +190,8 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
         int32_t ci8[8];
         double x8[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ci8[j] = cc[(int64_t)(k + j) * GL_WAVE];
+        for (int j = 0; j < 8; ++j)
+          ci8[j] = NT ? __builtin_nontemporal_load(cc + (int64_t)(k + j) * GL_WAVE) : cc[(int64_t)(k + j) * GL_WAVE];
 #pragma unroll
         for (int j = 0; j < 8; ++j) x8[j] = c[ci8[j]];
 #pragma unroll
@@ -232,8 +233,8 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
         uint32_t s4[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          w4[j] = wp[(int64_t)(q + j) * GL_WAVE];
-          s4[j] = sl[(int64_t)(q + j) * GL_WAVE];
+          w4[j] = NT ? __builtin_nontemporal_load(wp + (int64_t)(q + j) * GL_WAVE) : wp[(int64_t)(q + j) * GL_WAVE];
+          s4[j] = NT ? __builtin_nontemporal_load(sl + (int64_t)(q + j) * GL_WAVE) : sl[(int64_t)(q + j) * GL_WAVE];
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) corner(w4[j], s4[j]);
@@ -249,11 +250,13 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
       for (; k + 8 <= len; k += 8) {
         double S8[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) S8[j] = sv[(int64_t)(k + j) * GL_WAVE];
+        for (int j = 0; j < 8; ++j)
+          S8[j] = NT ? __builtin_nontemporal_load(sv + (int64_t)(k + j) * GL_WAVE) : sv[(int64_t)(k + j) * GL_WAVE];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const double Av = S8[j] + two_dt * acc[(k + j) * GL_WAVE + lane];
-          av[(int64_t)(k + j) * GL_WAVE] = Av;
+          if (NT) __builtin_nontemporal_store(Av, av + (int64_t)(k + j) * GL_WAVE);
+          else av[(int64_t)(k + j) * GL_WAVE] = Av;
           r += 0.5 * (Av + S8[j]) * cn[(k + j) * GL_WAVE + lane];
           if (k + j == dk) d = Av;
         }
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
 // hot: SELL-64 SpMV  y = A x  (+ addv), optional Dirichlet row mask, optional fused dot products
 //   partials[b] = ( r.x , y.x , r.r ) over the rows of logical block b   (x plays the role of u = Dinv r)
 // ---------------------------------------------------------------------------------------------------
-template <int DOTS, int UNR>
+template <int DOTS, int UNR, int NT>
 __global__ __launch_bounds__(256) void k_spmv(int n_launch, int chunk, const int32_t* __restrict__ slice_list,
                                                int64_t n_own, const int64_t* __restrict__ slice_ptr,
                                                const int32_t* __restrict__ cols, const double* __restrict__ vals,
@@ -318,16 +321,24 @@ __global__ __launch_bounds__(256) void k_spmv(int n_launch, int chunk, const int
     for (; k + UNR <= len; k += UNR) {
       int32_t cu[UNR];
       double vu[UNR], xu[UNR];
+      // NT: values and columns are streamed exactly once per SpMV -> non-temporal, so that they do not displace the
+      // gathered x entries from L2 / Infinity Cache
 #pragma unroll
-      for (int j = 0; j < UNR; ++j) cu[j] = cc[(int64_t)(k + j) * GL_WAVE];
+      for (int j = 0; j < UNR; ++j)
+        cu[j] = NT ? __builtin_nontemporal_load(cc + (int64_t)(k + j) * GL_WAVE) : cc[(int64_t)(k + j) * GL_WAVE];
 #pragma unroll
-      for (int j = 0; j < UNR; ++j) vu[j] = v[(int64_t)(k + j) * GL_WAVE];
+      for (int j = 0; j < UNR; ++j)
+        vu[j] = NT ? __builtin_nontemporal_load(v + (int64_t)(k + j) * GL_WAVE) : v[(int64_t)(k + j) * GL_WAVE];
 #pragma unroll
       for (int j = 0; j < UNR; ++j) xu[j] = x[cu[j]];
 #pragma unroll
       for (int j = 0; j < UNR; ++j) acc += vu[j] * xu[j];
     }
-    for (; k < len; ++k) acc += v[(int64_t)k * GL_WAVE] * x[cc[(int64_t)k * GL_WAVE]];
+    for (; k < len; ++k) {
+      const int32_t cj = NT ? __builtin_nontemporal_load(cc + (int64_t)k * GL_WAVE) : cc[(int64_t)k * GL_WAVE];
+      const double vj = NT ? __builtin_nontemporal_load(v + (int64_t)k * GL_WAVE) : v[(int64_t)k * GL_WAVE];
+      acc += vj * x[cj];
+    }
     if (row < n_own) {
       if (fixed && fixed[row]) acc = 0.0;
       if (addv) acc += addv[row];
@@ -531,17 +542,19 @@ void gl_rd_assemble(glims_ctx* h, const double* c, const double* b, const double
   const uint8_t* fx = h->have_fixed_c ? h->fixed_c.p : nullptr;
   const int grid = gl_rd_grid(h);
   const int chunk = (p.n_slices + grid - 1) / grid;
+#define GL_RD(NV, NT)                                                                                              \
+  do {                                                                                                             \
+    set_lds(k_rd_assemble<NV, NT>, lds);                                                                           \
+    hipLaunchKernelGGL((k_rd_assemble<NV, NT>), dim3(grid), dim3(GL_WAVE), lds, h->st, p.n_slices, chunk, h->n_own, \
+                       p.slice_ptr.p, p.cols.p, p.cslice_ptr.p, p.cslots.p, p.cw.p, p.diag_k.p, h->vS.p, h->vA.p, c, \
+                       b, b2, r_out, r2_out, h->dinv.p, fx, 2.0 * h->opt.dt, partials, p.max_len, 0);              \
+  } while (0)
   if (h->nv == 3) {
-    set_lds(k_rd_assemble<3>, lds);
-    hipLaunchKernelGGL(k_rd_assemble<3>, dim3(grid), dim3(GL_WAVE), lds, h->st, p.n_slices, chunk, h->n_own,
-                       p.slice_ptr.p, p.cols.p, p.cslice_ptr.p, p.cslots.p, p.cw.p, p.diag_k.p, h->vS.p, h->vA.p, c, b,
-                       b2, r_out, r2_out, h->dinv.p, fx, 2.0 * h->opt.dt, partials, p.max_len, 1);
+    if (h->tune_rd_nt) GL_RD(3, 1); else GL_RD(3, 0);
   } else {
-    set_lds(k_rd_assemble<4>, lds);
-    hipLaunchKernelGGL(k_rd_assemble<4>, dim3(grid), dim3(GL_WAVE), lds, h->st, p.n_slices, chunk, h->n_own,
-                       p.slice_ptr.p, p.cols.p, p.cslice_ptr.p, p.cslots.p, p.cw.p, p.diag_k.p, h->vS.p, h->vA.p, c, b,
-                       b2, r_out, r2_out, h->dinv.p, fx, 2.0 * h->opt.dt, partials, p.max_len, 1);
+    if (h->tune_rd_nt) GL_RD(4, 1); else GL_RD(4, 0);
   }
+#undef GL_RD
   GL_HIP(hipGetLastError());
 }
 
@@ -559,14 +572,16 @@ void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* s
   const int grid = gl_spmv_grid(n_launch);
   const int chunk = (n_launch + grid - 1) / grid;
   const int remap = (slice_list || !h->tune_xcd_remap) ? 0 : 1;
-#define GL_SPMV(DOTS, UNR)                                                                                     \
-  hipLaunchKernelGGL((k_spmv<DOTS, UNR>), dim3(grid), dim3(256), 0, st, n_launch, chunk, slice_list, h->n_own, \
+#define GL_SPMV(DOTS, UNR, NT)                                                                                     \
+  hipLaunchKernelGGL((k_spmv<DOTS, UNR, NT>), dim3(grid), dim3(256), 0, st, n_launch, chunk, slice_list, h->n_own, \
                      p.slice_ptr.p, p.cols.p, vals, x, y, fixed, addv, r, partials, partial_off, done, remap)
   const int unr = h->tune_spmv_unroll;
-  if (r) {
-    if (unr == 2) GL_SPMV(1, 2); else if (unr == 8) GL_SPMV(1, 8); else GL_SPMV(1, 4);
+  if (h->tune_spmv_nt) {
+    if (r) { if (unr == 8) GL_SPMV(1, 8, 1); else GL_SPMV(1, 4, 1); }
+    else   { if (unr == 8) GL_SPMV(0, 8, 1); else GL_SPMV(0, 4, 1); }
   } else {
-    if (unr == 2) GL_SPMV(0, 2); else if (unr == 8) GL_SPMV(0, 8); else GL_SPMV(0, 4);
+    if (r) { if (unr == 8) GL_SPMV(1, 8, 0); else GL_SPMV(1, 4, 0); }
+    else   { if (unr == 8) GL_SPMV(0, 8, 0); else GL_SPMV(0, 4, 0); }
   }
 #undef GL_SPMV
   GL_HIP(hipGetLastError());

@@ -51,14 +51,47 @@ __global__ void k_cg_init(int64_t n_own, const double* __restrict__ r, const dou
   }
 }
 
-// p = u + beta p;  s = w + beta s;  x += alpha p;  r -= alpha s;  u = Dinv r      (one pass over 7 vectors)
+// Chronopoulos-Gear recurrence + vector update in one kernel.
+//   red = (gamma = r.u, delta = w.u, rr = r.r), already global sums.  Every thread derives alpha/beta from `red`
+//   and the previous iteration's scalars (`prev`, read-only here); thread 0 of block 0 publishes the new scalars to
+//   `cur` (ping-pong) and to `info` = {iterations done, last rr} for the host.  No separate scalar kernel.
+//   p = u + beta p;  s = w + beta s;  x += alpha p;  r -= alpha s;  u = Dinv r      (one pass over 7 vectors)
 template <int BS>
-__global__ void k_cg_update(int64_t n_own, const double* __restrict__ scal, const int* __restrict__ done,
+__global__ void k_cg_update(int64_t n_own, const double* __restrict__ red, const double* __restrict__ prev,
+                            double* __restrict__ cur, double* __restrict__ info, int* __restrict__ done, double tol2,
                             double* __restrict__ p, double* __restrict__ s, double* __restrict__ x,
                             double* __restrict__ r, double* __restrict__ u, const double* __restrict__ w,
                             const double* __restrict__ dinv) {
   if (*done) return;
-  const double alpha = scal[SC_ALPHA], beta = scal[SC_BETA];
+  const double gamma = red[0], delta = red[1], rr = red[2];
+  const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+  if (lead) info[1] = rr;
+  if (!(isfinite(gamma) && isfinite(delta) && isfinite(rr))) {
+    if (lead) *done = 2;
+    return;
+  }
+  if (rr <= tol2) {
+    if (lead) *done = 1;
+    return;
+  }
+  const double it = prev[SC_IT];
+  double beta = 0.0, denom = delta;
+  if (it > 0.0) {
+    beta = gamma / prev[SC_GAMMA];
+    denom = delta - beta * gamma / prev[SC_ALPHA];
+  }
+  if (!(denom > 0.0)) {   // operator not SPD on this Krylov space (or exact breakdown)
+    if (lead) *done = 3;
+    return;
+  }
+  const double alpha = gamma / denom;
+  if (lead) {
+    cur[SC_ALPHA] = alpha;
+    cur[SC_BETA] = beta;
+    cur[SC_GAMMA] = gamma;
+    cur[SC_IT] = it + 1.0;
+    info[0] = it + 1.0;
+  }
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_own; i += stride) {
     if constexpr (BS == 1) {
@@ -130,37 +163,6 @@ __global__ __launch_bounds__(256) void k_reduce(int n, int nq, const double* __r
     if (threadIdx.x == 0) red[q] = sm[0];
     __syncthreads();
   }
-}
-
-// Chronopoulos-Gear recurrence scalars.  red = (gamma = r.u, delta = w.u, rr = r.r), already global sums.
-__global__ void k_cg_scalars(const double* __restrict__ red, double* __restrict__ scal, int* __restrict__ done,
-                             double tol2) {
-  if (*done) return;
-  const double gamma = red[0], delta = red[1], rr = red[2];
-  scal[SC_RR] = rr;
-  if (!(isfinite(gamma) && isfinite(delta) && isfinite(rr))) {
-    *done = 2;
-    return;
-  }
-  if (rr <= tol2) {
-    *done = 1;
-    return;
-  }
-  const double it = scal[SC_IT];
-  double beta = 0.0, denom = delta;
-  if (it > 0.0) {
-    beta = gamma / scal[SC_GAMMA];
-    denom = delta - beta * gamma / scal[SC_ALPHA];
-  }
-  if (!(denom > 0.0)) {   // operator not SPD on this Krylov space (or exact breakdown)
-    *done = 3;
-    return;
-  }
-  scal[SC_ALPHA] = gamma / denom;
-  scal[SC_BETA] = beta;
-  scal[SC_GAMMA] = gamma;
-  scal[SC_DELTA] = delta;
-  scal[SC_IT] = it + 1.0;
 }
 
 __global__ void k_pack(int64_t n, int bs, const int32_t* __restrict__ idx, const double* __restrict__ vec,
@@ -327,13 +329,13 @@ static void reduce_partials(glims_ctx* h, int n, int nq, const int* done) {
   GL_HIP(hipGetLastError());
 }
 
-static void poll(glims_ctx* h, int* done, double* scal8) {
-  // one small D2H of the decision word + recurrence scalars, then the only host sync of a batch
-  GL_HIP(hipMemcpyAsync(h->h_pinned, h->scal.p, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->st));
-  GL_HIP(hipMemcpyAsync(h->h_pinned + SC_COUNT, h->done.p, sizeof(int), hipMemcpyDeviceToHost, h->st));
+static void poll(glims_ctx* h, int* done, double* info2) {
+  // one small D2H of the decision word + {iterations, last rr}, then the only host sync of a batch
+  GL_HIP(hipMemcpyAsync(h->h_pinned, h->scal.p + 2 * SC_COUNT, 2 * sizeof(double), hipMemcpyDeviceToHost, h->st));
+  GL_HIP(hipMemcpyAsync(h->h_pinned + 2, h->done.p, sizeof(int), hipMemcpyDeviceToHost, h->st));
   GL_HIP(hipStreamSynchronize(h->st));
-  std::memcpy(scal8, h->h_pinned, SC_COUNT * sizeof(double));
-  std::memcpy(done, h->h_pinned + SC_COUNT, sizeof(int));
+  std::memcpy(info2, h->h_pinned, 2 * sizeof(double));
+  std::memcpy(done, h->h_pinned + 2, sizeof(int));
 }
 
 static void read_red(glims_ctx* h, int n, double* out) {
@@ -371,7 +373,7 @@ static void apply_with_halo(glims_ctx* h, const CgVecs& v) {
   }
   // interior slices overlap with the xGMI transfer; boundary slices run once the ghosts have landed
   halo_start(h, v.u, v.bs);
-  const int nbi = gl_spmv_grid(p.n_interior);
+  const int nbi = p.n_interior > 0 ? gl_spmv_grid(p.n_interior) : 0;   // partial-sum slots of the interior launch
   if (v.vals)
     gl_launch_spmv(h, h->st, p.n_interior, p.interior_slices.p, v.vals, v.u, v.w, v.fixed, nullptr, v.r,
                    h->partials.p, 0, h->done.p);
@@ -390,12 +392,15 @@ static void apply_with_halo(glims_ctx* h, const CgVecs& v) {
 static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, int64_t* its_out, double* res_out) {
   const DevPattern& p = h->pat;
   const bool split = h->world > 1 && h->n_peers > 0;
-  const int nblocks = split ? gl_spmv_grid(p.n_interior) + (p.n_boundary > 0 ? gl_spmv_grid(p.n_boundary) : 0)
+  const int nblocks = split ? (p.n_interior > 0 ? gl_spmv_grid(p.n_interior) : 0) +
+                                  (p.n_boundary > 0 ? gl_spmv_grid(p.n_boundary) : 0)
                             : gl_spmv_grid(p.n_slices);
   const int64_t n = h->n_own;
-  GL_HIP(hipMemsetAsync(h->scal.p, 0, SC_COUNT * sizeof(double), h->st));
+  // scal = [ping | pong | info{its, rr}]
+  GL_HIP(hipMemsetAsync(h->scal.p, 0, (2 * SC_COUNT + 2) * sizeof(double), h->st));
   GL_HIP(hipMemsetAsync(h->done.p, 0, sizeof(int), h->st));
   const unsigned g = grid_for(n);
+  const double tol2 = tol_abs * tol_abs;
 #define GL_VEC(K, ...)                                                                  \
   do {                                                                                  \
     if (v.bs == 1) hipLaunchKernelGGL(K<1>, dim3(g), dim3(256), 0, h->st, __VA_ARGS__); \
@@ -404,27 +409,28 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
     GL_HIP(hipGetLastError());                                                          \
   } while (0)
   GL_VEC(k_cg_init, n, v.r, v.dinv, v.u, v.p, v.s);
-  const double tol2 = tol_abs * tol_abs;
   int done = 0;
-  double sc[SC_COUNT];
+  double info[2] = {0.0, 0.0};
   const int batch = h->opt.check_every > 0 ? h->opt.check_every : 8;
   int enq = 0;
+  double* info_dev = h->scal.p + 2 * SC_COUNT;
   while (enq < maxit + 1) {
     const int nb = std::min(batch, maxit + 1 - enq);
     for (int j = 0; j < nb; ++j) {
+      const double* prev = h->scal.p + ((enq + j) & 1) * SC_COUNT;
+      double* cur = h->scal.p + ((enq + j + 1) & 1) * SC_COUNT;
       apply_with_halo(h, v);
       reduce_partials(h, nblocks, 3, h->done.p);
       allreduce_sum(h, h->red.p, 3);
-      hipLaunchKernelGGL(k_cg_scalars, dim3(1), dim3(1), 0, h->st, h->red.p, h->scal.p, h->done.p, tol2);
-      GL_VEC(k_cg_update, n, h->scal.p, h->done.p, v.p, v.s, v.x, v.r, v.u, v.w, v.dinv);
+      GL_VEC(k_cg_update, n, h->red.p, prev, cur, info_dev, h->done.p, tol2, v.p, v.s, v.x, v.r, v.u, v.w, v.dinv);
     }
     enq += nb;
-    poll(h, &done, sc);
+    poll(h, &done, info);
     if (done) break;
   }
 #undef GL_VEC
-  *its_out = (int64_t)sc[SC_IT];
-  *res_out = std::sqrt(sc[SC_RR]);
+  *its_out = (int64_t)info[0];
+  *res_out = std::sqrt(info[1]);
   if (done == 1) return GLIMS_OK;
   if (done == 2) return GLIMS_NAN;
   return GLIMS_NOT_CONVERGED;
