@@ -1,0 +1,191 @@
+"""
+SPMD support for the simulation classes: one process per GPU (``torchrun`` / ``torch.distributed``), the mesh
+partitioned by ``glimslib_amd.partition``, halos and reductions inside libglimship over RCCL.
+
+The reference's counterpart is "run the same script under ``mpirun -np N``" (README.md:142-183): DOLFIN distributes
+the mesh and PETSc does the communication.  Here every rank holds the full (host) mesh, owns a Morton range of the
+nodes on its GPU, and ``sync_solution`` all-gathers the owned values so that ``sim.solution`` is the global field
+on every rank.
+
+``HostStagedTransport`` is an alternative to RCCL that plugs into ``glims_set_transport``: device buffers are
+staged through the host and exchanged with the process group's CPU backend (gloo).  It exists for boxes where RCCL
+cannot be used -- e.g. several ranks sharing one GPU, which RCCL rejects ("Duplicate GPU detected") -- and is what
+the 2-rank single-GPU tests use.  Select it with ``GLIMS_TRANSPORT=gloo``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+from . import _backend
+from .partition import partition_mesh
+
+
+def dist_info():
+    """(dist module or None, rank, world)."""
+    try:
+        import torch.distributed as dist
+    except Exception:   # pragma: no cover
+        return None, 0, 1
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist, dist.get_rank(), dist.get_world_size()
+    return None, 0, 1
+
+
+class HostStagedTransport:
+    """glims_halo_fn / glims_allreduce_fn implemented with hipMemcpy staging + torch.distributed CPU collectives."""
+
+    def __init__(self, dist, group=None):
+        import torch
+        self.torch = torch
+        self.dist = dist
+        self.group = group
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+        self.hip = hip
+        self.halo_cb = _backend.HALO_FN(self._halo)
+        self.allreduce_cb = _backend.ALLREDUCE_FN(self._allreduce)
+
+    def _d2h(self, ptr, n):
+        a = np.empty(n)
+        if self.hip.hipMemcpy(a.ctypes.data, ptr, n * 8, 2) != 0:
+            raise RuntimeError("hipMemcpy D2H failed")
+        return a
+
+    def _h2d(self, ptr, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if self.hip.hipMemcpy(ptr, a.ctypes.data, a.size * 8, 1) != 0:
+            raise RuntimeError("hipMemcpy H2D failed")
+
+    def _halo(self, user, sendbuf, send_ptr, ghosts, recv_ptr, n_peers, peers, bs, stream):
+        try:
+            self.hip.hipStreamSynchronize(stream)
+            reqs, rbufs = [], []
+            for p in range(n_peers):
+                lo, hi = send_ptr[p] * bs, send_ptr[p + 1] * bs
+                sb = self.torch.from_numpy(self._d2h(sendbuf + lo * 8, hi - lo))
+                reqs.append(self.dist.isend(sb, int(peers[p]), group=self.group))
+                rb = self.torch.empty(int((recv_ptr[p + 1] - recv_ptr[p]) * bs), dtype=self.torch.float64)
+                reqs.append(self.dist.irecv(rb, int(peers[p]), group=self.group))
+                rbufs.append((recv_ptr[p] * bs, rb))
+            for r in reqs:
+                r.wait()
+            for off, rb in rbufs:
+                self._h2d(ghosts + off * 8, rb.numpy())
+            return 0
+        except Exception as e:   # noqa: BLE001 -- must not unwind through the C frame
+            print("glimslib_amd: halo transport failed: %r" % (e,), flush=True)
+            return 1
+
+    def _allreduce(self, user, values, n, stream):
+        try:
+            self.hip.hipStreamSynchronize(stream)
+            t = self.torch.from_numpy(self._d2h(values, n))
+            self.dist.all_reduce(t, group=self.group)
+            self._h2d(values, t.numpy())
+            return 0
+        except Exception as e:   # noqa: BLE001
+            print("glimslib_amd: allreduce transport failed: %r" % (e,), flush=True)
+            return 1
+
+
+class DistributedHandle:
+    """
+    Rank-local ``_backend.Handle`` + the index maps between global (mesh) and local (owned | ghost) numbering.
+    Presents the same methods the simulation classes use on a plain Handle, with *global* arrays at the interface.
+    """
+
+    def __init__(self, points, cells, cell_label, dist, rank, world, device):
+        import torch
+        self.dist, self.rank, self.world = dist, rank, world
+        self.n_global = len(points)
+        self.dim = np.asarray(points).shape[1]
+        self.part = partition_mesh(points, cells, world, rank)
+        p = self.part
+        self.h = _backend.Handle(p.points, p.cells, np.asarray(cell_label)[p.cell_ids], n_own=p.n_own, device=device)
+        self.cpu_group = None
+        use_gloo = os.environ.get("GLIMS_TRANSPORT", "rccl").lower() == "gloo"
+        if use_gloo:
+            self._transport = HostStagedTransport(dist)
+            self.h.set_transport(rank, world, self._transport.halo_cb, self._transport.allreduce_cb)
+        else:
+            uid = [_backend.Handle.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            self.h.comm_init(rank, world, uid[0])
+        self.h.set_halo(p.peer_rank, p.send_ptr, p.send_idx, p.recv_count)
+        self.g2l_owned = np.full(self.n_global, -1, dtype=np.int64)
+        self.g2l_owned[p.global_ids[:p.n_own]] = np.arange(p.n_own)
+        self.options = self.h.options
+
+    # -- pass-through -----------------------------------------------------------------------------------------
+    def set_materials(self, *a):
+        self.h.set_materials(*a)
+
+    def set_options(self, **kw):
+        self.h.set_options(**kw)
+
+    def setup(self, with_mechanics=True):
+        self.h.setup(with_mechanics)
+
+    def step(self, n=1):
+        return self.h.step(n)
+
+    def solve_mechanics(self):
+        return self.h.solve_mechanics()
+
+    def stats(self):
+        return self.h.stats()
+
+    def reset_stats(self):
+        self.h.reset_stats()
+
+    def close(self):
+        self.h.close()
+
+    # -- global <-> local -----------------------------------------------------------------------------------------
+    def _local(self, v, bs=1):
+        v = np.asarray(v, dtype=np.float64).reshape(self.n_global, bs) if bs > 1 else np.asarray(v, dtype=np.float64)
+        return v[self.part.global_ids]
+
+    def set_rd_load(self, f):
+        self.h.set_rd_load(None if f is None else self._local(f))
+
+    def set_mech_load(self, f):
+        self.h.set_mech_load(None if f is None else self._local(f, self.dim).reshape(-1))
+
+    def set_dirichlet_c(self, nodes, values):
+        nodes = np.asarray(nodes, dtype=np.int64)
+        loc = self.g2l_owned[nodes] if len(nodes) else nodes
+        keep = loc >= 0
+        self.h.set_dirichlet_c(loc[keep], np.asarray(values, dtype=np.float64)[keep] if len(nodes) else values)
+
+    def set_dirichlet_u(self, dofs, values):
+        dofs = np.asarray(dofs, dtype=np.int64)
+        if len(dofs) == 0:
+            self.h.set_dirichlet_u(dofs, values)
+            return
+        node, comp = dofs // self.dim, dofs % self.dim
+        loc = self.g2l_owned[node]
+        keep = loc >= 0
+        self.h.set_dirichlet_u(loc[keep] * self.dim + comp[keep], np.asarray(values, dtype=np.float64)[keep])
+
+    def set_state(self, c, u=None):
+        self.h.set_state(self._local(c), None if u is None else self._local(u, self.dim).reshape(-1))
+
+    def get_state(self, want_u=True):
+        """All-gathers the owned values: every rank returns the global fields."""
+        c, u = self.h.get_state(want_u=want_u)
+        n_own = self.part.n_own
+        mine = (self.part.global_ids[:n_own], c[:n_own], None if u is None else u.reshape(-1, self.dim)[:n_own])
+        parts = [None] * self.world
+        self.dist.all_gather_object(parts, mine)
+        cg = np.empty(self.n_global)
+        ug = np.empty((self.n_global, self.dim)) if want_u else None
+        for gid, cc, uu in parts:
+            cg[gid] = cc
+            if want_u:
+                ug[gid] = uu
+        return cg, (ug.reshape(-1) if want_u else None)

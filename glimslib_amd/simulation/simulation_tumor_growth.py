@@ -15,6 +15,7 @@ system for u only at recorded steps; same fixed point, checked against the monol
 from __future__ import annotations
 
 import logging
+import os
 
 import numpy as np
 
@@ -180,7 +181,14 @@ class TumorGrowth(FenicsSimulation):
             self.source_term = Constant(0.0)
         mechanics = bool(self.solver_options.get('mechanics', True))
         if self._backend is None:
-            self._backend = _backend.Handle(self.mesh.points, self.mesh.cells, labels, device=self.device)
+            from ..parallel import dist_info, DistributedHandle
+            dist, rank, world = dist_info()
+            if world > 1:
+                # SPMD like the reference under mpirun: this rank owns a Morton range of the nodes on its own GPU
+                device = int(os.environ.get("GLIMS_FORCE_DEVICE", os.environ.get("LOCAL_RANK", self.device)))
+                self._backend = DistributedHandle(self.mesh.points, self.mesh.cells, labels, dist, rank, world, device)
+            else:
+                self._backend = _backend.Handle(self.mesh.points, self.mesh.cells, labels, device=self.device)
         h = self._backend
         t = self._material_tables(n_labels)
         h.set_materials(t['D'], t['rho'], t['gamma'], t['E'], t['nu'])

@@ -157,3 +157,77 @@ def test_two_ranks_on_one_gpu_match_serial(tmp_path, backend):
     c1, u1 = h.get_state()
     h.close()
     assert rel_l2(c, c1) < 1e-10 and rel_l2(u.reshape(-1), u1) < 1e-9
+
+
+# ---- the same through the public API (SPMD under torch.distributed, like the reference under mpirun) -----------------
+def _api_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["GLIMS_TRANSPORT"] = "gloo"      # two ranks on one GPU: RCCL refuses, use the host-staged transport
+    os.environ["GLIMS_FORCE_DEVICE"] = "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from glimslib_amd import fenics_local as fenics
+        from glimslib_amd.simulation import TumorGrowthBrain
+
+        class Boundary(fenics.SubDomain):
+            def inside(self, x, on_boundary):
+                return on_boundary
+
+        mesh = fenics.BoxMesh(fenics.Point(0, 0, 0), fenics.Point(20, 18, 16), 10, 9, 8)
+        mid = mesh.cell_midpoints()
+        r = np.linalg.norm((mid - np.array([10, 9, 8])) / np.array([10, 9, 8]), axis=1)
+        lab = np.where(r < 0.25, 4, np.where(r < 0.6, 3, np.where(r < 0.85, 2, 1)))
+        sim = TumorGrowthBrain(mesh)
+        sim.setup_global_parameters(subdomains=lab, domain_names={1: 'CSF', 3: 'WM', 2: 'GM', 4: 'Ventricles'},
+                                    boundaries={'boundary_all': Boundary()},
+                                    dirichlet_bcs={'clamped_0': {'bc_value': fenics.Constant((0.0, 0.0, 0.0)),
+                                                                 'named_boundary': 'boundary_all', 'subspace_id': 0}})
+        iv = fenics.Expression('exp(-a*pow(x[0]-x0, 2) - a*pow(x[1]-y0, 2) - a*pow(x[2]-z0,2))', degree=1, a=0.05,
+                               x0=14, y0=9, z0=8)
+        sim.setup_model_parameters(iv_expression={0: fenics.Constant((0., 0., 0.)), 1: iv}, sim_time=4, sim_time_step=1,
+                                   E_GM=3000E-6, E_WM=3000E-6, E_CSF=1000E-6, E_VENT=1000E-6, nu_GM=0.45, nu_WM=0.45,
+                                   nu_CSF=0.45, nu_VENT=0.3, D_GM=0.01, D_WM=0.05, rho_GM=0.05, rho_WM=0.05,
+                                   coupling=0.1)
+        sol = sim.run(keep_nth=2, save_method=None, plot=False)
+        np.savez(os.path.join(out_dir, "api_rank%d.npz" % rank), c=sol.components[1], u=sol.components[0],
+                 steps=sim.results.get_recording_steps())
+        sim.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_public_api_spmd_two_ranks_equals_single_process(tmp_path):
+    world = 2
+    mp.spawn(_api_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    z0 = np.load(os.path.join(str(tmp_path), "api_rank0.npz"))
+    z1 = np.load(os.path.join(str(tmp_path), "api_rank1.npz"))
+    assert np.array_equal(z0['c'], z1['c']) and np.array_equal(z0['u'], z1['u'])      # every rank holds the global field
+    assert list(z0['steps']) == [0, 1, 2]
+    # single-process run of the same script
+    from glimslib_amd import fenics_local as fenics
+    from glimslib_amd.simulation import TumorGrowthBrain
+
+    class Boundary(fenics.SubDomain):
+        def inside(self, x, on_boundary):
+            return on_boundary
+
+    mesh = fenics.BoxMesh(fenics.Point(0, 0, 0), fenics.Point(20, 18, 16), 10, 9, 8)
+    mid = mesh.cell_midpoints()
+    r = np.linalg.norm((mid - np.array([10, 9, 8])) / np.array([10, 9, 8]), axis=1)
+    lab = np.where(r < 0.25, 4, np.where(r < 0.6, 3, np.where(r < 0.85, 2, 1)))
+    sim = TumorGrowthBrain(mesh)
+    sim.setup_global_parameters(subdomains=lab, domain_names={1: 'CSF', 3: 'WM', 2: 'GM', 4: 'Ventricles'},
+                                boundaries={'boundary_all': Boundary()},
+                                dirichlet_bcs={'clamped_0': {'bc_value': fenics.Constant((0.0, 0.0, 0.0)),
+                                                             'named_boundary': 'boundary_all', 'subspace_id': 0}})
+    iv = fenics.Expression('exp(-a*pow(x[0]-x0, 2) - a*pow(x[1]-y0, 2) - a*pow(x[2]-z0,2))', degree=1, a=0.05,
+                           x0=14, y0=9, z0=8)
+    sim.setup_model_parameters(iv_expression={0: fenics.Constant((0., 0., 0.)), 1: iv}, sim_time=4, sim_time_step=1,
+                               E_GM=3000E-6, E_WM=3000E-6, E_CSF=1000E-6, E_VENT=1000E-6, nu_GM=0.45, nu_WM=0.45,
+                               nu_CSF=0.45, nu_VENT=0.3, D_GM=0.01, D_WM=0.05, rho_GM=0.05, rho_WM=0.05, coupling=0.1)
+    sol = sim.run(keep_nth=2, save_method=None, plot=False)
+    sim.close()
+    assert rel_l2(z0['c'], sol.components[1]) < 1e-10
+    assert rel_l2(z0['u'], sol.components[0]) < 1e-8
