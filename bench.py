@@ -30,33 +30,36 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(budget_s=20.0):
+def cpu_baseline(budget_s=15.0):
     """
-    The CPU oracle (numpy/scipy restatement, oracle/glims_oracle.py) timed on this box's host cores on a bounded
-    sample of the same workload: the brain-extent box at n=40 cells/edge (68 921 DoF), as many implicit steps as fit
-    in ~budget_s seconds (at least 2).  kind = "port": FEniCS itself is not installed here.
+    CPU baseline ("port"): the C/OpenMP restatement oracle/glims_oracle_c.c (Newton + Jacobi-PCG on CSR, fp64, same
+    tolerances as the device run) on ALL host cores of this box, on a bounded sample of the same workload: the
+    brain-extent box at n=99 (config C3, 1 000 000 DoF), as many implicit steps as fit in ~budget_s seconds.
+    FEniCS itself is not installed here, hence kind = "port", not "reference".
     """
-    from oracle.glims_oracle import OracleTumorGrowth
+    from oracle.c_port import COracle
     from glimslib_amd import workloads
-    w = workloads.config_c3(n=40)
+    w = workloads.config_c3()
     t0 = time.perf_counter()
-    o = OracleTumorGrowth(w.mesh.points, w.mesh.cells, w.per_cell('D'), w.per_cell('rho'), w.per_cell('gamma'),
-                          w.per_cell('E'), w.per_cell('nu'), w.dt)
+    o = COracle(w.mesh.points, w.mesh.cells, w.per_cell('D'), w.per_cell('rho'), w.dt)
     t_setup = time.perf_counter() - t0
-    c = w.c0.copy()
-    c, _ = o.rd_step(c, rtol=1e-10, atol=1e-13, linear='cg')      # warm-up step (not timed)
+    c = o.step(w.c0, 1)                                             # warm-up step (not timed)
     steps = 0
     t0 = time.perf_counter()
     while True:
-        c, _ = o.rd_step(c, rtol=1e-10, atol=1e-13, linear='cg')
+        c = o.step(c, 1)
         steps += 1
         el = time.perf_counter() - t0
-        if steps >= 2 and el > budget_s or steps >= 50:
+        if (steps >= 3 and el > budget_s) or steps >= 200:
             break
     n = w.mesh.num_vertices()
-    return {"value": n * steps / el, "unit": "DoF-updates/s", "cores": 1, "kind": "port",
-            "sample": "oracle (numpy/scipy Newton + Jacobi-CG, fp64, 1 thread) on the same brain-extent box at "
-                      "n=40 (%d DoF), %d implicit steps in %.1f s (setup %.1f s excluded)" % (n, steps, el, t_setup)}
+    st = o.stats()
+    return {"value": n * steps / el, "unit": "DoF-updates/s", "cores": COracle.threads(), "kind": "port",
+            "sample": "oracle/glims_oracle_c.c (C + OpenMP, CSR Newton/Jacobi-PCG, fp64) on the same brain-extent box "
+                      "at n=99 (%d DoF): %d implicit steps in %.1f s on %d threads (setup %.1f s excluded; "
+                      "%.1f Newton, %.1f PCG iterations per step)" %
+                      (n, steps, el, COracle.threads(), t_setup, st['newton_its'] / (steps + 1.0),
+                       st['cg_its'] / (steps + 1.0))}
 
 
 def main():

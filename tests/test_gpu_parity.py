@@ -241,3 +241,22 @@ def test_c2_sized_step_matches_oracle_cg(backend):
     assert h.step(3) == 0
     assert rel_l2(h.get_state(want_u=False)[0], c) < 1e-9
     h.close()
+
+
+@pytest.mark.parametrize("name,steps", [("c2", 3), ("c3", 2)])
+def test_full_size_baseline_configs_match_the_c_oracle(backend, name, steps):
+    """BASELINE configs C2 (103 823 DoF) and C3 (1 000 000 DoF, two tissues) at FULL size against the C/OpenMP
+    oracle (a third independent implementation; finishes in seconds at these sizes)."""
+    from oracle.c_port import COracle
+    w = workloads.by_name(name)
+    co = COracle(w.mesh.points, w.mesh.cells, w.per_cell('D'), w.per_cell('rho'), w.dt)
+    ref = co.step(w.c0, steps, rtol=1e-11, cg_rtol=1e-4)
+    h = _handle(backend, w.mesh, w.cell_label, w.dt, w.tables, mechanics=False)
+    h.set_state(w.c0)
+    assert h.step(steps) == 0
+    c = h.get_state(want_u=False)[0]
+    assert rel_l2(c, ref) < 1e-9
+    x = np.random.default_rng(0).standard_normal(len(ref))
+    assert rel_l2(h.apply(2, x)[0], co.apply(2, x)) < 1e-13 and rel_l2(h.apply(1, x)[0], co.apply(1, x)) < 1e-13
+    h.close()
+    co.close()
