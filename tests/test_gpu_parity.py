@@ -260,3 +260,59 @@ def test_full_size_baseline_configs_match_the_c_oracle(backend, name, steps):
     assert rel_l2(h.apply(2, x)[0], co.apply(2, x)) < 1e-13 and rel_l2(h.apply(1, x)[0], co.apply(1, x)) < 1e-13
     h.close()
     co.close()
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_unstructured_numbering_and_ragged_rows(backend, dim):
+    """An 'unstructured' input: interior nodes jittered, node AND cell numbering randomly permuted, local vertex
+    order of every cell shuffled (orientation flips), 3 tissues.  Exercises the Morton / sigma renumbering, ragged
+    SELL slices and the slot maps; compared with the oracle on the permuted arrays and with the unpermuted run."""
+    rng = np.random.default_rng(10 + dim)
+    mesh, lab = _case(dim)
+    pts = mesh.points.copy()
+    f = mesh.facets()
+    interior = np.setdiff1d(np.arange(len(pts)), np.unique(f['vertices'][f['exterior']]))
+    h_min = np.min(np.ptp(pts, axis=0) / np.array([20, 17] if dim == 2 else [7, 6, 5]))
+    pts[interior] += 0.2 * h_min * (rng.random((len(interior), dim)) - 0.5)
+    n, m = len(pts), len(mesh.cells)
+    pn, pc = rng.permutation(n), rng.permutation(m)              # new node i = old node pn[i]
+    inv = np.empty(n, dtype=np.int64)
+    inv[pn] = np.arange(n)
+    cells2 = inv[mesh.cells[pc]]
+    for row in cells2:                                           # shuffle local vertex order per cell
+        rng.shuffle(row)
+    pts2, lab2 = pts[pn], lab[pc]
+    from glimslib_amd.mesh import Mesh
+    mesh2 = Mesh(pts2, cells2.astype(np.int32))
+    dt = 0.6
+    c0 = np.exp(-6 * ((pts - pts.mean(0)) ** 2).sum(1) / np.ptp(pts[:, 0]) ** 2)
+    bn = np.unique(f['vertices'][f['exterior']])
+    dofs2 = (inv[bn][:, None] * dim + np.arange(dim)).ravel()
+    o = _oracle(mesh2, lab2, dt, dirichlet_u=(dofs2, np.zeros(len(dofs2))))
+    uo, co = o.run(c0[pn], 4 * dt)
+    h = _handle(backend, mesh2, lab2, dt)
+    h.set_dirichlet_u(dofs2, np.zeros(len(dofs2)))
+    h.set_state(c0[pn])
+    assert h.step(4) == 0 and h.solve_mechanics() == 0
+    c, u = h.get_state()
+    assert rel_l2(c, co) < 1e-9 and rel_l2(u, uo) < 1e-8
+    st = h.stats()
+    assert st['nnz_padded'] >= st['nnz']
+    h.close()
+    # same physics in the original numbering
+    mesh1 = Mesh(pts, mesh.cells)
+    h = _handle(backend, mesh1, lab, dt)
+    dofs = (bn[:, None] * dim + np.arange(dim)).ravel()
+    h.set_dirichlet_u(dofs, np.zeros(len(dofs)))
+    h.set_state(c0)
+    assert h.step(4) == 0 and h.solve_mechanics() == 0
+    c1, u1 = h.get_state()
+    h.close()
+    assert rel_l2(c, c1[pn]) < 1e-10 and rel_l2(u.reshape(-1, dim), u1.reshape(-1, dim)[pn]) < 1e-8
+
+
+def test_orphaned_vertex_is_rejected_with_a_message(backend):
+    mesh, lab = _case(2)
+    pts = np.vstack([mesh.points, [[100.0, 100.0]]])             # a vertex no cell uses (cf. data_io.py:429-467)
+    with pytest.raises(backend.BackendError, match="orphan"):
+        backend.Handle(pts, mesh.cells, lab)
