@@ -147,21 +147,31 @@ __global__ __launch_bounds__(256) void k_reduce_stage1(int n, int nq, int per_bl
   }
 }
 
-__global__ __launch_bounds__(256) void k_reduce(int n, int nq, const double* __restrict__ partials,
-                                                 double* __restrict__ red, const int* __restrict__ done) {
+// final stage: ONE block of 1024 threads, every thread keeps nq (<= 3) independent accumulators so that its loads
+// are all in flight together; fixed summation order (thread-strided, then a fixed tree) -> reproducible.
+__global__ __launch_bounds__(1024) void k_reduce(int n, int nq, const double* __restrict__ partials,
+                                                  double* __restrict__ red, const int* __restrict__ done) {
   if (done && *done) return;
-  __shared__ double sm[256];
-  for (int q = 0; q < nq; ++q) {
-    double v = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) v += partials[(size_t)i * nq + q];
-    sm[threadIdx.x] = v;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) red[q] = sm[0];
-    __syncthreads();
+  __shared__ double sm[16][3];
+  double v[3] = {0.0, 0.0, 0.0};
+  const int total = n * nq;   // partials are [n][nq]: walk the flat array with a stride that is a multiple of nq
+  const int stride = 1024 * nq;
+  for (int i = threadIdx.x * nq; i < total; i += stride)
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      if (q < nq) v[q] += partials[i + q];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v[q] += __shfl_down(v[q], o, 64);
+  }
+  if ((threadIdx.x & 63) == 0)
+    for (int q = 0; q < 3; ++q) sm[threadIdx.x >> 6][q] = v[q];
+  __syncthreads();
+  if ((int)threadIdx.x < nq) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += sm[w][threadIdx.x];
+    red[threadIdx.x] = t;
   }
 }
 
@@ -318,13 +328,13 @@ void gl_comm_destroy(glims_ctx* h) {
 }
 
 static void reduce_partials(glims_ctx* h, int n, int nq, const int* done) {
-  if (n > 2048) {
+  if (n > 16384) {
     const int per_block = 1024, nb1 = (n + per_block - 1) / per_block;
     hipLaunchKernelGGL(k_reduce_stage1, dim3(nb1), dim3(256), 0, h->st, n, nq, per_block, h->partials.p,
                        h->partials2.p, done);
-    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, h->st, nb1, nq, h->partials2.p, h->red.p, done);
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, nb1, nq, h->partials2.p, h->red.p, done);
   } else {
-    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, h->st, n, nq, h->partials.p, h->red.p, done);
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, n, nq, h->partials.p, h->red.p, done);
   }
   GL_HIP(hipGetLastError());
 }
@@ -389,7 +399,10 @@ static void apply_with_halo(glims_ctx* h, const CgVecs& v) {
                          h->done.p);
 }
 
-static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, int64_t* its_out, double* res_out) {
+// `hint`: expected iteration count (0 = unknown).  The first batch is hint + 1 launches (the extra one only detects
+// convergence), later batches are short; every launch after the device-side `done` is a ~2 us no-op.
+static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, int hint, int64_t* its_out,
+                    double* res_out) {
   const DevPattern& p = h->pat;
   const bool split = h->world > 1 && h->n_peers > 0;
   const int nblocks = split ? (p.n_interior > 0 ? gl_spmv_grid(p.n_interior) : 0) +
@@ -415,7 +428,9 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
   int enq = 0;
   double* info_dev = h->scal.p + 2 * SC_COUNT;
   while (enq < maxit + 1) {
-    const int nb = std::min(batch, maxit + 1 - enq);
+    int want = batch;
+    if (hint > 0) want = enq == 0 ? hint + 1 : std::max(2, std::min(batch, hint / 4 + 1));
+    const int nb = std::min(want, maxit + 1 - enq);
     for (int j = 0; j < nb; ++j) {
       const double* prev = h->scal.p + ((enq + j) & 1) * SC_COUNT;
       double* cur = h->scal.p + ((enq + j + 1) & 1) * SC_COUNT;
@@ -500,7 +515,9 @@ int gl_step(glims_ctx* h, int n_steps) {
                h->dinv.p, h->vA.p, h->have_fixed_c ? h->fixed_c.p : nullptr, 1};
       int64_t its = 0;
       double res = 0.0;
-      const int cs = cg_solve(h, v, tol_lin, o.cg_maxit, &its, &res);
+      const int slot = std::min(it, 7);
+      const int cs = cg_solve(h, v, tol_lin, o.cg_maxit, h->cg_hint[slot], &its, &res);
+      h->cg_hint[slot] = (int)its;
       h->stats.cg_its += its;
       h->stats.newton_its++;
       h->stats.last_cg_res = res;
@@ -580,7 +597,8 @@ int gl_solve_mechanics(glims_ctx* h) {
   CgVecs v{h->U.p, h->m_r.p, h->m_u.p, h->m_w.p, h->m_p.p, h->m_s.p, h->m_dinv.p, nullptr, fx, bs};
   int64_t its = 0;
   double res = 0.0;
-  int cs = cg_solve(h, v, tol, h->opt.mech_maxit, &its, &res);
+  int cs = cg_solve(h, v, tol, h->opt.mech_maxit, h->mech_hint, &its, &res);
+  h->mech_hint = (int)its;
   h->stats.mech_cg_its += its;
   h->stats.mech_solves++;
   h->stats.last_mech_res = res;
