@@ -71,6 +71,7 @@ SIGNATURES = {
     "glims_reset_stats": (C.c_int, [_h]),
     "glims_apply": (C.c_int, [_h, C.c_int, _dp, _dp, C.c_int, _dp]),
     "glims_rd_residual": (C.c_int, [_h, _dp, _dp, _dp]),
+    "glims_project": (C.c_int, [_h, _dp, _dp, C.c_int, C.c_double]),
     "glims_comm_unique_id": (C.c_int, [C.c_char_p]),
     "glims_comm_init": (C.c_int, [_h, C.c_int, C.c_int, C.c_char_p]),
     "glims_set_halo": (C.c_int, [_h, C.c_int, _i32p, _i64p, _i32p, _i64p]),
@@ -232,6 +233,15 @@ class Handle:
         R = np.empty(self.n_nodes)
         self._check(self.lib.glims_rd_residual(self._h, _ptr(c, _dp), _ptr(cp, _dp), _ptr(R, _dp)))
         return R
+
+    def project(self, rhs, rtol=1e-12):
+        """Solve M x = rhs for rhs [n_nodes] or [n_nodes, k] (L2 projection onto P1 given integrated loads)."""
+        rhs = np.asarray(rhs, dtype=np.float64)
+        k = 1 if rhs.ndim == 1 else rhs.shape[1]
+        r = _f64(rhs.reshape(self.n_nodes, k))
+        x = np.empty_like(r)
+        self._check(self.lib.glims_project(self._h, _ptr(r, _dp), _ptr(x, _dp), int(k), float(rtol)))
+        return x.reshape(rhs.shape)
 
     # -- multi-GPU -------------------------------------------------------------------------------
     @staticmethod

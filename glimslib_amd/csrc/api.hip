@@ -495,6 +495,27 @@ int glims_rd_residual(glims_ctx* h, const double* c, const double* c_prev, doubl
   });
 }
 
+int glims_project(glims_ctx* h, const double* rhs, double* x, int ncomp, double rtol) {
+  return guarded(h, [&]() {
+    GL_REQUIRE(rhs && x && ncomp >= 1 && rtol > 0.0, "bad arguments");
+    const int64_t n = h->n_nodes;
+    std::vector<double> col(n), out(n);
+    dvec<double> d_rhs, d_x;
+    d_rhs.alloc_zero((size_t)n, h->st);
+    d_x.alloc_zero((size_t)n, h->st);
+    int status = GLIMS_OK;
+    for (int q = 0; q < ncomp; ++q) {
+      for (int64_t i = 0; i < n; ++i) col[i] = rhs[i * ncomp + q];
+      to_device_perm(h, col.data(), d_rhs.p, 1);
+      const int st = gl_project(h, d_rhs.p, d_x.p, rtol);
+      if (st != GLIMS_OK) status = st;
+      from_device_perm(h, d_x.p, out.data(), 1, h->n_nodes);
+      for (int64_t i = 0; i < n; ++i) x[i * ncomp + q] = out[i];
+    }
+    return status;
+  });
+}
+
 int glims_comm_unique_id(char id[GLIMS_UNIQUE_ID_BYTES]) {
   static_assert(GLIMS_UNIQUE_ID_BYTES >= 2 * sizeof(ncclUniqueId), "unique id buffer too small");
   if (!id) return GLIMS_E_USAGE;

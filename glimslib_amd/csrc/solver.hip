@@ -555,6 +555,38 @@ int gl_step(glims_ctx* h, int n_steps) {
 }
 
 // ===================================================================================================
+// L2 projection: M x = rhs (consistent P1 mass matrix), Jacobi-PCG with the same single-reduction recurrence
+// ===================================================================================================
+__global__ void k_mass_dinv(int64_t n_own, const int64_t* __restrict__ slice_ptr, const uint8_t* __restrict__ diag_k,
+                            const double* __restrict__ vM, double* __restrict__ dinv) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n_own) return;
+  dinv[row] = 1.0 / vM[slice_ptr[row >> 6] + (int64_t)diag_k[row] * GL_WAVE + (row & 63)];
+}
+
+int gl_project(glims_ctx* h, double* rhs, double* x, double rtol) {
+  GL_REQUIRE(h->is_setup, "glims_project before glims_setup");
+  const int64_t n = h->n_own;
+  h->pending = false;   // dinv and the PCG work vectors are shared with the time stepper
+  hipLaunchKernelGGL(k_mass_dinv, dim3(grid_exact(n)), dim3(256), 0, h->st, n, h->pat.slice_ptr.p, h->pat.diag_k.p,
+                     h->vM.p, h->dinv.p);
+  const unsigned gd = grid_for(n, 256, 1024);
+  hipLaunchKernelGGL(k_dot_partials, dim3(gd), dim3(256), 0, h->st, n, rhs, rhs, h->partials.p);
+  reduce_partials(h, (int)gd, 1, nullptr);
+  allreduce_sum(h, h->red.p, 1);
+  const double nb = std::sqrt(read_red0(h));
+  GL_HIP(hipMemsetAsync(x, 0, (size_t)h->n_nodes * sizeof(double), h->st));
+  if (!(nb > 0.0)) return std::isfinite(nb) ? GLIMS_OK : GLIMS_NAN;
+  CgVecs v{x, rhs, h->cg_u.p, h->cg_w.p, h->cg_p.p, h->cg_s.p, h->dinv.p, h->vM.p, nullptr, 1};
+  int64_t its = 0;
+  double res = 0.0;
+  const int cs = cg_solve(h, v, rtol * nb, 10000, 0, &its, &res);
+  gl_halo_exchange(h, x, 1);
+  GL_HIP(hipStreamSynchronize(h->st));
+  return cs;
+}
+
+// ===================================================================================================
 // mechanics:  K_el u = G c + f,  Dirichlet dofs eliminated symmetrically (projected operator P K P)
 // ===================================================================================================
 int gl_solve_mechanics(glims_ctx* h) {

@@ -145,6 +145,17 @@ class DistributedHandle:
     def close(self):
         self.h.close()
 
+    def project(self, rhs, rtol=1e-12):
+        rhs = np.asarray(rhs, dtype=np.float64)
+        loc = self.h.project(rhs[self.part.global_ids], rtol)
+        n_own = self.part.n_own
+        parts = [None] * self.world
+        self.dist.all_gather_object(parts, (self.part.global_ids[:n_own], loc[:n_own]))
+        out = np.empty_like(rhs)
+        for gid, v in parts:
+            out[gid] = v
+        return out
+
     # -- global <-> local -----------------------------------------------------------------------------------------
     def _local(self, v, bs=1):
         v = np.asarray(v, dtype=np.float64).reshape(self.n_global, bs) if bs > 1 else np.asarray(v, dtype=np.float64)

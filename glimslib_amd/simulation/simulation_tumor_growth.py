@@ -219,5 +219,16 @@ class TumorGrowth(FenicsSimulation):
         self.run(keep_nth=1, save_method=None, clear_all=False, plot=False, output_dir=output_dir)
         return self.solution
 
+    def init_postprocess(self, output_dir=config.output_dir_simulation_tmp):
+        """:172-173 -- derived fields (stress, pressure, Jacobians ...) of the recorded solutions"""
+        from ..simulation_helpers.postprocess import PostProcessTumorGrowth
+        if self._backend is None:
+            raise RuntimeError("init_postprocess needs a finished run() (the L2 projections run on its device backend)")
+        labels = self._labels()
+        t = self._material_tables(int(labels.max()) + 1)
+        self.postprocess = PostProcessTumorGrowth(self.results, self.params, output_dir=output_dir,
+                                                  backend=self._backend, tables=t, labels=labels)
+        return self.postprocess
+
     def solver_statistics(self):
         return self._backend.stats() if self._backend is not None else {}

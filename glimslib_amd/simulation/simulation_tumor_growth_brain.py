@@ -66,3 +66,15 @@ class TumorGrowthBrain(TumorGrowth):
         self.params.coupling = parameters[4]
         self.run(keep_nth=1, save_method=None, clear_all=False, plot=False, output_dir=output_dir)
         return self.solution
+
+    def init_postprocess(self, output_dir=config.output_dir_simulation_tmp):
+        """:148-152"""
+        from ..simulation_helpers.postprocess import PostProcessTumorGrowthBrain
+        if self._backend is None:
+            raise RuntimeError("init_postprocess needs a finished run()")
+        labels = self._labels()
+        t = self._material_tables(int(labels.max()) + 1)
+        self.postprocess = PostProcessTumorGrowthBrain(self.results, self.params, output_dir=output_dir,
+                                                       backend=self._backend, tables=t, labels=labels)
+        self.postprocess.map_params()
+        return self.postprocess

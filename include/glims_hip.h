@@ -154,6 +154,12 @@ int glims_apply(glims_ctx* h, int which, const double* x, double* y, int reps, d
  *   R = 1/2 (A(c) + S) c - M c_prev - rd_load.  R may be NULL. */
 int glims_rd_residual(glims_ctx* h, const double* c, const double* c_prev, double* R);
 
+/* L2 projection onto the P1 space: solves M x = rhs for `ncomp` right-hand sides stored [n_nodes][ncomp]
+ * (rhs_i = int f phi_i dx, integrated by the caller), Jacobi-PCG to ||r|| <= rtol*||rhs|| per component.
+ * Stands in for fenics.project(expr, FunctionSpace(mesh, "Lagrange", 1)) as used by the PostProcess classes
+ * (helper_classes.py:1566-1618, 1736-1786).  Ghost entries of rhs are ignored, ghosts of x are filled. */
+int glims_project(glims_ctx* h, const double* rhs, double* x, int ncomp, double rtol);
+
 /* ---- single-node multi-GPU (one process per GPU, RCCL over xGMI) ------------------------------------- */
 
 #define GLIMS_UNIQUE_ID_BYTES 256   /* two RCCL unique ids: halo communicator + reduction communicator */
