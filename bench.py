@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--extrapolate", type=int, default=0)
     ap.add_argument("--cg-rtol", type=float, default=None, help="override glims_options.cg_rtol (tuning runs only)")
     ap.add_argument("--check-every", type=int, default=None)
+    ap.add_argument("--warm-start", type=int, default=None, help="override GLIMS_FLAG_WARM_START (tuning runs only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -135,7 +136,10 @@ def main():
         extra["cg_rtol"] = args.cg_rtol
     if args.check_every is not None:
         extra["check_every"] = args.check_every
-    h.set_options(dt=w.dt, flags=FLAG_EXTRAPOLATE_GUESS if args.extrapolate else 0, **extra)
+    flags = FLAG_EXTRAPOLATE_GUESS if args.extrapolate else h.options.flags
+    if args.warm_start is not None:
+        flags = (flags | 2) if args.warm_start else (flags & ~2)
+    h.set_options(dt=w.dt, flags=flags, **extra)
     h.setup(with_mechanics=False)
     h.set_state(c0)
     st0 = h.stats()

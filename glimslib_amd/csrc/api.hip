@@ -94,7 +94,7 @@ int glims_options_default(glims_options* o) {
   o->mech_atol = 0.0;
   o->mech_maxit = 200000;
   o->check_every = 8;
-  o->flags = 0;
+  o->flags = GLIMS_FLAG_WARM_START;
   return GLIMS_OK;
 }
 
@@ -384,6 +384,7 @@ int glims_set_state(glims_ctx* h, const double* c, const double* u) {
   return guarded(h, [&]() {
     GL_REQUIRE(c, "null concentration");
     h->pending = false;
+    h->have_c_old = false;
     to_device_perm(h, c, h->c.p, 1);
     if (h->U.p) {
       if (u)

@@ -137,6 +137,7 @@ struct glims_ctx {
   dvec<double> cg_p, cg_s, cg_u, cg_w, cg_r, cg_r2, b2;     // scalar CG work vectors; r2/b2: speculative next step
   int cg_hint[8] = {0, 0, 0, 0, 0, 0, 0, 0};                  // PCG iterations of the k-th Newton solve of the previous step
   int mech_hint = 0;
+  bool have_c_old = false;                                    // c_old holds the state at the start of the previous step
   bool pending = false;                                      // cg_r / b / vA already hold the first assembly of the next step
   double pending_r0 = 0.0;
   dvec<double> U, mload, m_rhs, m_x, m_p, m_s, m_u, m_w, m_r, m_dinv, m_uD;   // mechanics, [n_nodes*dim]

@@ -205,6 +205,23 @@ __global__ void k_extrapolate(int64_t n, double* __restrict__ c, double* __restr
   if (have_old && !(fixed && fixed[i])) c[i] = 2.0 * cur - old;
 }
 
+// warm start of a step's first Newton solve: u = c - c_old (the previous step's increment), c_old = c
+__global__ void k_ws_delta(int64_t n, const double* __restrict__ c, double* __restrict__ c_old, double* __restrict__ u) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double ci = c[i];
+  u[i] = ci - c_old[i];
+  c_old[i] = ci;
+}
+// r -= A u (w = A u), c += u
+__global__ void k_ws_apply(int64_t n, double* __restrict__ r, const double* __restrict__ w, double* __restrict__ c,
+                           const double* __restrict__ u) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  r[i] -= w[i];
+  c[i] += u[i];
+}
+
 __global__ __launch_bounds__(256) void k_dot_partials(int64_t n, const double* __restrict__ a,
                                                        const double* __restrict__ b, double* __restrict__ partials) {
   __shared__ double sm[4];
@@ -511,6 +528,19 @@ int gl_step(glims_ctx* h, int n_steps) {
       }
       // A(c_k) delta = -R(c_k);  the update is accumulated straight into c (x0 = 0  <=>  x = c_k)
       const double tol_lin = std::max(std::max(o.cg_atol, 0.1 * target), o.cg_rtol * nr);
+      if (it == 0 && (o.flags & GLIMS_FLAG_WARM_START)) {
+        // initial guess of the first linear solve = the previous step's total increment: same linear system, same
+        // solution, the Krylov iteration just starts closer.  One SpMV with the already assembled A(c^n).
+        hipLaunchKernelGGL(k_ws_delta, dim3(grid_exact(h->n_nodes)), dim3(256), 0, h->st, h->n_nodes, h->c.p,
+                           h->c_old.p, h->cg_u.p);
+        if (h->have_c_old) {
+          gl_launch_spmv(h, h->st, p.n_slices, nullptr, h->vA.p, h->cg_u.p, h->cg_w.p,
+                         h->have_fixed_c ? h->fixed_c.p : nullptr, nullptr, nullptr, nullptr, 0, nullptr);
+          hipLaunchKernelGGL(k_ws_apply, dim3(grid_exact(n)), dim3(256), 0, h->st, n, h->cg_r.p, h->cg_w.p, h->c.p,
+                             h->cg_u.p);
+        }
+        h->have_c_old = true;
+      }
       CgVecs v{h->c.p, h->cg_r.p, h->cg_u.p, h->cg_w.p, h->cg_p.p, h->cg_s.p,
                h->dinv.p, h->vA.p, h->have_fixed_c ? h->fixed_c.p : nullptr, 1};
       int64_t its = 0;

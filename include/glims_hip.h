@@ -60,10 +60,11 @@ typedef struct glims_options {
   double mech_atol;       /*                                                               default 0     */
   int    mech_maxit;      /*                                                               default 200000*/
   int    check_every;     /* Krylov iterations enqueued between host convergence polls      default 8     */
-  int    flags;           /* GLIMS_FLAG_* */
+  int    flags;           /* GLIMS_FLAG_*                                                   default WARM_START */
 } glims_options;
 
 #define GLIMS_FLAG_EXTRAPOLATE_GUESS 1  /* Newton guess c^n + (c^n - c^{n-1}) instead of c^n (reference: c^n) */
+#define GLIMS_FLAG_WARM_START 2         /* first linear solve of a step starts from the previous step's increment */
 
 typedef struct glims_stats {
   int64_t steps;            /* implicit time steps taken */
