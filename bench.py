@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--extrapolate", type=int, default=0)
     ap.add_argument("--cg-rtol", type=float, default=None, help="override glims_options.cg_rtol (tuning runs only)")
     ap.add_argument("--check-every", type=int, default=None)
+    ap.add_argument("--newton-rtol", type=float, default=None)
     ap.add_argument("--warm-start", type=int, default=None, help="override GLIMS_FLAG_WARM_START (tuning runs only)")
     args = ap.parse_args()
 
@@ -136,6 +137,8 @@ def main():
         extra["cg_rtol"] = args.cg_rtol
     if args.check_every is not None:
         extra["check_every"] = args.check_every
+    if args.newton_rtol is not None:
+        extra["newton_rtol"] = args.newton_rtol
     flags = FLAG_EXTRAPOLATE_GUESS if args.extrapolate else h.options.flags
     if args.warm_start is not None:
         flags = (flags | 2) if args.warm_start else (flags & ~2)

@@ -317,3 +317,52 @@ def test_orphaned_vertex_is_rejected_with_a_message(backend):
     pts = np.vstack([mesh.points, [[100.0, 100.0]]])             # a vertex no cell uses (cf. data_io.py:429-467)
     with pytest.raises(backend.BackendError, match="orphan"):
         backend.Handle(pts, mesh.cells, lab)
+
+
+def test_edge_cases_empty_and_degenerate_inputs(backend):
+    """Zero steps, an all-zero state (||R_0|| = 0), a single-cell mesh (one slice of 61-62 padding rows), the largest
+    admissible tissue id, and a mesh where every cell has rho = D = 0 (the sweep skips every incidence)."""
+    # single triangle / single tetrahedron
+    for pts, cells in ((np.array([[0., 0.], [1., 0.], [0., 1.]]), np.array([[0, 1, 2]], dtype=np.int32)),
+                       (np.array([[0., 0, 0], [1., 0, 0], [0, 1., 0], [0, 0, 1.]]), np.array([[0, 1, 2, 3]], dtype=np.int32))):
+        from glimslib_amd.mesh import Mesh
+        mesh = Mesh(pts, cells)
+        lab = np.array([255], dtype=np.int32)
+        tabs = {k: np.zeros(256) for k in ('D', 'rho', 'gamma')}
+        tabs['E'], tabs['nu'] = np.ones(256), np.full(256, 0.3)
+        tabs['D'][255], tabs['rho'][255], tabs['gamma'][255] = 0.1, 0.2, 0.1
+        h = _handle(backend, mesh, lab, 0.5, tabs)
+        o = _oracle(mesh, lab, 0.5, tabs)
+        c0 = np.linspace(0.1, 0.4, len(pts))
+        h.set_state(c0)
+        assert h.step(0) == 0                                        # zero steps: state untouched
+        assert np.array_equal(h.get_state(want_u=False)[0], c0)
+        assert h.step(3) == 0
+        _, co = o.run(c0, 1.5, mechanics=False)
+        assert rel_l2(h.get_state(want_u=False)[0], co) < 1e-10
+        h.set_state(np.zeros(len(pts)))                               # zero state: R_0 = 0, nothing to solve
+        assert h.step(2) == 0 and h.stats()['newton_its'] == h.stats()['newton_its']
+        assert np.array_equal(h.get_state(want_u=False)[0], np.zeros(len(pts)))
+        h.close()
+    # inert tissue everywhere: c stays exactly what the mass matrix preserves (M c = M c_prev  =>  c = c_prev)
+    mesh, lab = _case(3)
+    tabs = dict(D=[0.0] * 4, rho=[0.0] * 4, gamma=[0.0] * 4, E=[1.0] * 4, nu=[0.3] * 4)
+    h = _handle(backend, mesh, lab, 1.0, tabs, mechanics=False)
+    c0 = np.random.default_rng(3).random(mesh.num_vertices())
+    h.set_state(c0)
+    assert h.step(2) == 0
+    assert np.abs(h.get_state(want_u=False)[0] - c0).max() < 1e-12
+    h.close()
+
+
+def test_options_newton_tolerance_of_the_reference(backend):
+    """SNES defaults of the reference (rtol 1e-9): still far inside the 1e-6 parity bar."""
+    mesh, lab = _case(3)
+    c0 = np.exp(-4 * ((mesh.points - mesh.points.mean(0)) ** 2).sum(1))
+    o = _oracle(mesh, lab, 1.0)
+    _, co = o.run(c0, 8.0, mechanics=False)
+    h = _handle(backend, mesh, lab, 1.0, mechanics=False, newton_rtol=1e-9, newton_atol=1e-10)
+    h.set_state(c0)
+    assert h.step(8) == 0
+    assert rel_l2(h.get_state(want_u=False)[0], co) < 1e-8
+    h.close()
