@@ -93,8 +93,37 @@ __global__ void k_cg_update(int64_t n_own, const double* __restrict__ red, const
     info[0] = it + 1.0;
   }
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_own; i += stride) {
-    if constexpr (BS == 1) {
+  if constexpr (BS == 1) {
+    // 16 B per lane (two rows per thread): all seven streams are hipMalloc-aligned
+    const int64_t n2 = n_own >> 1;
+    double2* p2 = reinterpret_cast<double2*>(p);
+    double2* s2 = reinterpret_cast<double2*>(s);
+    double2* x2 = reinterpret_cast<double2*>(x);
+    double2* r2 = reinterpret_cast<double2*>(r);
+    double2* u2 = reinterpret_cast<double2*>(u);
+    const double2* w2 = reinterpret_cast<const double2*>(w);
+    const double2* d2 = reinterpret_cast<const double2*>(dinv);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+      const double2 uu = u2[i], pp = p2[i], ww = w2[i], ss = s2[i], rr2 = r2[i], dd = d2[i];
+      double2 xx = x2[i], pn, sn, rn, un;
+      pn.x = uu.x + beta * pp.x;
+      pn.y = uu.y + beta * pp.y;
+      sn.x = ww.x + beta * ss.x;
+      sn.y = ww.y + beta * ss.y;
+      xx.x += alpha * pn.x;
+      xx.y += alpha * pn.y;
+      rn.x = rr2.x - alpha * sn.x;
+      rn.y = rr2.y - alpha * sn.y;
+      un.x = dd.x * rn.x;
+      un.y = dd.y * rn.y;
+      p2[i] = pn;
+      s2[i] = sn;
+      x2[i] = xx;
+      r2[i] = rn;
+      u2[i] = un;
+    }
+    if ((n_own & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+      const int64_t i = n_own - 1;
       const double pi = u[i] + beta * p[i];
       const double si = w[i] + beta * s[i];
       p[i] = pi;
@@ -103,6 +132,12 @@ __global__ void k_cg_update(int64_t n_own, const double* __restrict__ red, const
       const double ri = r[i] - alpha * si;
       r[i] = ri;
       u[i] = dinv[i] * ri;
+    }
+    return;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_own; i += stride) {
+    if constexpr (BS == 1) {
+      // (handled above)
     } else {
       double rv[BS];
 #pragma unroll
