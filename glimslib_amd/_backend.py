@@ -75,6 +75,7 @@ SIGNATURES = {
     "glims_project": (C.c_int, [_h, _dp, _dp, C.c_int, C.c_double]),
     "glims_comm_unique_id": (C.c_int, [C.c_char_p]),
     "glims_comm_init": (C.c_int, [_h, C.c_int, C.c_int, C.c_char_p]),
+    "glims_comm_selftest": (C.c_int, [_h]),
     "glims_set_halo": (C.c_int, [_h, C.c_int, _i32p, _i64p, _i32p, _i64p]),
     "glims_set_transport": (C.c_int, [_h, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
@@ -257,6 +258,9 @@ class Handle:
     def comm_init(self, rank, world, uid):
         assert len(uid) == GLIMS_UNIQUE_ID_BYTES
         self._check(self.lib.glims_comm_init(self._h, int(rank), int(world), uid))
+
+    def comm_selftest(self):
+        self._check(self.lib.glims_comm_selftest(self._h))
 
     def set_transport(self, rank, world, halo_cb, allreduce_cb):
         """halo_cb / allreduce_cb: HALO_FN / ALLREDUCE_FN instances (kept alive by this handle)."""

@@ -548,6 +548,10 @@ int glims_comm_init(glims_ctx* h, int rank, int world, const char id[GLIMS_UNIQU
   });
 }
 
+int glims_comm_selftest(glims_ctx* h) {
+  return guarded(h, [&]() { return gl_comm_selftest(h); });
+}
+
 int glims_set_transport(glims_ctx* h, int rank, int world, glims_halo_fn halo, glims_allreduce_fn allreduce,
                         void* user) {
   return guarded(h, [&]() {

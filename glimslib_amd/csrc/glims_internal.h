@@ -185,4 +185,5 @@ int gl_step(glims_ctx* h, int n_steps);
 int gl_solve_mechanics(glims_ctx* h);
 void gl_halo_exchange(glims_ctx* h, double* vec, int bs);   // blocking w.r.t. h->st (no overlap)
 void gl_comm_destroy(glims_ctx* h);
+int gl_comm_selftest(glims_ctx* h);
 int gl_project(glims_ctx* h, double* rhs_dev /*[n_nodes], overwritten*/, double* x_dev /*[n_nodes]*/, double rtol);

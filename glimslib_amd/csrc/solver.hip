@@ -705,3 +705,61 @@ int gl_solve_mechanics(glims_ctx* h) {
   GL_HIP(hipStreamSynchronize(h->st));
   return cs;
 }
+
+
+// ===================================================================================================
+// RCCL self-test on a one-rank communicator (see glims_comm_selftest in the header)
+// ===================================================================================================
+__global__ void k_fill_iota(int64_t n, double* __restrict__ v, double scale) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = scale * (double)(i + 1);
+}
+
+int gl_comm_selftest(glims_ctx* h) {
+  const int64_t n = 4096;
+  const int bs = 3;
+  ncclUniqueId ida, idb;
+  GL_NCCL(ncclGetUniqueId(&ida));
+  GL_NCCL(ncclGetUniqueId(&idb));
+  ncclComm_t ca = nullptr, cb = nullptr;
+  GL_NCCL(ncclCommInitRank(&ca, 1, ida, 0));
+  GL_NCCL(ncclCommInitRank(&cb, 1, idb, 0));
+  dvec<double> vec, sendbuf, red;
+  dvec<int32_t> idx;
+  vec.alloc_zero((size_t)2 * n * bs, h->st);          // [owned n | ghosts n], block size 3
+  sendbuf.alloc_zero((size_t)n * bs, h->st);
+  red.alloc_zero(4, h->st);
+  std::vector<int32_t> hidx(n);
+  for (int64_t k = 0; k < n; ++k) hidx[k] = (int32_t)(n - 1 - k);   // send the owned nodes in reverse order
+  idx.upload(hidx, h->st);
+  hipLaunchKernelGGL(k_fill_iota, dim3(grid_exact(n * bs)), dim3(256), 0, h->st, n * bs, vec.p, 0.5);
+  // --- the halo sequence of halo_start()/halo_finish(), peer = self ---
+  hipLaunchKernelGGL(k_pack, dim3(grid_exact(n * bs)), dim3(256), 0, h->st, n, bs, idx.p, vec.p, sendbuf.p);
+  GL_HIP(hipEventRecord(h->ev_pack, h->st));
+  GL_HIP(hipStreamWaitEvent(h->st_comm, h->ev_pack, 0));
+  GL_NCCL(ncclGroupStart());
+  GL_NCCL(ncclSend(sendbuf.p, (size_t)n * bs, ncclDouble, 0, ca, h->st_comm));
+  GL_NCCL(ncclRecv(vec.p + n * bs, (size_t)n * bs, ncclDouble, 0, ca, h->st_comm));
+  GL_NCCL(ncclGroupEnd());
+  GL_HIP(hipEventRecord(h->ev_halo, h->st_comm));
+  GL_HIP(hipStreamWaitEvent(h->st, h->ev_halo, 0));
+  // --- the reduction sequence of allreduce_sum() ---
+  hipLaunchKernelGGL(k_fill_iota, dim3(1), dim3(256), 0, h->st, (int64_t)3, red.p, 1.25);
+  GL_NCCL(ncclAllReduce(red.p, red.p, 3, ncclDouble, ncclSum, cb, h->st));
+  std::vector<double> out((size_t)2 * n * bs), r3(3);
+  GL_HIP(hipMemcpyAsync(out.data(), vec.p, out.size() * sizeof(double), hipMemcpyDeviceToHost, h->st));
+  GL_HIP(hipMemcpyAsync(r3.data(), red.p, 3 * sizeof(double), hipMemcpyDeviceToHost, h->st));
+  GL_HIP(hipStreamSynchronize(h->st));
+  GL_HIP(hipStreamSynchronize(h->st_comm));
+  (void)ncclCommDestroy(ca);
+  (void)ncclCommDestroy(cb);
+  for (int64_t k = 0; k < n; ++k)
+    for (int a = 0; a < bs; ++a) {
+      const double want = 0.5 * (double)((n - 1 - k) * bs + a + 1);
+      if (out[(size_t)(n + k) * bs + a] != want)
+        throw glims_error(GLIMS_E_RCCL, "RCCL self-test: ghost value mismatch at " + std::to_string(k));
+    }
+  for (int q = 0; q < 3; ++q)
+    if (r3[q] != 1.25 * (q + 1)) throw glims_error(GLIMS_E_RCCL, "RCCL self-test: all-reduce value mismatch");
+  return GLIMS_OK;
+}

@@ -167,6 +167,12 @@ int glims_project(glims_ctx* h, const double* rhs, double* x, int ncomp, double 
 int glims_comm_unique_id(char id[GLIMS_UNIQUE_ID_BYTES]);           /* rank 0; broadcast by the host program */
 int glims_comm_init(glims_ctx* h, int rank, int world, const char id[GLIMS_UNIQUE_ID_BYTES]);
 
+/* Diagnostic: runs the library's RCCL call sequence (pack -> event -> grouped ncclSend/ncclRecv on the communication
+ * stream -> event -> compute stream, then ncclAllReduce on the compute stream) on a fresh ONE-rank communicator pair,
+ * sending to itself, and checks the data.  Proves that the RCCL library the process resolved is usable with this
+ * build (ABI, datatypes, stream/event ordering); it cannot prove multi-rank semantics. */
+int glims_comm_selftest(glims_ctx* h);
+
 /* Halo plan: for peer p (rank peer_rank[p]) this rank sends the values of its owned nodes
  * send_idx[send_ptr[p] .. send_ptr[p+1]) and receives recv_count[p] values into consecutive ghost slots;
  * ghost slots are laid out peer after peer in the order of peer_rank[], starting at node n_own, and the

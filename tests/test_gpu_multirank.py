@@ -231,3 +231,14 @@ def test_public_api_spmd_two_ranks_equals_single_process(tmp_path):
     sim.close()
     assert rel_l2(z0['c'], sol.components[1]) < 1e-10
     assert rel_l2(z0['u'], sol.components[0]) < 1e-8
+
+
+def test_rccl_call_sequence_on_a_one_rank_communicator(backend):
+    """The literal RCCL calls of the halo exchange and of the all-reduce, on real hardware (self-send); run with torch
+    imported, i.e. with whatever librccl the bench / driver processes resolve."""
+    import torch  # noqa: F401
+    mesh, label, bn, c0 = _problem()
+    h = backend.Handle(mesh.points, mesh.cells, label)
+    h.comm_selftest()
+    h.comm_selftest()          # communicators are created and destroyed per call
+    h.close()
