@@ -165,6 +165,14 @@ int glims_create(glims_ctx** out, int dim, int64_t n_nodes, int64_t n_own, int64
     p.n_interior = (int32_t)hp.interior_slices.size();
     p.n_boundary = (int32_t)hp.boundary_slices.size();
     h->d_old2new.upload(hp.old2new, h->st);
+    for (size_t b = 0; b < hp.bucket_cap.size(); ++b) {
+      if (hp.bucket_slices[b].empty()) continue;
+      p.bucket_cap.push_back(hp.bucket_cap[b]);
+      p.bucket_count.push_back((int32_t)hp.bucket_slices[b].size());
+      auto* dv = new dvec<int32_t>();
+      dv->upload(hp.bucket_slices[b], h->st);
+      p.bucket_slices.push_back(dv);
+    }
 
     std::vector<uint8_t> lab(n_cells);
     for (int64_t e = 0; e < n_cells; ++e) lab[e] = (uint8_t)cell_label[e];

@@ -9,7 +9,8 @@
 #include "../../include/glims_hip.h"
 
 #define GL_WAVE 64                 // wavefront width of CDNA4; SELL slice height
-#define GL_SIGMA 4096              // sigma window (rows) of the SELL-C-sigma row sort
+#define GL_SIGMA 256               // sigma window (rows) of the SELL-C-sigma row sort (tools/sigma_sweep.py: on an
+                                   // unstructured mesh 256 beats 4096 by 1.7x in SpMV time despite +17 % padding)
 #define GL_MAX_LABELS 256
 
 struct glims_error : std::runtime_error {
@@ -83,6 +84,10 @@ struct HostPattern {
   std::vector<uint32_t> cslots;            // 4 x uint8: slot (within the row) of each vertex of the cell
   std::vector<int32_t> celem;              // cell id, -1 = padding
   std::vector<int32_t> interior_slices, boundary_slices;   // boundary = references a ghost column
+  // slices grouped by row-length class (LDS footprint of the assembly sweep): bucket b holds the slices with
+  // bucket_cap[b-1] < len <= bucket_cap[b]
+  std::vector<int> bucket_cap;
+  std::vector<std::vector<int32_t>> bucket_slices;
   int max_len = 0, max_clen = 0;
   int64_t nnz = 0, n_corners = 0;
 };
@@ -103,6 +108,10 @@ struct DevPattern {
   dvec<double> cw;                         // per-incidence reaction weight rho_T |T| d!/(d+3)!
   dvec<int32_t> interior_slices, boundary_slices;
   int32_t n_interior = 0, n_boundary = 0;
+  std::vector<int> bucket_cap;
+  std::vector<int32_t> bucket_count;
+  std::vector<dvec<int32_t>*> bucket_slices;   // owned; released in ~DevPattern
+  ~DevPattern() { for (auto* b : bucket_slices) delete b; }
   int64_t total_entries = 0, total_corners = 0;
 };
 

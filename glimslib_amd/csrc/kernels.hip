@@ -180,20 +180,21 @@ __device__ __forceinline__ void corner_batch(const double* __restrict__ wp, cons
 
 template <int NV, int NT, int CU>
 __global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
-    int n_slices, int chunk, int64_t n_own, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ cols,
+    const int32_t* __restrict__ slice_list, int64_t n_own, const int64_t* __restrict__ slice_ptr,
+    const int32_t* __restrict__ cols,
     const int64_t* __restrict__ cslice_ptr, const uint32_t* __restrict__ cslots, const double* __restrict__ cw,
     const uint8_t* __restrict__ diag_k, const double* __restrict__ vS, double* __restrict__ vA,
     const double* __restrict__ c, const double* __restrict__ b, const double* __restrict__ b2,
     double* __restrict__ r_out, double* __restrict__ r2_out, double* __restrict__ dinv,
-    const uint8_t* __restrict__ fixed, double two_dt, double* __restrict__ partials, int max_len, int remap) {
+    const uint8_t* __restrict__ fixed, double two_dt, double* __restrict__ partials, int max_len) {
+  // one block (= one wave) per slice of this launch's length class; LDS = 2 * max_len columns of 64 doubles
   extern __shared__ double lds[];
   double* acc = lds;
   double* cn = lds + (size_t)max_len * GL_WAVE;
   const int lane = threadIdx.x;
-  const int blk = remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
-  const int s_end = min(n_slices, (blk + 1) * chunk);
   double rr = 0.0, rr2 = 0.0;
-  for (int s = blk * chunk; s < s_end; ++s) {
+  const int s = slice_list[blockIdx.x];
+  {
     const int64_t row = (int64_t)s * GL_WAVE + lane;
     const int64_t base = slice_ptr[s], cbase = cslice_ptr[s];
     const int len = (int)((slice_ptr[s + 1] - base) >> 6), clen = (int)((cslice_ptr[s + 1] - cbase) >> 6);
@@ -292,8 +293,8 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
   rr = wave_sum(rr);
   rr2 = wave_sum(rr2);
   if (lane == 0) {
-    partials[(size_t)blk * 2 + 0] = rr;
-    partials[(size_t)blk * 2 + 1] = rr2;
+    partials[(size_t)s * 2 + 0] = rr;
+    partials[(size_t)s * 2 + 1] = rr2;
   }
 }
 
@@ -545,28 +546,33 @@ int gl_rd_grid(const glims_ctx* h) { return h->pat.n_slices; }
 void gl_rd_assemble(glims_ctx* h, const double* c, const double* b, const double* b2, double* r_out, double* r2_out,
                     double* partials) {
   const DevPattern& p = h->pat;
-  const size_t lds = (size_t)2 * p.max_len * GL_WAVE * sizeof(double);
   const uint8_t* fx = h->have_fixed_c ? h->fixed_c.p : nullptr;
-  const int grid = gl_rd_grid(h);
-  const int chunk = (p.n_slices + grid - 1) / grid;
-#define GL_RD(NV, NT)                                                                                              \
-  do {                                                                                                             \
-    if (h->tune_rd_unroll == 24) { GL_RD2(NV, NT, 24); }                                                           \
-    else if (h->tune_rd_unroll == 12) { GL_RD2(NV, NT, 12); }                                                      \
-    else if (h->tune_rd_unroll == 4) { GL_RD2(NV, NT, 4); }                                                        \
-    else { GL_RD2(NV, NT, 8); }                                                                                    \
-  } while (0)
 #define GL_RD2(NV, NT, CU)                                                                                         \
   do {                                                                                                             \
     set_lds(k_rd_assemble<NV, NT, CU>, lds);                                                                       \
-    hipLaunchKernelGGL((k_rd_assemble<NV, NT, CU>), dim3(grid), dim3(GL_WAVE), lds, h->st, p.n_slices, chunk, h->n_own, \
+    hipLaunchKernelGGL((k_rd_assemble<NV, NT, CU>), dim3(grid), dim3(GL_WAVE), lds, h->st, list, h->n_own,          \
                        p.slice_ptr.p, p.cols.p, p.cslice_ptr.p, p.cslots.p, p.cw.p, p.diag_k.p, h->vS.p, h->vA.p, c, \
-                       b, b2, r_out, r2_out, h->dinv.p, fx, 2.0 * h->opt.dt, partials, p.max_len, 0);              \
+                       b, b2, r_out, r2_out, h->dinv.p, fx, 2.0 * h->opt.dt, partials, cap);                       \
   } while (0)
-  if (h->nv == 3) {
-    if (h->tune_rd_nt) GL_RD(3, 1); else GL_RD(3, 0);
-  } else {
-    if (h->tune_rd_nt) GL_RD(4, 1); else GL_RD(4, 0);
+#define GL_RD(NV, NT)                                                                                              \
+  do {                                                                                                             \
+    if (h->tune_rd_unroll == 12) { GL_RD2(NV, NT, 12); }                                                           \
+    else if (h->tune_rd_unroll == 8) { GL_RD2(NV, NT, 8); }                                                        \
+    else if (h->tune_rd_unroll == 4) { GL_RD2(NV, NT, 4); }                                                        \
+    else { GL_RD2(NV, NT, 24); }                                                                                   \
+  } while (0)
+  // one launch per row-length class: the LDS footprint (2 * cap * 512 B per wave) decides the occupancy, so the
+  // (few) long rows of an unstructured mesh must not size it for everybody
+  for (size_t bk = 0; bk < p.bucket_cap.size(); ++bk) {
+    const int cap = p.bucket_cap[bk];
+    const int grid = p.bucket_count[bk];
+    const int32_t* list = p.bucket_slices[bk]->p;
+    const size_t lds = (size_t)2 * cap * GL_WAVE * sizeof(double);
+    if (h->nv == 3) {
+      if (h->tune_rd_nt) GL_RD(3, 1); else GL_RD(3, 0);
+    } else {
+      if (h->tune_rd_nt) GL_RD(4, 1); else GL_RD(4, 0);
+    }
   }
 #undef GL_RD
 #undef GL_RD2

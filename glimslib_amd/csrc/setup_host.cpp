@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstring>
 #include <numeric>
+#include <cstdlib>
 
 namespace {
 
@@ -146,10 +147,14 @@ void build_host_pattern(HostPattern& hp, int dim, int64_t n_nodes, int64_t n_own
   hp.new2old.resize(n_nodes);
   hp.old2new.resize(n_nodes);
   {
-    const int64_t nwin = (n_own + GL_SIGMA - 1) / GL_SIGMA;
+    // sigma = rows per sorting window (multiple of 64).  Large windows minimise padding but scatter a window's rows
+    // over its slices by length, i.e. they trade gather locality for padding; GLIMS_SIGMA overrides the default.
+    int64_t sigma = GL_SIGMA;
+    if (const char* e = getenv("GLIMS_SIGMA")) sigma = std::max<int64_t>(GL_WAVE, (atoll(e) / GL_WAVE) * GL_WAVE);
+    const int64_t nwin = (n_own + sigma - 1) / sigma;
 #pragma omp parallel for schedule(dynamic, 4)
     for (int64_t w = 0; w < nwin; ++w) {
-      int64_t a = w * GL_SIGMA, b = std::min<int64_t>(n_own, a + GL_SIGMA);
+      int64_t a = w * sigma, b = std::min<int64_t>(n_own, a + sigma);
       std::stable_sort(keys.begin() + a, keys.begin() + b, [&](const KeyIdx& x, const KeyIdx& y) {
         return (nbr_ptr[x.idx + 1] - nbr_ptr[x.idx]) > (nbr_ptr[y.idx + 1] - nbr_ptr[y.idx]);
       });
@@ -242,4 +247,13 @@ void build_host_pattern(HostPattern& hp, int dim, int64_t n_nodes, int64_t n_own
     }
   }
   for (int32_t s = 0; s < n_slices; ++s) (is_boundary[s] ? hp.boundary_slices : hp.interior_slices).push_back(s);
+  // length classes for the assembly sweep (its LDS footprint is 2 * cap * 64 * 8 B per wave)
+  hp.bucket_cap = {16, 24, 32, 48, 64, 96, 128, 255};
+  hp.bucket_slices.assign(hp.bucket_cap.size(), {});
+  for (int32_t s = 0; s < n_slices; ++s) {
+    const int len = (int)((hp.slice_ptr[s + 1] - hp.slice_ptr[s]) / GL_WAVE);
+    size_t b = 0;
+    while (hp.bucket_cap[b] < len) ++b;
+    hp.bucket_slices[b].push_back(s);
+  }
 }

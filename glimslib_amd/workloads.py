@@ -94,6 +94,33 @@ def config_c5(n=99):
     return _brain_box(n, True, 50, "C5 coupled (c + u) brain-extent box n=%d" % n)
 
 
+def config_unstructured(n_points=200000, mechanics=False, seed=0):
+    """
+    Truly unstructured stand-in for the CGAL atlas meshes: Delaunay tetrahedralisation (scipy / Qhull) of uniformly
+    random points (np.random.default_rng(seed)) in the brain-extent box, WM ellipsoid in a GM shell, same parameters
+    as C3/C4.  Row lengths range from ~6 to ~45 (mean ~16), cell volumes over three orders of magnitude.
+    """
+    from scipy.spatial import Delaunay
+    from .mesh import Mesh
+    rng = np.random.default_rng(seed)
+    pts = rng.random((int(n_points), 3)) * np.array([240.0, 240.0, 155.0]) + np.array([0.0, -240.0, 0.0])
+    cells = Delaunay(pts).simplices.astype(np.int32)
+    X = pts[cells]
+    vol = np.abs(np.linalg.det(X[:, 1:] - X[:, :1])) / 6.0
+    cells = cells[vol > 1e-9 * vol.mean()]                       # drop numerically flat slivers Qhull may emit
+    mesh = Mesh(pts, cells)
+    mid = mesh.cell_midpoints()
+    q = ((mid[:, 0] - 120.0) / 80.0) ** 2 + ((mid[:, 1] + 120.0) / 80.0) ** 2 + ((mid[:, 2] - 77.5) / 50.0) ** 2
+    label = np.where(q < 1.0, WM, GM).astype(np.int32)
+    tables = dict(D=[0.0, 0.0, 0.01, 0.05, 0.0], rho=[0.0, 0.0, 0.05, 0.05, 0.0],
+                  gamma=[0.0, 0.1, 0.1, 0.1, 0.1], E=[1.0, 1000e-6, 3000e-6, 3000e-6, 1000e-6],
+                  nu=[0.3, 0.45, 0.45, 0.45, 0.3])
+    d2 = ((pts - np.array([118.0, -109.0, 72.0])) ** 2).sum(axis=1)
+    c0 = np.exp(-0.005 * d2)
+    return Workload("unstructured Delaunay mesh, %d points" % n_points, mesh, label, tables, c0, 1.0, 50, mechanics,
+                    _exterior_nodes(mesh) if mechanics else None)
+
+
 def by_name(name, n=None):
     name = name.lower()
     if name == 'c1':
@@ -106,6 +133,8 @@ def by_name(name, n=None):
         return config_c4(*([n] if n else []))
     if name == 'c5':
         return config_c5(*([n] if n else []))
+    if name in ('u', 'unstructured'):
+        return config_unstructured(*([n] if n else []))
     raise KeyError(name)
 
 

@@ -366,3 +366,33 @@ def test_options_newton_tolerance_of_the_reference(backend):
     assert h.step(8) == 0
     assert rel_l2(h.get_state(want_u=False)[0], co) < 1e-8
     h.close()
+
+
+def test_delaunay_mesh_matches_both_oracles(backend):
+    """Unstructured Delaunay mesh (row lengths ~6..45, volumes over 3 decades): HIP vs the C oracle (RD, 3 steps) and
+    vs the numpy oracle (operators), with mechanics clamped on the hull."""
+    from oracle.c_port import COracle
+    w = workloads.config_unstructured(3000, mechanics=True)
+    n = w.mesh.num_vertices()
+    h = _handle(backend, w.mesh, w.cell_label, w.dt, w.tables)
+    st = h.stats()
+    assert st["nnz_padded"] < 1.35 * st["nnz"]                   # sigma-sorted SELL-64 keeps the padding small
+    co = COracle(w.mesh.points, w.mesh.cells, w.per_cell('D'), w.per_cell('rho'), w.dt)
+    ref = co.step(w.c0, 3, rtol=1e-11, cg_rtol=1e-4)
+    dofs = (w.dirichlet_nodes[:, None] * 3 + np.arange(3)).ravel()
+    h.set_dirichlet_u(dofs, np.zeros(len(dofs)))
+    h.set_state(w.c0)
+    assert h.step(3) == 0
+    assert rel_l2(h.get_state(want_u=False)[0], ref) < 1e-9
+    o = OracleTumorGrowth(w.mesh.points, w.mesh.cells, w.per_cell('D'), w.per_cell('rho'), w.per_cell('gamma'),
+                          w.per_cell('E'), w.per_cell('nu'), w.dt, dirichlet_u=(dofs, np.zeros(len(dofs))))
+    x = np.random.default_rng(1).standard_normal(n)
+    xu = np.random.default_rng(2).standard_normal(3 * n)
+    Kel, G = o._mech_setup()
+    assert rel_l2(h.apply(1, x)[0], o.S @ x) < 1e-13 and rel_l2(h.apply(3, xu)[0], Kel @ xu) < 1e-13
+    assert rel_l2(h.apply(4, x)[0], G @ x) < 1e-13
+    assert h.solve_mechanics() == 0
+    u = h.get_state()[1]
+    assert rel_l2(u, o.mech_solve(ref)) < 1e-6                   # slivers: K_el is ill-conditioned, PCG at rtol 1e-10
+    h.close()
+    co.close()
