@@ -167,7 +167,12 @@ int glims_create(glims_ctx** out, int dim, int64_t n_nodes, int64_t n_own, int64
     h->d_old2new.upload(hp.old2new, h->st);
     for (size_t b = 0; b < hp.bucket_cap.size(); ++b) {
       if (hp.bucket_slices[b].empty()) continue;
-      p.bucket_cap.push_back(hp.bucket_cap[b]);
+      // LDS of the class = its actual longest slice, not the class bound (16 rows x 1 KB would be exactly 1/10 of
+      // the CU's LDS and fit only 9 times; the structured meshes' 15 fits 10 times)
+      int cap = 1;
+      for (int32_t sl : hp.bucket_slices[b])
+        cap = std::max(cap, (int)((hp.slice_ptr[sl + 1] - hp.slice_ptr[sl]) / GL_WAVE));
+      p.bucket_cap.push_back(cap);
       p.bucket_count.push_back((int32_t)hp.bucket_slices[b].size());
       auto* dv = new dvec<int32_t>();
       dv->upload(hp.bucket_slices[b], h->st);
@@ -203,6 +208,7 @@ int glims_create(glims_ctx** out, int dim, int64_t n_nodes, int64_t n_own, int64
     h->mat.alloc_zero(5 * GL_MAX_LABELS, h->st);
     h->partials.alloc_zero((size_t)p.n_slices * 3 + 4096, h->st);
     h->partials2.alloc_zero((size_t)(p.n_slices * 3 + 4096) / 1024 * 3 + 64, h->st);
+    h->partials_v.alloc_zero(2 * 4096 + 64, h->st);
     h->red.alloc_zero(4, h->st);
     h->scal.alloc_zero(2 * SC_COUNT + 8, h->st);
     h->done.alloc_zero(1, h->st);
@@ -294,16 +300,14 @@ int glims_set_dirichlet_c(glims_ctx* h, int64_t n, const int64_t* node_ids, cons
       return GLIMS_OK;
     }
     GL_REQUIRE(node_ids && values, "null Dirichlet arrays");
+    // the values themselves enter through glims_set_state (the caller writes them into c); here only the row mask
+    (void)values;
     std::vector<uint8_t> fx(h->n_nodes, 0);
-    std::vector<double> val(h->n_nodes, 0.0);
     for (int64_t k = 0; k < n; ++k) {
       GL_REQUIRE(node_ids[k] >= 0 && node_ids[k] < h->n_nodes, "Dirichlet node out of range");
-      const int32_t nw = h->old2new[node_ids[k]];
-      fx[nw] = 1;
-      val[nw] = values[k];
+      fx[h->old2new[node_ids[k]]] = 1;
     }
     h->fixed_c.upload(fx, h->st);
-    h->cD.upload(val, h->st);
     GL_HIP(hipStreamSynchronize(h->st));
     h->have_fixed_c = true;
     return GLIMS_OK;

@@ -79,7 +79,6 @@ struct HostPattern {
   std::vector<int64_t> slice_ptr;          // [n_slices+1] offsets into cols (multiples of 64)
   std::vector<int32_t> cols;               // SELL-64 column indices (new numbering), padded with the row itself
   std::vector<uint8_t> diag_k;             // [n_slices*64] slot of the diagonal in each row
-  std::vector<uint8_t> row_len;            // [n_slices*64] structural length of each row (0 for pad rows)
   std::vector<int64_t> cslice_ptr;         // [n_slices+1] offsets into the (row, cell) incidence arrays
   std::vector<uint32_t> cslots;            // 4 x uint8: slot (within the row) of each vertex of the cell
   std::vector<int32_t> celem;              // cell id, -1 = padding
@@ -116,7 +115,7 @@ struct DevPattern {
 };
 
 // scalar slots of the Krylov recurrence (device array `scal`)
-enum { SC_ALPHA = 0, SC_BETA, SC_GAMMA, SC_IT, SC_RR, SC_DELTA, SC_COUNT = 8 };
+enum { SC_ALPHA = 0, SC_BETA, SC_GAMMA, SC_IT, SC_COUNT = 8 };
 
 struct glims_ctx {
   int dim = 0, nv = 0, device = 0;
@@ -149,18 +148,17 @@ struct glims_ctx {
   bool have_c_old = false;                                    // c_old holds the state at the start of the previous step
   bool pending = false;                                      // cg_r / b / vA already hold the first assembly of the next step
   double pending_r0 = 0.0;
-  dvec<double> U, mload, m_rhs, m_x, m_p, m_s, m_u, m_w, m_r, m_dinv, m_uD;   // mechanics, [n_nodes*dim]
+  dvec<double> U, mload, m_rhs, m_p, m_s, m_u, m_w, m_r, m_dinv, m_uD;   // mechanics, [n_nodes*dim]
   dvec<uint8_t> fixed_c, fixed_u;
-  dvec<double> cD;
   bool have_fixed_c = false, have_fixed_u = false, have_load_rd = false, have_mload = false;
   dvec<double> stage;                      // staging for host<->device permuted transfers [n_nodes*dim]
 
   dvec<double> partials, partials2;        // per-block partial sums (stage 1 / stage 2 of the reduction)
+  dvec<double> partials_v;                 // (r.u, r.r) pairs per block of the PCG vector kernels
   dvec<double> red;                        // [4] reduced sums
   dvec<double> scal;                       // [SC_COUNT] recurrence scalars
   dvec<int> done;                          // [1] 0 running, 1 converged, 2 non-finite, 3 breakdown
   double* h_pinned = nullptr;              // pinned host mirror (16 doubles)
-  int n_partial_blocks = 0;
 
   // multi-GPU
   int rank = 0, world = 1;

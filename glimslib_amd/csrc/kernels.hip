@@ -300,7 +300,8 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
 
 // ---------------------------------------------------------------------------------------------------
 // hot: SELL-64 SpMV  y = A x  (+ addv), optional Dirichlet row mask, optional fused dot products
-//   partials[b] = ( r.x , y.x , r.r ) over the rows of logical block b   (x plays the role of u = Dinv r)
+//   DOTS: partials[b] = y.x over the rows of logical block b (the PCG's delta = w.u; r.u and r.r come from the
+//   vector-update kernel, which has r and u in registers anyway, so this kernel never reads r)
 // ---------------------------------------------------------------------------------------------------
 template <int DOTS, int UNR, int NT>
 __global__ __launch_bounds__(256) void k_spmv(int n_launch, int chunk, const int32_t* __restrict__ slice_list,
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(256) void k_spmv(int n_launch, int chunk, const int
   const int b = remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int s_end = min(n_launch, (b + 1) * chunk);
-  double pg = 0.0, pd = 0.0, pr = 0.0;
+  double pd = 0.0;
   for (int si = b * chunk + wid; si < s_end; si += 4) {
     const int s = slice_list ? slice_list[si] : si;
     const int64_t row = (int64_t)s * GL_WAVE + lane;
@@ -351,29 +352,15 @@ __global__ __launch_bounds__(256) void k_spmv(int n_launch, int chunk, const int
       if (fixed && fixed[row]) acc = 0.0;
       if (addv) acc += addv[row];
       y[row] = acc;
-      if (DOTS) {
-        const double ri = r[row], ui = x[row];
-        pg += ri * ui;
-        pd += acc * ui;
-        pr += ri * ri;
-      }
+      if (DOTS) pd += acc * x[row];
     }
   }
   if (DOTS) {
-    __shared__ double red[4][3];
-    pg = wave_sum(pg);
+    __shared__ double red[4];
     pd = wave_sum(pd);
-    pr = wave_sum(pr);
-    if (lane == 0) {
-      red[wid][0] = pg;
-      red[wid][1] = pd;
-      red[wid][2] = pr;
-    }
+    if (lane == 0) red[wid] = pd;
     __syncthreads();
-    if (threadIdx.x < 3) {
-      const int q = threadIdx.x;
-      partials[(size_t)(partial_off + b) * 3 + q] = red[0][q] + red[1][q] + red[2][q] + red[3][q];
-    }
+    if (threadIdx.x == 0) partials[(size_t)(partial_off + b)] = red[0] + red[1] + red[2] + red[3];
   }
 }
 
@@ -391,7 +378,7 @@ __global__ __launch_bounds__(256) void k_spmv_block(int n_launch, int chunk,
   const int b = remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int s_end = min(n_launch, (b + 1) * chunk);
-  double pg = 0.0, pd = 0.0, pr = 0.0;
+  double pd = 0.0;
   for (int si = b * chunk + wid; si < s_end; si += 4) {
     const int s = slice_list ? slice_list[si] : si;
     const int64_t row = (int64_t)s * GL_WAVE + lane;
@@ -419,30 +406,16 @@ __global__ __launch_bounds__(256) void k_spmv_block(int n_launch, int chunk,
         double v = acc[a];
         if (fixed && fixed[row * BS + a]) v = 0.0;
         y[row * BS + a] = v;
-        if (DOTS) {
-          const double ri = r[row * BS + a], ui = x[row * BS + a];
-          pg += ri * ui;
-          pd += v * ui;
-          pr += ri * ri;
-        }
+        if (DOTS) pd += v * x[row * BS + a];
       }
     }
   }
   if (DOTS) {
-    __shared__ double red[4][3];
-    pg = wave_sum(pg);
+    __shared__ double red[4];
     pd = wave_sum(pd);
-    pr = wave_sum(pr);
-    if (lane == 0) {
-      red[wid][0] = pg;
-      red[wid][1] = pd;
-      red[wid][2] = pr;
-    }
+    if (lane == 0) red[wid] = pd;
     __syncthreads();
-    if (threadIdx.x < 3) {
-      const int q = threadIdx.x;
-      partials[(size_t)(partial_off + b) * 3 + q] = red[0][q] + red[1][q] + red[2][q] + red[3][q];
-    }
+    if (threadIdx.x == 0) partials[(size_t)(partial_off + b)] = red[0] + red[1] + red[2] + red[3];
   }
 }
 

@@ -6,8 +6,9 @@
 //
 // Layout decisions (MI355X):
 //   * rows are renumbered along a Morton curve of their coordinates so that the x-gather of a 64-row slice
-//     stays inside a compact neighbourhood (L1/L2 hits), then sorted by length inside windows of GL_SIGMA rows
-//     (SELL-C-sigma) so that a slice is padded only to the longest of 64 similar rows;
+//     stays inside a compact neighbourhood (L1/L2 hits), then sorted by length inside windows of GL_SIGMA (256) rows
+//     (SELL-C-sigma) so that a slice is padded only to the longest of 64 similar rows -- small windows on purpose:
+//     a large window scatters its rows over its slices and destroys the gather locality (tools/sigma_sweep.py);
 //   * a slice is 64 rows = one wavefront, entries stored slot-major ([slot][lane]) so that lane l of a wave
 //     reads address base + slot*64 + l: every value/column stream is a unit-stride 512 B / 256 B access;
 //   * the (row, cell) incidences ("corners") use the same slot-major layout.  A corner stores, for each vertex
@@ -200,7 +201,6 @@ void build_host_pattern(HostPattern& hp, int dim, int64_t n_nodes, int64_t n_own
   hp.max_clen = max_clen;
   hp.cols.resize(hp.slice_ptr[n_slices]);
   hp.diag_k.assign((size_t)n_slices * GL_WAVE, 0);
-  hp.row_len.assign((size_t)n_slices * GL_WAVE, 0);
   hp.cslots.assign(hp.cslice_ptr[n_slices], 0u);
   hp.celem.assign(hp.cslice_ptr[n_slices], -1);
   std::vector<uint8_t> is_boundary(n_slices, 0);
@@ -223,7 +223,6 @@ void build_host_pattern(HostPattern& hp, int dim, int64_t n_nodes, int64_t n_own
         const int rl = (int)(nbr_ptr[o + 1] - nbr_ptr[o]);
         for (int k = 0; k < rl; ++k) row[k] = hp.old2new[nbr[nbr_ptr[o] + k]];
         std::sort(row.begin(), row.begin() + rl);
-        hp.row_len[r] = (uint8_t)rl;
         for (int k = 0; k < rl; ++k) {
           hp.cols[base + (int64_t)k * GL_WAVE + l] = row[k];
           if (row[k] == (int32_t)r) hp.diag_k[r] = (uint8_t)k;

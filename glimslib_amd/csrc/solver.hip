@@ -25,15 +25,38 @@ void gl_launch_spmv_block(glims_ctx* h, hipStream_t st, int n_launch, const int3
 
 namespace {
 
+// block-level sum of two values -> pv[blockIdx.x*2 + {0,1}]   (256-thread blocks)
+__device__ __forceinline__ void block_sum2(double a, double b, double* __restrict__ pv) {
+  __shared__ double sm[4][2];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_down(a, o, 64);
+    b += __shfl_down(b, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    sm[threadIdx.x >> 6][0] = a;
+    sm[threadIdx.x >> 6][1] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) pv[(size_t)blockIdx.x * 2 + threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+}
+
+// u = Dinv r, p = s = 0, and the first (r.u, r.r) partials
 template <int BS>
-__global__ void k_cg_init(int64_t n_own, const double* __restrict__ r, const double* __restrict__ dinv,
-                          double* __restrict__ u, double* __restrict__ p, double* __restrict__ s) {
+__global__ __launch_bounds__(256) void k_cg_init(int64_t n_own, const double* __restrict__ r,
+                                                  const double* __restrict__ dinv, double* __restrict__ u,
+                                                  double* __restrict__ p, double* __restrict__ s,
+                                                  double* __restrict__ pv) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double pg = 0.0, pr = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_own; i += stride) {
     if constexpr (BS == 1) {
-      u[i] = dinv[i] * r[i];
+      const double ri = r[i], ui = dinv[i] * ri;
+      u[i] = ui;
       p[i] = 0.0;
       s[i] = 0.0;
+      pg += ri * ui;
+      pr += ri * ri;
     } else {
       double rv[BS];
 #pragma unroll
@@ -46,22 +69,28 @@ __global__ void k_cg_init(int64_t n_own, const double* __restrict__ r, const dou
         u[i * BS + a] = v;
         p[i * BS + a] = 0.0;
         s[i * BS + a] = 0.0;
+        pg += rv[a] * v;
+        pr += rv[a] * rv[a];
       }
     }
   }
+  block_sum2(pg, pr, pv);
 }
 
 // Chronopoulos-Gear recurrence + vector update in one kernel.
-//   red = (gamma = r.u, delta = w.u, rr = r.r), already global sums.  Every thread derives alpha/beta from `red`
+//   red = (gamma = r.u, delta = w.u, rr = r.r), already global sums (gamma, rr from the previous launch of this kernel
+//   or k_cg_init, delta from the SpMV).  Every thread derives alpha/beta from `red`
 //   and the previous iteration's scalars (`prev`, read-only here); thread 0 of block 0 publishes the new scalars to
 //   `cur` (ping-pong) and to `info` = {iterations done, last rr} for the host.  No separate scalar kernel.
 //   p = u + beta p;  s = w + beta s;  x += alpha p;  r -= alpha s;  u = Dinv r      (one pass over 7 vectors)
 template <int BS>
-__global__ void k_cg_update(int64_t n_own, const double* __restrict__ red, const double* __restrict__ prev,
-                            double* __restrict__ cur, double* __restrict__ info, int* __restrict__ done, double tol2,
-                            double* __restrict__ p, double* __restrict__ s, double* __restrict__ x,
-                            double* __restrict__ r, double* __restrict__ u, const double* __restrict__ w,
-                            const double* __restrict__ dinv) {
+__global__ __launch_bounds__(256) void k_cg_update(int64_t n_own, const double* __restrict__ red,
+                                                    const double* __restrict__ prev, double* __restrict__ cur,
+                                                    double* __restrict__ info, int* __restrict__ done, double tol2,
+                                                    double* __restrict__ p, double* __restrict__ s,
+                                                    double* __restrict__ x, double* __restrict__ r,
+                                                    double* __restrict__ u, const double* __restrict__ w,
+                                                    const double* __restrict__ dinv, double* __restrict__ pv) {
   if (*done) return;
   const double gamma = red[0], delta = red[1], rr = red[2];
   const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
@@ -93,6 +122,7 @@ __global__ void k_cg_update(int64_t n_own, const double* __restrict__ red, const
     info[0] = it + 1.0;
   }
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double pg = 0.0, pr = 0.0;   // partials of the NEXT iteration's gamma = r.u and rr = r.r
   if constexpr (BS == 1) {
     // 16 B per lane (two rows per thread): all seven streams are hipMalloc-aligned
     const int64_t n2 = n_own >> 1;
@@ -116,6 +146,8 @@ __global__ void k_cg_update(int64_t n_own, const double* __restrict__ red, const
       rn.y = rr2.y - alpha * sn.y;
       un.x = dd.x * rn.x;
       un.y = dd.y * rn.y;
+      pg += rn.x * un.x + rn.y * un.y;
+      pr += rn.x * rn.x + rn.y * rn.y;
       p2[i] = pn;
       s2[i] = sn;
       x2[i] = xx;
@@ -132,7 +164,10 @@ __global__ void k_cg_update(int64_t n_own, const double* __restrict__ red, const
       const double ri = r[i] - alpha * si;
       r[i] = ri;
       u[i] = dinv[i] * ri;
+      pg += ri * (dinv[i] * ri);
+      pr += ri * ri;
     }
+    block_sum2(pg, pr, pv);
     return;
   }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_own; i += stride) {
@@ -157,9 +192,12 @@ __global__ void k_cg_update(int64_t n_own, const double* __restrict__ red, const
 #pragma unroll
         for (int b = 0; b < BS; ++b) v += dinv[i * BS * BS + a * BS + b] * rv[b];
         u[i * BS + a] = v;
+        pg += rv[a] * v;
+        pr += rv[a] * rv[a];
       }
     }
   }
+  block_sum2(pg, pr, pv);
 }
 
 // red[q] = sum_b partials[b*nq + q] in a fixed order -> bitwise reproducible.  Two stages: `nb1` blocks each sum a
@@ -204,6 +242,33 @@ __global__ __launch_bounds__(1024) void k_reduce(int n, int nq, const double* __
     for (int q = 0; q < 3; ++q) sm[threadIdx.x >> 6][q] = v[q];
   __syncthreads();
   if ((int)threadIdx.x < nq) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += sm[w][threadIdx.x];
+    red[threadIdx.x] = t;
+  }
+}
+
+// PCG reduction: red = ( sum pv[.][0] , sum ps[.] , sum pv[.][1] ) = (gamma, delta, rr), fixed order
+__global__ __launch_bounds__(1024) void k_reduce_cg(int ns, const double* __restrict__ ps, int nv,
+                                                     const double* __restrict__ pv, double* __restrict__ red,
+                                                     const int* __restrict__ done) {
+  if (done && *done) return;
+  __shared__ double sm[16][3];
+  double v[3] = {0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < ns; i += 1024) v[1] += ps[i];
+  for (int i = threadIdx.x; i < nv; i += 1024) {
+    v[0] += pv[(size_t)i * 2];
+    v[2] += pv[(size_t)i * 2 + 1];
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v[q] += __shfl_down(v[q], o, 64);
+  }
+  if ((threadIdx.x & 63) == 0)
+    for (int q = 0; q < 3; ++q) sm[threadIdx.x >> 6][q] = v[q];
+  __syncthreads();
+  if (threadIdx.x < 3) {
     double t = 0.0;
     for (int w = 0; w < 16; ++w) t += sm[w][threadIdx.x];
     red[threadIdx.x] = t;
@@ -473,7 +538,7 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
     else hipLaunchKernelGGL(K<3>, dim3(g), dim3(256), 0, h->st, __VA_ARGS__);           \
     GL_HIP(hipGetLastError());                                                          \
   } while (0)
-  GL_VEC(k_cg_init, n, v.r, v.dinv, v.u, v.p, v.s);
+  GL_VEC(k_cg_init, n, v.r, v.dinv, v.u, v.p, v.s, h->partials_v.p);
   int done = 0;
   double info[2] = {0.0, 0.0};
   const int batch = h->opt.check_every > 0 ? h->opt.check_every : 8;
@@ -487,9 +552,22 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
       const double* prev = h->scal.p + ((enq + j) & 1) * SC_COUNT;
       double* cur = h->scal.p + ((enq + j + 1) & 1) * SC_COUNT;
       apply_with_halo(h, v);
-      reduce_partials(h, nblocks, 3, h->done.p);
+      // delta partials: one per SpMV block (stage 1 only when there are very many); gamma / rr partials: one pair
+      // per block of the previous vector kernel
+      const double* ps = h->partials.p;
+      int ns = nblocks;
+      if (nblocks > 16384) {
+        const int per_block = 1024;
+        ns = (nblocks + per_block - 1) / per_block;
+        hipLaunchKernelGGL(k_reduce_stage1, dim3(ns), dim3(256), 0, h->st, nblocks, 1, per_block, h->partials.p,
+                           h->partials2.p, h->done.p);
+        ps = h->partials2.p;
+      }
+      hipLaunchKernelGGL(k_reduce_cg, dim3(1), dim3(1024), 0, h->st, ns, ps, (int)g, h->partials_v.p, h->red.p,
+                         h->done.p);
       allreduce_sum(h, h->red.p, 3);
-      GL_VEC(k_cg_update, n, h->red.p, prev, cur, info_dev, h->done.p, tol2, v.p, v.s, v.x, v.r, v.u, v.w, v.dinv);
+      GL_VEC(k_cg_update, n, h->red.p, prev, cur, info_dev, h->done.p, tol2, v.p, v.s, v.x, v.r, v.u, v.w, v.dinv,
+             h->partials_v.p);
     }
     enq += nb;
     poll(h, &done, info);

@@ -112,6 +112,8 @@ int glims_set_options(glims_ctx* h, const glims_options* opt);
 
 /* Dirichlet data (fenics.DirichletBC lists built at helper_classes.py:632-723).  n == 0 clears. */
 int glims_set_dirichlet_u(glims_ctx* h, int64_t n, const int64_t* dof_ids, const double* values);
+/* Concentration: the listed nodes keep the value they have in the state passed to glims_set_state (write the
+ * Dirichlet data into c there); `values` documents them and is checked for presence only. */
 int glims_set_dirichlet_c(glims_ctx* h, int64_t n, const int64_t* node_ids, const double* values);
 
 /* Load vectors already integrated by the host (NULL clears):
