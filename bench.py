@@ -189,11 +189,12 @@ def main():
     try:
         pmc = json.load(open(os.path.join(HERE, "profiles", "r01_pmc_c4.json")))
         if world == 1 and pmc["n_rows"] == st['n_rows'] and pmc["nnz"] == st['nnz']:
-            traffic = pmc["kernels"]["k_spmv<0, 4>"]["hbm_bytes_per_launch"]
+            key = [k for k in pmc["kernels"] if k.startswith("k_spmv<0")][0]
+            traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
     except Exception:
         traffic = None
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_spmv<0,4> (SELL-64, fp64 values, "
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_spmv<0,4,1> (SELL-64, fp64 values, "
                 "int32 columns)", "algorithmic_bytes_per_launch": b_alg, "avg_launch_us": t_spmv * 1e6,
                 "launches_timed": args.spmv_reps}
 

@@ -17,6 +17,7 @@ void read_tuning(glims_ctx* h) {
   if (const char* e = getenv("GLIMS_XCD_REMAP")) h->tune_xcd_remap = atoi(e);
   if (const char* e = getenv("GLIMS_SPMV_NT")) h->tune_spmv_nt = atoi(e);
   if (const char* e = getenv("GLIMS_RD_NT")) h->tune_rd_nt = atoi(e);
+  if (const char* e = getenv("GLIMS_RD_REMAP")) h->tune_rd_remap = atoi(e);
   if (const char* e = getenv("GLIMS_RD_UNROLL")) h->tune_rd_unroll = atoi(e);
 }
 

@@ -19,6 +19,17 @@ __device__ __forceinline__ int xcd_remap(int b, int nb) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
 }
 
+__device__ __forceinline__ int xcd_chunk_remap(int b, int nb, int G) {
+  // Hardware deals block b to XCD b % 8.  Give every XCD chunks of G consecutive logical blocks, chunk after chunk
+  // round-robin over the XCDs: neighbouring slices (overlapping x gathers) share one L2, while the eight XCDs
+  // together still walk the matrix front to back (one shared, moving x window in the Infinity Cache; DRAM pages are
+  // visited nearly sequentially).  Blocks beyond the last full group of 8*G keep their index -> bijective.
+  const int full = (nb / (8 * G)) * (8 * G);
+  if (b >= full) return b;
+  const int q = b >> 3, xcd = b & 7;
+  return ((q / G) * 8 + xcd) * G + (q % G);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -186,14 +197,15 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
     const uint8_t* __restrict__ diag_k, const double* __restrict__ vS, double* __restrict__ vA,
     const double* __restrict__ c, const double* __restrict__ b, const double* __restrict__ b2,
     double* __restrict__ r_out, double* __restrict__ r2_out, double* __restrict__ dinv,
-    const uint8_t* __restrict__ fixed, double two_dt, double* __restrict__ partials, int max_len) {
+    const uint8_t* __restrict__ fixed, double two_dt, double* __restrict__ partials, int max_len, int remap) {
   // one block (= one wave) per slice of this launch's length class; LDS = 2 * max_len columns of 64 doubles
   extern __shared__ double lds[];
   double* acc = lds;
   double* cn = lds + (size_t)max_len * GL_WAVE;
   const int lane = threadIdx.x;
   double rr = 0.0, rr2 = 0.0;
-  const int s = slice_list[blockIdx.x];
+  // same XCD-chunked mapping as the SpMV (one slice per block here, so 4x the chunk length)
+  const int s = slice_list[remap > 1 ? xcd_chunk_remap(blockIdx.x, gridDim.x, 4 * remap) : blockIdx.x];
   {
     const int64_t row = (int64_t)s * GL_WAVE + lane;
     const int64_t base = slice_ptr[s], cbase = cslice_ptr[s];
@@ -313,7 +325,8 @@ __global__ __launch_bounds__(256) void k_spmv(int n_launch, int chunk, const int
                                                int partial_off, const int* __restrict__ done, int remap) {
   if (done && *done) return;
   // block b owns the contiguous slice range [b*chunk, (b+1)*chunk); its 4 waves interleave inside that range
-  const int b = remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int b = remap == 1 ? xcd_remap(blockIdx.x, gridDim.x)
+                : remap > 1 ? xcd_chunk_remap(blockIdx.x, gridDim.x, remap) : blockIdx.x;
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int s_end = min(n_launch, (b + 1) * chunk);
   double pd = 0.0;
@@ -525,7 +538,7 @@ void gl_rd_assemble(glims_ctx* h, const double* c, const double* b, const double
     set_lds(k_rd_assemble<NV, NT, CU>, lds);                                                                       \
     hipLaunchKernelGGL((k_rd_assemble<NV, NT, CU>), dim3(grid), dim3(GL_WAVE), lds, h->st, list, h->n_own,          \
                        p.slice_ptr.p, p.cols.p, p.cslice_ptr.p, p.cslots.p, p.cw.p, p.diag_k.p, h->vS.p, h->vA.p, c, \
-                       b, b2, r_out, r2_out, h->dinv.p, fx, 2.0 * h->opt.dt, partials, cap);                       \
+                       b, b2, r_out, r2_out, h->dinv.p, fx, 2.0 * h->opt.dt, partials, cap, h->tune_rd_remap);    \
   } while (0)
 #define GL_RD(NV, NT)                                                                                              \
   do {                                                                                                             \
@@ -565,7 +578,7 @@ void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* s
   const DevPattern& p = h->pat;
   const int grid = gl_spmv_grid(n_launch);
   const int chunk = (n_launch + grid - 1) / grid;
-  const int remap = (slice_list || !h->tune_xcd_remap) ? 0 : 1;
+  const int remap = slice_list ? 0 : h->tune_xcd_remap;   // 0 plain, 1 contiguous eighths, G > 1 chunks of G blocks
 #define GL_SPMV(DOTS, UNR, NT)                                                                                     \
   hipLaunchKernelGGL((k_spmv<DOTS, UNR, NT>), dim3(grid), dim3(256), 0, st, n_launch, chunk, slice_list, h->n_own, \
                      p.slice_ptr.p, p.cols.p, vals, x, y, fixed, addv, r, partials, partial_off, done, remap)

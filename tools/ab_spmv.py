@@ -15,11 +15,9 @@ h.setup(False)
 st = h.stats()
 b_alg = workloads.b_spmv_bytes(st['nnz'], st['n_rows'])
 x = np.random.default_rng(0).standard_normal(h.n_nodes)
-variants = [("u4 remap", dict(GLIMS_SPMV_UNROLL="4", GLIMS_XCD_REMAP="1", GLIMS_SPMV_NT="0")),
-            ("u4", dict(GLIMS_SPMV_UNROLL="4", GLIMS_XCD_REMAP="0", GLIMS_SPMV_NT="0")),
-            ("u8", dict(GLIMS_SPMV_UNROLL="8", GLIMS_XCD_REMAP="0", GLIMS_SPMV_NT="0")),
-            ("u4 nt", dict(GLIMS_SPMV_UNROLL="4", GLIMS_XCD_REMAP="0", GLIMS_SPMV_NT="1")),
-            ("u8 nt", dict(GLIMS_SPMV_UNROLL="8", GLIMS_XCD_REMAP="0", GLIMS_SPMV_NT="1"))]
+variants = [("plain", dict(GLIMS_XCD_REMAP="0")), ("eighths", dict(GLIMS_XCD_REMAP="1")),
+            ("chunks of 4", dict(GLIMS_XCD_REMAP="4")), ("chunks of 16", dict(GLIMS_XCD_REMAP="16")),
+            ("chunks of 64", dict(GLIMS_XCD_REMAP="64")), ("chunks of 256", dict(GLIMS_XCD_REMAP="256"))]
 res = {n: [] for n, _ in variants}
 for rnd in range(6):
     for name, env in variants:
@@ -31,18 +29,3 @@ for name, v in res.items():
     v = np.array(v)
     print("%-18s median %7.1f us  min %7.1f us   -> %6.0f GB/s (median)" % (name, np.median(v), v.min(), b_alg / np.median(v) / 1e3))
 
-# ---- assembly sweep A/B (non-temporal streams on / off) ----
-c = w.c0
-resr = {"rd nt=0": [], "rd nt=1": []}
-import time
-for rnd in range(5):
-    for name, val in (("rd nt=0", "0"), ("rd nt=1", "1")):
-        os.environ["GLIMS_RD_NT"] = val
-        h.rd_residual(c, c)
-        t0 = time.perf_counter()
-        for _ in range(3):
-            h.rd_residual(c, c)
-        if rnd > 0:
-            resr[name].append((time.perf_counter() - t0) / 3 * 1e3)
-for name, v in resr.items():
-    print("%-10s median %.2f ms per glims_rd_residual call (includes 2 x 80 MB H2D + 1 D2H + mass SpMV)" % (name, np.median(v)))
