@@ -191,7 +191,9 @@ void build_host_pattern(HostPattern& hp, int dim, int64_t n_nodes, int64_t n_own
     max_len = std::max(max_len, (int)len);
     max_clen = std::max(max_clen, (int)clen);
   }
-  GL_REQUIRE(max_len <= 255, "a mesh node has more than 255 neighbours; not supported");
+  // slot indices are 8-bit, and the assembly sweep keeps 2 * len columns of 64 doubles in LDS (160 KB per CU)
+  GL_REQUIRE(max_len <= 150, "a mesh node has " + std::to_string(max_len) +
+                                 " neighbours; rows longer than 150 do not fit the LDS-resident assembly");
   for (int32_t s = 0; s < n_slices; ++s) {
     hp.slice_ptr[s + 1] += hp.slice_ptr[s];
     hp.cslice_ptr[s + 1] += hp.cslice_ptr[s];
