@@ -72,6 +72,10 @@ SIGNATURES = {
     "glims_reset_stats": (C.c_int, [_h]),
     "glims_apply": (C.c_int, [_h, C.c_int, _dp, _dp, C.c_int, _dp]),
     "glims_rd_residual": (C.c_int, [_h, _dp, _dp, _dp]),
+    "glims_snapshot_save": (C.c_int, [_h, _i64p]),
+    "glims_snapshot_load": (C.c_int, [_h, C.c_int64, _dp]),
+    "glims_snapshot_mechanics": (C.c_int, [_h, C.c_int64, _dp]),
+    "glims_snapshot_clear": (C.c_int, [_h]),
     "glims_project": (C.c_int, [_h, _dp, _dp, C.c_int, C.c_double]),
     "glims_comm_unique_id": (C.c_int, [C.c_char_p]),
     "glims_comm_init": (C.c_int, [_h, C.c_int, C.c_int, C.c_char_p]),
@@ -235,6 +239,25 @@ class Handle:
         R = np.empty(self.n_nodes)
         self._check(self.lib.glims_rd_residual(self._h, _ptr(c, _dp), _ptr(cp, _dp), _ptr(R, _dp)))
         return R
+
+    def snapshot_save(self):
+        sid = C.c_int64(-1)
+        self._check(self.lib.glims_snapshot_save(self._h, C.byref(sid)))
+        return int(sid.value)
+
+    def snapshot_load(self, sid):
+        c = np.empty(self.n_nodes)
+        self._check(self.lib.glims_snapshot_load(self._h, int(sid), _ptr(c, _dp)))
+        return c
+
+    def snapshot_mechanics(self, sid):
+        u = np.empty(self.n_nodes * self.dim)
+        st = self._check(self.lib.glims_snapshot_mechanics(self._h, int(sid), _ptr(u, _dp)),
+                         allow=(GLIMS_NOT_CONVERGED, GLIMS_NAN))
+        return u, st
+
+    def snapshot_clear(self):
+        self._check(self.lib.glims_snapshot_clear(self._h))
 
     def project(self, rhs, rtol=1e-12):
         """Solve M x = rhs for rhs [n_nodes] or [n_nodes, k] (L2 projection onto P1 given integrated loads)."""

@@ -243,6 +243,8 @@ int glims_destroy(glims_ctx* h) {
   (void)hipSetDevice(h->device);
   if (h->st) (void)hipStreamSynchronize(h->st);
   if (h->st_comm) (void)hipStreamSynchronize(h->st_comm);
+  for (auto* d : h->snapshots) delete d;
+  h->snapshots.clear();
   gl_comm_destroy(h);
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
   if (h->ev_a) (void)hipEventDestroy(h->ev_a);
@@ -506,6 +508,49 @@ int glims_rd_residual(glims_ctx* h, const double* c, const double* c_prev, doubl
       from_device_perm(h, h->cg_r.p, R, 1, h->n_own);
       for (int64_t i = 0; i < h->n_nodes; ++i) R[i] = -R[i];   // the kernel stores -R (the Newton right-hand side)
     }
+    return GLIMS_OK;
+  });
+}
+
+int glims_snapshot_save(glims_ctx* h, int64_t* id_out) {
+  return guarded(h, [&]() {
+    GL_REQUIRE(h->have_state && id_out, "glims_snapshot_save needs a state and an output id");
+    auto* d = new dvec<double>();
+    try {
+      d->alloc((size_t)h->n_nodes);
+    } catch (...) {
+      delete d;
+      throw;
+    }
+    GL_HIP(hipMemcpyAsync(d->p, h->c.p, (size_t)h->n_nodes * sizeof(double), hipMemcpyDeviceToDevice, h->st));
+    GL_HIP(hipStreamSynchronize(h->st));
+    h->snapshots.push_back(d);
+    *id_out = (int64_t)h->snapshots.size() - 1;
+    return GLIMS_OK;
+  });
+}
+
+int glims_snapshot_load(glims_ctx* h, int64_t id, double* c) {
+  return guarded(h, [&]() {
+    GL_REQUIRE(c && id >= 0 && id < (int64_t)h->snapshots.size() && h->snapshots[id], "unknown snapshot id");
+    from_device_perm(h, h->snapshots[id]->p, c, 1, h->n_nodes);
+    return GLIMS_OK;
+  });
+}
+
+int glims_snapshot_mechanics(glims_ctx* h, int64_t id, double* u) {
+  return guarded(h, [&]() {
+    GL_REQUIRE(u && id >= 0 && id < (int64_t)h->snapshots.size() && h->snapshots[id], "unknown snapshot id");
+    const int st = gl_solve_mechanics(h, h->snapshots[id]->p);
+    from_device_perm(h, h->U.p, u, h->dim, h->n_nodes);
+    return st;
+  });
+}
+
+int glims_snapshot_clear(glims_ctx* h) {
+  return guarded(h, [&]() {
+    for (auto* d : h->snapshots) delete d;
+    h->snapshots.clear();
     return GLIMS_OK;
   });
 }

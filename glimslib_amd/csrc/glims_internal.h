@@ -151,6 +151,7 @@ struct glims_ctx {
   dvec<double> U, mload, m_rhs, m_p, m_s, m_u, m_w, m_r, m_dinv, m_uD;   // mechanics, [n_nodes*dim]
   dvec<uint8_t> fixed_c, fixed_u;
   bool have_fixed_c = false, have_fixed_u = false, have_load_rd = false, have_mload = false;
+  std::vector<dvec<double>*> snapshots;     // device-resident recorded concentrations (owned)
   dvec<double> stage;                      // staging for host<->device permuted transfers [n_nodes*dim]
 
   dvec<double> partials, partials2;        // per-block partial sums (stage 1 / stage 2 of the reduction)
@@ -189,7 +190,7 @@ void gl_spmv_block(glims_ctx* h, const double* x, double* y, bool masked);
 
 // solver.hip ----------------------------------------------------------------------------------------
 int gl_step(glims_ctx* h, int n_steps);
-int gl_solve_mechanics(glims_ctx* h);
+int gl_solve_mechanics(glims_ctx* h, const double* c_dev = nullptr);   // c_dev: concentration to use (default: state)
 void gl_halo_exchange(glims_ctx* h, double* vec, int bs);   // blocking w.r.t. h->st (no overlap)
 void gl_comm_destroy(glims_ctx* h);
 int gl_comm_selftest(glims_ctx* h);

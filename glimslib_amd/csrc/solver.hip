@@ -732,7 +732,7 @@ int gl_project(glims_ctx* h, double* rhs, double* x, double rtol) {
 // ===================================================================================================
 // mechanics:  K_el u = G c + f,  Dirichlet dofs eliminated symmetrically (projected operator P K P)
 // ===================================================================================================
-int gl_solve_mechanics(glims_ctx* h) {
+int gl_solve_mechanics(glims_ctx* h, const double* c_dev) {
   GL_REQUIRE(h->is_setup && h->have_mech, "glims_solve_mechanics needs glims_setup(with_mechanics=1)");
   GL_REQUIRE(h->have_state, "glims_solve_mechanics before glims_set_state");
   const DevPattern& p = h->pat;
@@ -748,7 +748,7 @@ int gl_solve_mechanics(glims_ctx* h) {
                        p.diag_k.p, h->vKel.p, fx, h->m_dinv.p);
   GL_HIP(hipGetLastError());
   // rhs = G c + f - K u_D, zero on constrained dofs
-  gl_apply_G(h, h->c.p, h->m_rhs.p);
+  gl_apply_G(h, c_dev ? c_dev : h->c.p, h->m_rhs.p);
   if (fx) {
     gl_halo_exchange(h, h->m_uD.p, bs);
     gl_spmv_block(h, h->m_uD.p, h->m_w.p, false);

@@ -110,10 +110,14 @@ class FenicsSimulation(ABC):
 
     # -- run -----------------------------------------------------------------------------------------------
     def run(self, keep_nth=1, save_method='xdmf', clear_all=False, plot=True,
-            output_dir=config.output_dir_simulation_tmp):
+            output_dir=config.output_dir_simulation_tmp, results_on_device=None):
         """
         simulation_base.py:236-317.  ``save_method``: None, 'vtk' or 'xdmf' (both write .vtu files here).
         Returns ``self.solution`` (mixed Function {0: displacement, 1: concentration}).
+
+        ``results_on_device`` (extension): keep the recorded steps in HBM and materialise them lazily -- the
+        concentration is downloaded, and the displacement of a recorded step is solved, only when that step is
+        accessed.  None = automatic (on for meshes of >= 100 000 nodes when nothing is written to disk per step).
         """
         if self.geometric_dimension == 3:
             plot = False
@@ -139,6 +143,9 @@ class FenicsSimulation(ABC):
         sim_time = float(self.params.sim_time)
         keep_nth = max(1, int(keep_nth))
         single_step = self.solver.time_dependent_inputs
+        if results_on_device is None:
+            results_on_device = self.mesh.num_vertices() >= 100000 and save_method is None
+        lazy = bool(results_on_device) and getattr(self.solver, 'supports_snapshots', lambda: False)()
         while (current_sim_time <= sim_time - 1e-5) and continue_simulation:
             # steps until the next recorded step (or until the loop guard fails); they run back to back on the
             # device unless some input carries a time attribute `.t`, which forces the reference's per-step updates
@@ -163,8 +170,11 @@ class FenicsSimulation(ABC):
             time_step += done
             if (time_step % keep_nth == 0) and continue_simulation:
                 recording_step += 1
-                self.solver.sync_solution(with_mechanics=True)
-                self.results.add_to_results(current_sim_time, time_step, recording_step, self.solution)
+                if lazy:
+                    self.results.add_to_results(current_sim_time, time_step, recording_step, self.solver.snapshot())
+                else:
+                    self.solver.sync_solution(with_mechanics=True)
+                    self.results.add_to_results(current_sim_time, time_step, recording_step, self.solution)
                 self.results.save_solution(recording_step, current_sim_time, method=save_method)
 
         self.solver.sync_solution(with_mechanics=continue_simulation)

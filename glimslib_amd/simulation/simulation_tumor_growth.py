@@ -58,6 +58,14 @@ class HipTimeStepSolver:
     def update_time_dependent_inputs(self):
         self.sim._upload_loads_and_bcs(self.handle)
 
+    def supports_snapshots(self):
+        return hasattr(self.handle, 'snapshot_save')
+
+    def snapshot(self):
+        """Record the current step on the device; returns a lazily materialised Function."""
+        sid = self.handle.snapshot_save()
+        return DeviceSnapshotFunction(self.sim.mesh, self.sim.functionspace.subspaces.names, self, sid)
+
     def sync_solution(self, with_mechanics=True):
         if self.mechanics and with_mechanics and not self._mech_current:
             st = self.handle.solve_mechanics()
@@ -69,6 +77,76 @@ class HipTimeStepSolver:
         sol.components[1] = c
         if u is not None:
             sol.components[0] = u.reshape(-1, self.sim.geometric_dimension)
+
+
+class _LazyComponents(dict):
+    """{0: displacement, 1: concentration} of one recorded step, fetched / solved on first access."""
+
+    def __init__(self, solver, sid, dim, n):
+        super().__init__()
+        self._solver, self._sid, self._dim, self._n = solver, sid, dim, n
+
+    def _materialise(self, k):
+        if dict.__contains__(self, k):
+            return
+        if k == 1:
+            dict.__setitem__(self, 1, self._solver.handle.snapshot_load(self._sid))
+        elif k == 0:
+            if self._solver.mechanics:
+                u, st = self._solver.handle.snapshot_mechanics(self._sid)
+                self._solver._mech_current = False          # the device's displacement buffer now belongs to this step
+                if st != _backend.GLIMS_OK:
+                    self._solver.sim.logger.warning("    - displacement solve did not converge (status %d)" % st)
+                dict.__setitem__(self, 0, u.reshape(self._n, self._dim))
+            else:
+                dict.__setitem__(self, 0, np.zeros((self._n, self._dim)))
+        else:
+            raise KeyError(k)
+
+    def __getitem__(self, k):
+        self._materialise(k)
+        return dict.__getitem__(self, k)
+
+    def __contains__(self, k):
+        return k in (0, 1)
+
+    def keys(self):
+        return [0, 1]
+
+    def __iter__(self):
+        return iter([0, 1])
+
+    def __len__(self):
+        return 2
+
+    def items(self):
+        return [(k, self[k]) for k in (0, 1)]
+
+    def values(self):
+        return [self[k] for k in (0, 1)]
+
+
+class DeviceSnapshotFunction(Function):
+    """
+    A recorded solution that lives on the device (``glims_snapshot_save``): the concentration is downloaded and the
+    displacement is SOLVED only when first accessed -- legitimate because the displacement of a step depends on that
+    step's concentration alone (one-way coupling, simulation_tumor_growth.py:110-120).  Immutable: ``copy()`` returns
+    self, which is what ``Results.add_to_results`` (a deep copy per recorded step in the reference) stores.
+    """
+
+    def __init__(self, mesh, names, solver, sid):
+        self.mesh = mesh
+        self.names = names
+        self._name = 'solution_function'
+        self.label = 'solution_function'
+        self.components = _LazyComponents(solver, sid, mesh.dim, mesh.num_vertices())
+        self.snapshot_id = sid
+
+    def copy(self, deepcopy=True):
+        return self
+
+    def assign(self, other):
+        raise TypeError("device snapshots are immutable")
 
 
 class TumorGrowth(FenicsSimulation):
@@ -201,6 +279,8 @@ class TumorGrowth(FenicsSimulation):
             c0[cnodes] = cvals
         h.set_state(c0, u_previous.components[0].reshape(-1) if mechanics else None)
         h.reset_stats()
+        if hasattr(h, 'snapshot_clear'):
+            h.snapshot_clear()
         self.solution = self.functionspace.new_function(name='solution_function')
         self.solution.label = 'solution_function'
         self.solution.assign(u_previous)

@@ -157,6 +157,22 @@ int glims_apply(glims_ctx* h, int which, const double* x, double* y, int reps, d
  *   R = 1/2 (A(c) + S) c - M c_prev - rd_load.  R may be NULL. */
 int glims_rd_residual(glims_ctx* h, const double* c, const double* c_prev, double* R);
 
+/* ---- device-resident time series ----------------------------------------------------------------------------------
+ * Results.add_to_results deep-copies the mixed solution on the host at every recorded step
+ * (helper_classes.py:1128-1144, called from simulation_base.py:306-309).  With 288 GB of HBM the recorded
+ * concentration fields can stay on the device instead (80 MB per step at 10 M nodes), and -- because the displacement of
+ * a step depends only on that step's concentration (simulation_tumor_growth.py:110-120) -- the elastic solve of a
+ * recorded step can be deferred until somebody asks for its displacement.
+ *   glims_snapshot_save       copies the current concentration into a new device buffer, returns its id (>= 0)
+ *   glims_snapshot_load       concentration of snapshot `id` -> host c[n_nodes]
+ *   glims_snapshot_mechanics  solves K_el u = G c_id + f for that snapshot -> host u[n_nodes*dim]; the time-stepping
+ *                             state is not touched (status as glims_solve_mechanics)
+ *   glims_snapshot_clear      releases all snapshots */
+int glims_snapshot_save(glims_ctx* h, int64_t* id_out);
+int glims_snapshot_load(glims_ctx* h, int64_t id, double* c);
+int glims_snapshot_mechanics(glims_ctx* h, int64_t id, double* u);
+int glims_snapshot_clear(glims_ctx* h);
+
 /* L2 projection onto the P1 space: solves M x = rhs for `ncomp` right-hand sides stored [n_nodes][ncomp]
  * (rhs_i = int f phi_i dx, integrated by the caller), Jacobi-PCG to ||r|| <= rtol*||rhs|| per component.
  * Stands in for fenics.project(expr, FunctionSpace(mesh, "Lagrange", 1)) as used by the PostProcess classes

@@ -271,3 +271,39 @@ def test_stale_bc_key_of_the_3d_atlas_script_leaves_the_body_unclamped(caplog):
     assert any('incomplete' in r.message for r in caplog.records)
     assert rel_l2(res['boundary_name'].components[1], res['named_boundary'].components[1]) < 1e-13
     assert np.isfinite(res['boundary_name'].components[0]).all()
+
+
+def test_results_on_device_are_lazy_and_identical():
+    """Recorded steps kept in HBM: same numbers as the eager path, but the displacement of a step is only solved when
+    that step is looked at (one elastic solve for run()'s return value + one per inspected step)."""
+    mesh = fenics.BoxMesh(fenics.Point(0, 0, 0), fenics.Point(20, 18, 16), 10, 9, 8)
+    sims = {}
+    for lazy in (False, True):
+        sim = TumorGrowth(mesh)
+        sim.setup_global_parameters(boundaries={'boundary_all': Boundary()},
+                                    dirichlet_bcs={'c': {'bc_value': fenics.Constant((0., 0., 0.)),
+                                                         'named_boundary': 'boundary_all', 'subspace_id': 0}})
+        iv = fenics.Expression('exp(-0.05*(pow(x[0]-12,2)+pow(x[1]-9,2)+pow(x[2]-8,2)))', degree=1)
+        sim.setup_model_parameters(iv_expression={0: fenics.Constant((0., 0., 0.)), 1: iv}, diffusion=0.05, coupling=0.1,
+                                   proliferation=0.05, E=0.003, poisson=0.45, sim_time=6, sim_time_step=1)
+        sim.run(save_method=None, plot=False, results_on_device=lazy)
+        sims[lazy] = sim
+    eager, lazy = sims[False], sims[True]
+    assert eager.solver_statistics()['mech_solves'] == 6
+    assert lazy.solver_statistics()['mech_solves'] == 1                  # only run()'s return value so far
+    assert lazy.results.get_recording_steps() == list(range(7))
+    c3 = lazy.results.get_solution_function(subspace_name='concentration', recording_step=3).values()
+    assert lazy.solver_statistics()['mech_solves'] == 1                  # concentration access does not solve anything
+    assert np.array_equal(c3, eager.results.get_solution_function(subspace_id=1, recording_step=3).values())
+    u3 = lazy.results.get_solution_function(subspace_name='displacement', recording_step=3).values()
+    assert lazy.solver_statistics()['mech_solves'] == 2
+    u3e = eager.results.get_solution_function(subspace_id=0, recording_step=3).values()
+    assert rel_l2(u3, u3e) < 1e-8
+    lazy.results.get_solution_function(subspace_name='displacement', recording_step=3)
+    assert lazy.solver_statistics()['mech_solves'] == 2                  # cached
+    assert rel_l2(lazy.solution.components[0], eager.solution.components[0]) < 1e-8
+    assert np.array_equal(lazy.solution.components[1], eager.solution.components[1])
+    pp = lazy.init_postprocess(None)                                      # derived fields work on lazy records too
+    assert np.isfinite(pp.get_pressure(recording_step=5).values()).all()
+    for s in sims.values():
+        s.close()
