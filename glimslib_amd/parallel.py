@@ -24,7 +24,11 @@ from .partition import partition_mesh
 
 
 def dist_info():
-    """(dist module or None, rank, world)."""
+    """(dist module or None, rank, world).  torch is only imported when a launcher environment is present or the
+    caller has imported it already (a single-process run should not pay ~1 s for it)."""
+    import sys
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1 and "torch" not in sys.modules:
+        return None, 0, 1
     try:
         import torch.distributed as dist
     except Exception:   # pragma: no cover
