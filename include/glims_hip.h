@@ -64,7 +64,8 @@ typedef struct glims_options {
 } glims_options;
 
 #define GLIMS_FLAG_EXTRAPOLATE_GUESS 1  /* Newton guess c^n + (c^n - c^{n-1}) instead of c^n (reference: c^n) */
-#define GLIMS_FLAG_WARM_START 2         /* first linear solve of a step starts from the previous step's increment */
+#define GLIMS_FLAG_WARM_START 2         /* first linear solve of a step starts from the previous step's increment
+                                           (ignored when GLIMS_FLAG_EXTRAPOLATE_GUESS is set) */
 
 typedef struct glims_stats {
   int64_t steps;            /* implicit time steps taken */

@@ -166,7 +166,8 @@ def test_bitwise_reproducible_and_guess_option(backend):
     mesh, lab = _case(3)
     c0 = np.exp(-4 * ((mesh.points - mesh.points.mean(0)) ** 2).sum(1))
     outs = []
-    for flags in (backend.FLAG_WARM_START, backend.FLAG_WARM_START, backend.FLAG_EXTRAPOLATE_GUESS, 0):
+    for flags in (backend.FLAG_WARM_START, backend.FLAG_WARM_START, backend.FLAG_EXTRAPOLATE_GUESS, 0,
+                  backend.FLAG_EXTRAPOLATE_GUESS | backend.FLAG_WARM_START):
         h = _handle(backend, mesh, lab, 1.0, mechanics=False, flags=flags)
         h.set_state(c0)
         assert h.step(6) == 0
@@ -175,6 +176,7 @@ def test_bitwise_reproducible_and_guess_option(backend):
     assert np.array_equal(outs[0], outs[1])                      # no atomics anywhere: same bits every run
     assert rel_l2(outs[2], outs[0]) < 1e-9                       # a different Newton guess, the same fixed point
     assert rel_l2(outs[3], outs[0]) < 1e-9                       # no warm start of the linear solve, ditto
+    assert np.array_equal(outs[4], outs[2])                      # warm start is ignored when extrapolating
 
 
 def test_failure_semantics_and_usage_errors(backend):
