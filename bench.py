@@ -121,9 +121,8 @@ def main():
     if world > 1:
         part = partition_mesh(w.mesh.points, w.mesh.cells, world, rank)
         h = Handle(part.points, part.cells, w.cell_label[part.cell_ids], n_own=part.n_own, device=local_rank)
-        uid = [Handle.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        h.comm_init(rank, world, uid[0])
+        from glimslib_amd.parallel import broadcast_unique_id
+        h.comm_init(rank, world, broadcast_unique_id(dist, rank))
         h.set_halo(part.peer_rank, part.send_ptr, part.send_idx, part.recv_count)
         c0 = w.c0[part.global_ids]
     else:

@@ -38,6 +38,23 @@ def dist_info():
     return None, 0, 1
 
 
+def broadcast_unique_id(dist, rank):
+    """RCCL unique id of rank 0 to every rank, as a CPU uint8 tensor (gloo side of a 'cpu:gloo,cuda:nccl' group)."""
+    import torch
+    buf = torch.zeros(_backend.GLIMS_UNIQUE_ID_BYTES, dtype=torch.uint8)
+    if rank == 0:
+        buf = torch.frombuffer(bytearray(_backend.Handle.comm_unique_id()), dtype=torch.uint8).clone()
+    try:
+        dist.broadcast(buf, src=0)
+    except Exception:
+        # process group without a CPU backend (plain 'nccl'): go through the GPU
+        dev = torch.device("cuda", torch.cuda.current_device())
+        gbuf = buf.to(dev)
+        dist.broadcast(gbuf, src=0)
+        buf = gbuf.cpu()
+    return bytes(buf.numpy().tobytes())
+
+
 class HostStagedTransport:
     """glims_halo_fn / glims_allreduce_fn implemented with hipMemcpy staging + torch.distributed CPU collectives."""
 
@@ -116,9 +133,7 @@ class DistributedHandle:
             self._transport = HostStagedTransport(dist)
             self.h.set_transport(rank, world, self._transport.halo_cb, self._transport.allreduce_cb)
         else:
-            uid = [_backend.Handle.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            self.h.comm_init(rank, world, uid[0])
+            self.h.comm_init(rank, world, broadcast_unique_id(dist, rank))
         self.h.set_halo(p.peer_rank, p.send_ptr, p.send_idx, p.recv_count)
         self.g2l_owned = np.full(self.n_global, -1, dtype=np.int64)
         self.g2l_owned[p.global_ids[:p.n_own]] = np.arange(p.n_own)

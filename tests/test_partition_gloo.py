@@ -125,3 +125,26 @@ def test_two_rank_gloo_step_equals_serial(tmp_path):
         assert 1 <= int(z['newton']) <= 6
     assert not np.isnan(c).any()
     assert rel_l2(c, c_ref) < 1e-9
+
+
+def _uid_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from glimslib_amd.parallel import broadcast_unique_id
+        uid = broadcast_unique_id(dist, rank)
+        with open(os.path.join(out_dir, "uid%d.bin" % rank), "wb") as f:
+            f.write(uid)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_rccl_unique_id_reaches_every_rank(tmp_path):
+    """The id bench.py / the API hand to glims_comm_init: generated on rank 0, identical bytes on all ranks."""
+    world = 2
+    mp.spawn(_uid_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    a = open(os.path.join(str(tmp_path), "uid0.bin"), "rb").read()
+    b = open(os.path.join(str(tmp_path), "uid1.bin"), "rb").read()
+    assert len(a) == 256 and a == b and any(a)
