@@ -33,7 +33,8 @@ def log(*a):
 def cpu_baseline(budget_s=15.0):
     """
     CPU baseline ("port"): the C/OpenMP restatement oracle/glims_oracle_c.c (Newton + Jacobi-PCG on CSR, fp64, same
-    tolerances as the device run) on ALL host cores of this box, on a bounded sample of the same workload: the
+    tolerances as the device run) on this job's CPU share of the box (16 OpenMP threads unless GLIMS_ORACLE_THREADS
+    says otherwise; the box reports more cores than one job may use), on a bounded sample of the same workload: the
     brain-extent box at n=99 (config C3, 1 000 000 DoF), as many implicit steps as fit in ~budget_s seconds.
     FEniCS itself is not installed here, hence kind = "port", not "reference".
     """

@@ -25,6 +25,11 @@ def lib():
         L.oc_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.oc_nnz.restype = C.c_int64
         L.oc_nnz.argtypes = [C.c_void_p]
+        L.oc_set_threads.argtypes = [C.c_int]
+        # a GPU box gives one job a share of ~16 cores although it reports many more; oversubscribed OpenMP barriers
+        # are catastrophic for the small configs, so cap the team (GLIMS_ORACLE_THREADS overrides)
+        n = int(os.environ.get("GLIMS_ORACLE_THREADS", min(os.cpu_count() or 1, 16)))
+        L.oc_set_threads(n)
         _lib = L
     return _lib
 

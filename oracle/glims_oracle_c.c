@@ -244,6 +244,13 @@ int oc_step(void* h, double* c, int n_steps, double rtol, double atol, double cg
 }
 
 void oc_stats(void* h, int64_t* out3) { oc_t* o = (oc_t*)h; out3[0] = o->newton_its; out3[1] = o->cg_its; out3[2] = o->sweeps; }
+void oc_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
 int oc_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

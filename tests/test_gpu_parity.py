@@ -398,3 +398,23 @@ def test_delaunay_mesh_matches_both_oracles(backend):
     assert rel_l2(u, o.mech_solve(ref)) < 1e-6                   # slivers: K_el is ill-conditioned, PCG at rtol 1e-10
     h.close()
     co.close()
+
+
+@pytest.mark.parametrize("name", ["c2", "c3"])
+def test_baseline_configs_complete_runs_match_the_c_oracle(backend, name):
+    """BASELINE configs C2 (20 steps) and C3 (50 steps) run to completion at full size; final concentration against
+    the C/OpenMP oracle run with a tighter Newton tolerance.  Bar: 1e-6 (north_star); observed ~1e-10."""
+    from oracle.c_port import COracle
+    w = workloads.by_name(name)
+    co = COracle(w.mesh.points, w.mesh.cells, w.per_cell('D'), w.per_cell('rho'), w.dt)
+    ref = co.step(w.c0, w.n_steps, rtol=1e-11, cg_rtol=1e-4)
+    h = _handle(backend, w.mesh, w.cell_label, w.dt, w.tables, mechanics=False)
+    h.set_state(w.c0)
+    assert h.step(w.n_steps) == 0
+    c = h.get_state(want_u=False)[0]
+    err = rel_l2(c, ref)
+    print("%s: %d steps, rel-L2 vs C oracle %.2e" % (name, w.n_steps, err))
+    assert err < 1e-8
+    assert h.stats()['steps'] == w.n_steps
+    h.close()
+    co.close()
