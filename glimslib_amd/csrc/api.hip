@@ -19,6 +19,7 @@ void read_tuning(glims_ctx* h) {
   if (const char* e = getenv("GLIMS_RD_NT")) h->tune_rd_nt = atoi(e);
   if (const char* e = getenv("GLIMS_RD_REMAP")) h->tune_rd_remap = atoi(e);
   if (const char* e = getenv("GLIMS_RD_UNROLL")) h->tune_rd_unroll = atoi(e);
+  if (const char* e = getenv("GLIMS_IDX16")) h->tune_idx16 = atoi(e);
 }
 
 std::mutex g_err_mu;
@@ -157,6 +158,9 @@ int glims_create(glims_ctx** out, int dim, int64_t n_nodes, int64_t n_own, int64
     p.total_corners = hp.cslice_ptr[hp.n_slices];
     p.slice_ptr.upload(hp.slice_ptr, h->st);
     p.cols.upload(hp.cols, h->st);
+    p.cols16.upload(hp.cols16, h->st);
+    p.win_base.upload(hp.win_base, h->st);
+    p.win_ok.upload(hp.win_ok, h->st);
     p.diag_k.upload(hp.diag_k, h->st);
     p.cslice_ptr.upload(hp.cslice_ptr, h->st);
     p.cslots.upload(hp.cslots, h->st);
@@ -219,6 +223,8 @@ int glims_create(glims_ctx** out, int dim, int64_t n_nodes, int64_t n_own, int64
     h->stats.nnz = hp.nnz;
     h->stats.nnz_padded = p.total_entries;
     h->stats.n_corners = hp.n_corners;
+    for (int32_t sl = 0; sl < hp.n_slices; ++sl)
+      if (hp.win_ok[sl] && h->tune_idx16) h->stats.nnz_idx16 += hp.slice_ptr[sl + 1] - hp.slice_ptr[sl];
     *out = h;
     return GLIMS_OK;
   } catch (const glims_error& e) {
@@ -449,6 +455,7 @@ int glims_reset_stats(glims_ctx* h) {
   h->stats.nnz = keep.nnz;
   h->stats.nnz_padded = keep.nnz_padded;
   h->stats.n_corners = keep.n_corners;
+  h->stats.nnz_idx16 = keep.nnz_idx16;
   h->stats.steps = keep.steps;   // step counter drives the extrapolated guess; keep it
   return GLIMS_OK;
 }

@@ -12,6 +12,12 @@
 #define GL_SIGMA 256               // sigma window (rows) of the SELL-C-sigma row sort (tools/sigma_sweep.py: on an
                                    // unstructured mesh 256 beats 4096 by 1.7x in SpMV time despite +17 % padding)
 #define GL_MAX_LABELS 256
+// 16-bit column codes: the columns of one 64-row slice fall into a few compact ranges of the Morton numbering (the
+// neighbouring 4x4x4 blocks), so a code = (window id, offset) against a per-slice table of GL_N_WIN window bases
+// covers every slice of the BASELINE meshes and of 1 M-point Delaunay meshes (tools/pattern_stats.cpp); the SpMV then
+// streams 2 B instead of 4 B of index per entry.  Slices that need more windows fall back to the 32-bit stream.
+#define GL_WIN_BITS 11
+#define GL_N_WIN 32
 
 struct glims_error : std::runtime_error {
   int code;
@@ -78,6 +84,12 @@ struct HostPattern {
   int32_t n_slices = 0;                    // ceil(n_own / 64)
   std::vector<int64_t> slice_ptr;          // [n_slices+1] offsets into cols (multiples of 64)
   std::vector<int32_t> cols;               // SELL-64 column indices (new numbering), padded with the row itself
+  // compressed column stream: cols16 = (window << GL_WIN_BITS) | offset, column = win_base[slice][window] + offset;
+  // slices whose columns need more than GL_N_WIN windows keep win_ok = 0 and are read through `cols`
+  std::vector<uint16_t> cols16;
+  std::vector<int32_t> win_base;           // [n_slices * GL_N_WIN]
+  std::vector<uint8_t> win_ok;             // [n_slices]
+  int64_t n_compressed = 0;                // slices with win_ok
   std::vector<uint8_t> diag_k;             // [n_slices*64] slot of the diagonal in each row
   std::vector<int64_t> cslice_ptr;         // [n_slices+1] offsets into the (row, cell) incidence arrays
   std::vector<uint32_t> cslots;            // 4 x uint8: slot (within the row) of each vertex of the cell
@@ -100,6 +112,9 @@ struct DevPattern {
   int max_len = 0, max_clen = 0;
   dvec<int64_t> slice_ptr;
   dvec<int32_t> cols;
+  dvec<uint16_t> cols16;
+  dvec<int32_t> win_base;
+  dvec<uint8_t> win_ok;
   dvec<uint8_t> diag_k;
   dvec<int64_t> cslice_ptr;
   dvec<uint32_t> cslots;
@@ -136,7 +151,7 @@ struct glims_ctx {
   glims_options opt;
   glims_stats stats;
   // tuning knobs (env GLIMS_SPMV_UNROLL = 4|8, GLIMS_XCD_REMAP = 0 plain | 1 eighths | G chunk, GLIMS_SPMV_NT = 0|1), read at glims_create and by glims_apply
-  int tune_spmv_unroll = 4, tune_xcd_remap = 64, tune_rd_remap = 64, tune_spmv_nt = 1, tune_rd_nt = 0, tune_rd_unroll = 24;
+  int tune_spmv_unroll = 4, tune_xcd_remap = 64, tune_rd_remap = 64, tune_spmv_nt = 1, tune_rd_nt = 0, tune_rd_unroll = 24, tune_idx16 = 1;
 
   // scalar operator planes (SELL-64 layout) and block planes
   dvec<double> vM, vS, vA, vKel, vG;

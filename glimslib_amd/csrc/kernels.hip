@@ -174,6 +174,11 @@ __global__ __launch_bounds__(GL_WAVE) void k_assemble_static(
 //   s_T = sum of c over the cell's vertices, w_T = rho_T |T| d!/(d+3)!   [exact integral of rho c_h phi_i phi_j]
 //   -R = b - 1/2 (A + S) c,   b = M c_prev + load
 // ---------------------------------------------------------------------------------------------------
+// column of one entry from its 16-bit code: window base by cross-lane read (lane w of `wb` holds base w), + offset
+__device__ __forceinline__ int32_t decode_col(uint32_t code, int32_t wb) {
+  return __builtin_amdgcn_ds_bpermute((int)((code >> GL_WIN_BITS) << 2), wb) + (int32_t)(code & ((1u << GL_WIN_BITS) - 1u));
+}
+
 // B (row, cell) incidence records of one lane: issue all loads, then apply them in order
 template <int B, int NT, class F>
 __device__ __forceinline__ void corner_batch(const double* __restrict__ wp, const uint32_t* __restrict__ sl, int q,
@@ -189,10 +194,11 @@ __device__ __forceinline__ void corner_batch(const double* __restrict__ wp, cons
   for (int j = 0; j < B; ++j) corner(wb[j], sb[j]);
 }
 
-template <int NV, int NT, int CU>
+template <int NV, int NT, int CU, int CIDX>
 __global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
     const int32_t* __restrict__ slice_list, int64_t n_own, const int64_t* __restrict__ slice_ptr,
-    const int32_t* __restrict__ cols,
+    const int32_t* __restrict__ cols, const uint16_t* __restrict__ cols16, const int32_t* __restrict__ win_base,
+    const uint8_t* __restrict__ win_ok,
     const int64_t* __restrict__ cslice_ptr, const uint32_t* __restrict__ cslots, const double* __restrict__ cw,
     const uint8_t* __restrict__ diag_k, const double* __restrict__ vS, double* __restrict__ vA,
     const double* __restrict__ c, const double* __restrict__ b, const double* __restrict__ b2,
@@ -210,16 +216,14 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
     const int64_t row = (int64_t)s * GL_WAVE + lane;
     const int64_t base = slice_ptr[s], cbase = cslice_ptr[s];
     const int len = (int)((slice_ptr[s + 1] - base) >> 6), clen = (int)((cslice_ptr[s + 1] - cbase) >> 6);
-    const int32_t* cc = cols + base + lane;
     // phase 1: gather the row's neighbour values of c into the lane's LDS column (same pattern as the SpMV gather)
-    {
+    auto gather = [&](auto load_col) {
       int k = 0;
       for (; k + 8 <= len; k += 8) {
         int32_t ci8[8];
         double x8[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          ci8[j] = NT ? __builtin_nontemporal_load(cc + (int64_t)(k + j) * GL_WAVE) : cc[(int64_t)(k + j) * GL_WAVE];
+        for (int j = 0; j < 8; ++j) ci8[j] = load_col(k + j);
 #pragma unroll
         for (int j = 0; j < 8; ++j) x8[j] = c[ci8[j]];
 #pragma unroll
@@ -229,9 +233,21 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
         }
       }
       for (; k < len; ++k) {
-        cn[k * GL_WAVE + lane] = c[cc[(int64_t)k * GL_WAVE]];
+        cn[k * GL_WAVE + lane] = c[load_col(k)];
         acc[k * GL_WAVE + lane] = 0.0;
       }
+    };
+    if (CIDX && win_ok[s]) {   // wave-uniform: 16-bit (window, offset) codes, see spmv_row
+      const uint16_t* c16 = cols16 + base + lane;
+      const int32_t wb = win_base[(int64_t)s * GL_N_WIN + (lane & (GL_N_WIN - 1))];
+      gather([&](int k) {
+        return decode_col(NT ? __builtin_nontemporal_load(c16 + (int64_t)k * GL_WAVE) : c16[(int64_t)k * GL_WAVE], wb);
+      });
+    } else {
+      const int32_t* cc = cols + base + lane;
+      gather([&](int k) {
+        return NT ? __builtin_nontemporal_load(cc + (int64_t)k * GL_WAVE) : cc[(int64_t)k * GL_WAVE];
+      });
     }
     const int dk = diag_k[row];
     const double ci = cn[dk * GL_WAVE + lane];
@@ -315,10 +331,59 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
 //   DOTS: partials[b] = y.x over the rows of logical block b (the PCG's delta = w.u; r.u and r.r come from the
 //   vector-update kernel, which has r and u in registers anyway, so this kernel never reads r)
 // ---------------------------------------------------------------------------------------------------
-template <int DOTS, int UNR, int NT>
+// one lane's row of a slice: UNR independent (column, value, gather) triples in flight
+// NT: values and columns are streamed exactly once per SpMV -> non-temporal, so that they do not displace the
+// gathered x entries from L2 / Infinity Cache
+template <int COMP, int UNR, int NT>
+__device__ __forceinline__ double spmv_row(const int32_t* __restrict__ cc, const uint16_t* __restrict__ c16,
+                                            int32_t wb, const double* __restrict__ v, const double* __restrict__ x,
+                                            int len) {
+  double acc = 0.0;
+  int k = 0;
+  for (; k + UNR <= len; k += UNR) {
+    int32_t cu[UNR];
+    double vu[UNR], xu[UNR];
+    if (COMP) {
+      uint16_t qu[UNR];
+#pragma unroll
+      for (int j = 0; j < UNR; ++j)
+        qu[j] = NT ? __builtin_nontemporal_load(c16 + (int64_t)(k + j) * GL_WAVE) : c16[(int64_t)(k + j) * GL_WAVE];
+#pragma unroll
+      for (int j = 0; j < UNR; ++j)
+        vu[j] = NT ? __builtin_nontemporal_load(v + (int64_t)(k + j) * GL_WAVE) : v[(int64_t)(k + j) * GL_WAVE];
+#pragma unroll
+      for (int j = 0; j < UNR; ++j) cu[j] = decode_col(qu[j], wb);
+    } else {
+#pragma unroll
+      for (int j = 0; j < UNR; ++j)
+        cu[j] = NT ? __builtin_nontemporal_load(cc + (int64_t)(k + j) * GL_WAVE) : cc[(int64_t)(k + j) * GL_WAVE];
+#pragma unroll
+      for (int j = 0; j < UNR; ++j)
+        vu[j] = NT ? __builtin_nontemporal_load(v + (int64_t)(k + j) * GL_WAVE) : v[(int64_t)(k + j) * GL_WAVE];
+    }
+#pragma unroll
+    for (int j = 0; j < UNR; ++j) xu[j] = x[cu[j]];
+#pragma unroll
+    for (int j = 0; j < UNR; ++j) acc += vu[j] * xu[j];
+  }
+  for (; k < len; ++k) {
+    int32_t cj;
+    if (COMP)
+      cj = decode_col(NT ? __builtin_nontemporal_load(c16 + (int64_t)k * GL_WAVE) : c16[(int64_t)k * GL_WAVE], wb);
+    else
+      cj = NT ? __builtin_nontemporal_load(cc + (int64_t)k * GL_WAVE) : cc[(int64_t)k * GL_WAVE];
+    const double vj = NT ? __builtin_nontemporal_load(v + (int64_t)k * GL_WAVE) : v[(int64_t)k * GL_WAVE];
+    acc += vj * x[cj];
+  }
+  return acc;
+}
+
+template <int DOTS, int UNR, int NT, int CIDX>
 __global__ __launch_bounds__(256) void k_spmv(int n_launch, int chunk, const int32_t* __restrict__ slice_list,
                                                int64_t n_own, const int64_t* __restrict__ slice_ptr,
-                                               const int32_t* __restrict__ cols, const double* __restrict__ vals,
+                                               const int32_t* __restrict__ cols, const uint16_t* __restrict__ cols16,
+                                               const int32_t* __restrict__ win_base,
+                                               const uint8_t* __restrict__ win_ok, const double* __restrict__ vals,
                                                const double* __restrict__ x, double* __restrict__ y,
                                                const uint8_t* __restrict__ fixed, const double* __restrict__ addv,
                                                const double* __restrict__ r, double* __restrict__ partials,
@@ -336,30 +401,12 @@ __global__ __launch_bounds__(256) void k_spmv(int n_launch, int chunk, const int
     const int64_t base = slice_ptr[s];
     const int len = (int)((slice_ptr[s + 1] - base) >> 6);
     const double* v = vals + base + lane;
-    const int32_t* cc = cols + base + lane;
-    double acc = 0.0;
-    int k = 0;
-    // UNR independent (column, value, gather) triples in flight per lane
-    for (; k + UNR <= len; k += UNR) {
-      int32_t cu[UNR];
-      double vu[UNR], xu[UNR];
-      // NT: values and columns are streamed exactly once per SpMV -> non-temporal, so that they do not displace the
-      // gathered x entries from L2 / Infinity Cache
-#pragma unroll
-      for (int j = 0; j < UNR; ++j)
-        cu[j] = NT ? __builtin_nontemporal_load(cc + (int64_t)(k + j) * GL_WAVE) : cc[(int64_t)(k + j) * GL_WAVE];
-#pragma unroll
-      for (int j = 0; j < UNR; ++j)
-        vu[j] = NT ? __builtin_nontemporal_load(v + (int64_t)(k + j) * GL_WAVE) : v[(int64_t)(k + j) * GL_WAVE];
-#pragma unroll
-      for (int j = 0; j < UNR; ++j) xu[j] = x[cu[j]];
-#pragma unroll
-      for (int j = 0; j < UNR; ++j) acc += vu[j] * xu[j];
-    }
-    for (; k < len; ++k) {
-      const int32_t cj = NT ? __builtin_nontemporal_load(cc + (int64_t)k * GL_WAVE) : cc[(int64_t)k * GL_WAVE];
-      const double vj = NT ? __builtin_nontemporal_load(v + (int64_t)k * GL_WAVE) : v[(int64_t)k * GL_WAVE];
-      acc += vj * x[cj];
+    double acc;
+    if (CIDX && win_ok[s]) {   // wave-uniform
+      const int32_t wb = win_base[(int64_t)s * GL_N_WIN + (lane & (GL_N_WIN - 1))];
+      acc = spmv_row<1, UNR, NT>(nullptr, cols16 + base + lane, wb, v, x, len);
+    } else {
+      acc = spmv_row<0, UNR, NT>(cols + base + lane, nullptr, 0, v, x, len);
     }
     if (row < n_own) {
       if (fixed && fixed[row]) acc = 0.0;
@@ -533,12 +580,17 @@ void gl_rd_assemble(glims_ctx* h, const double* c, const double* b, const double
                     double* partials) {
   const DevPattern& p = h->pat;
   const uint8_t* fx = h->have_fixed_c ? h->fixed_c.p : nullptr;
+#define GL_RD3(NV, NT, CU, CIDX)                                                                                   \
+  do {                                                                                                             \
+    set_lds(k_rd_assemble<NV, NT, CU, CIDX>, lds);                                                                 \
+    hipLaunchKernelGGL((k_rd_assemble<NV, NT, CU, CIDX>), dim3(grid), dim3(GL_WAVE), lds, h->st, list, h->n_own,    \
+                       p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, p.win_ok.p, p.cslice_ptr.p, p.cslots.p,   \
+                       p.cw.p, p.diag_k.p, h->vS.p, h->vA.p, c, b, b2, r_out, r2_out, h->dinv.p, fx,                 \
+                       2.0 * h->opt.dt, partials, cap, h->tune_rd_remap);                                          \
+  } while (0)
 #define GL_RD2(NV, NT, CU)                                                                                         \
   do {                                                                                                             \
-    set_lds(k_rd_assemble<NV, NT, CU>, lds);                                                                       \
-    hipLaunchKernelGGL((k_rd_assemble<NV, NT, CU>), dim3(grid), dim3(GL_WAVE), lds, h->st, list, h->n_own,          \
-                       p.slice_ptr.p, p.cols.p, p.cslice_ptr.p, p.cslots.p, p.cw.p, p.diag_k.p, h->vS.p, h->vA.p, c, \
-                       b, b2, r_out, r2_out, h->dinv.p, fx, 2.0 * h->opt.dt, partials, cap, h->tune_rd_remap);    \
+    if (h->tune_idx16) GL_RD3(NV, NT, CU, 1); else GL_RD3(NV, NT, CU, 0);                                         \
   } while (0)
 #define GL_RD(NV, NT)                                                                                              \
   do {                                                                                                             \
@@ -562,6 +614,7 @@ void gl_rd_assemble(glims_ctx* h, const double* c, const double* b, const double
   }
 #undef GL_RD
 #undef GL_RD2
+#undef GL_RD3
   GL_HIP(hipGetLastError());
 }
 
@@ -579,9 +632,14 @@ void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* s
   const int grid = gl_spmv_grid(n_launch);
   const int chunk = (n_launch + grid - 1) / grid;
   const int remap = slice_list ? 0 : h->tune_xcd_remap;   // 0 plain, 1 contiguous eighths, G > 1 chunks of G blocks
-#define GL_SPMV(DOTS, UNR, NT)                                                                                     \
-  hipLaunchKernelGGL((k_spmv<DOTS, UNR, NT>), dim3(grid), dim3(256), 0, st, n_launch, chunk, slice_list, h->n_own, \
-                     p.slice_ptr.p, p.cols.p, vals, x, y, fixed, addv, r, partials, partial_off, done, remap)
+#define GL_SPMV3(DOTS, UNR, NT, CIDX)                                                                              \
+  hipLaunchKernelGGL((k_spmv<DOTS, UNR, NT, CIDX>), dim3(grid), dim3(256), 0, st, n_launch, chunk, slice_list,      \
+                     h->n_own, p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, p.win_ok.p, vals, x, y, fixed,     \
+                     addv, r, partials, partial_off, done, remap)
+#define GL_SPMV(DOTS, UNR, NT)                                                       \
+  do {                                                                               \
+    if (h->tune_idx16) GL_SPMV3(DOTS, UNR, NT, 1); else GL_SPMV3(DOTS, UNR, NT, 0); \
+  } while (0)
   const int unr = h->tune_spmv_unroll;
   if (h->tune_spmv_nt) {
     if (r) { if (unr == 8) GL_SPMV(1, 8, 1); else GL_SPMV(1, 4, 1); }
@@ -591,6 +649,7 @@ void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* s
     else   { if (unr == 8) GL_SPMV(0, 8, 0); else GL_SPMV(0, 4, 0); }
   }
 #undef GL_SPMV
+#undef GL_SPMV3
   GL_HIP(hipGetLastError());
 }
 

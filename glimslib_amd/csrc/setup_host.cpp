@@ -248,6 +248,44 @@ void build_host_pattern(HostPattern& hp, int dim, int64_t n_nodes, int64_t n_own
     }
   }
   for (int32_t s = 0; s < n_slices; ++s) (is_boundary[s] ? hp.boundary_slices : hp.interior_slices).push_back(s);
+  // 16-bit (window, offset) column codes: greedy cover of each slice's sorted distinct columns by windows of
+  // 2^GL_WIN_BITS columns (optimal for fixed-length intervals); see glims_internal.h
+  hp.cols16.assign(hp.cols.size(), 0);
+  hp.win_base.assign((size_t)n_slices * GL_N_WIN, 0);
+  hp.win_ok.assign(n_slices, 0);
+  int64_t n_comp = 0;
+  int win_limit = GL_N_WIN;   // GLIMS_WIN_LIMIT < 32 forces slices onto the 32-bit fallback (tests)
+  if (const char* e = getenv("GLIMS_WIN_LIMIT")) win_limit = std::max(0, std::min(GL_N_WIN, atoi(e)));
+#pragma omp parallel reduction(+ : n_comp)
+  {
+    std::vector<int32_t> d;
+#pragma omp for schedule(dynamic, 64)
+    for (int32_t s = 0; s < n_slices; ++s) {
+      const int64_t b = hp.slice_ptr[s], e = hp.slice_ptr[s + 1];
+      d.assign(hp.cols.begin() + b, hp.cols.begin() + e);
+      std::sort(d.begin(), d.end());
+      d.erase(std::unique(d.begin(), d.end()), d.end());
+      int32_t* wb = hp.win_base.data() + (size_t)s * GL_N_WIN;
+      int nw = 0;
+      size_t i = 0;
+      while (i < d.size() && nw <= GL_N_WIN) {
+        const int32_t start = d[i];
+        if (nw < GL_N_WIN) wb[nw] = start;
+        ++nw;
+        while (i < d.size() && (int64_t)d[i] - start < (int64_t(1) << GL_WIN_BITS)) ++i;
+      }
+      if (nw > win_limit) continue;
+      for (int w = nw; w < GL_N_WIN; ++w) wb[w] = wb[nw - 1];
+      for (int64_t q = b; q < e; ++q) {
+        const int32_t cj = hp.cols[q];
+        const int w = (int)(std::upper_bound(wb, wb + nw, cj) - wb) - 1;
+        hp.cols16[q] = (uint16_t)((w << GL_WIN_BITS) | (cj - wb[w]));
+      }
+      hp.win_ok[s] = 1;
+      ++n_comp;
+    }
+  }
+  hp.n_compressed = n_comp;
   // length classes for the assembly sweep (its LDS footprint is 2 * cap * 64 * 8 B per wave)
   hp.bucket_cap = {16, 24, 32, 48, 64, 96, 128, 255};
   hp.bucket_slices.assign(hp.bucket_cap.size(), {});

@@ -83,6 +83,7 @@ typedef struct glims_stats {
   int64_t nnz;              /* structural nonzeros of the scalar operator (unpadded) */
   int64_t nnz_padded;       /* stored SELL-64 entries */
   int64_t n_corners;        /* (row, cell) incidences */
+  int64_t nnz_idx16;        /* stored entries whose column is streamed as a 16-bit (window, offset) code */
 } glims_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------------------- */

@@ -38,7 +38,7 @@ def test_struct_layouts_match_header_field_order():
     assert fields == [f for f, _ in _backend.Options._fields_]
     body = re.search(r"typedef struct glims_stats \{(.*?)\} glims_stats;", src, re.S).group(1)
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
-    fields = re.findall(r"(?:double|int64_t)\s+([a-z_]+);", body)
+    fields = re.findall(r"(?:double|int64_t)\s+([a-z_0-9]+);", body)
     assert fields == [f for f, _ in _backend.Stats._fields_]
     opt = _backend.Options()
     assert lib_default(opt) == 0 and opt.newton_rtol == 1e-10 and opt.check_every == 8

@@ -418,3 +418,38 @@ def test_baseline_configs_complete_runs_match_the_c_oracle(backend, name):
     assert h.stats()['steps'] == w.n_steps
     h.close()
     co.close()
+
+
+def test_column_index_streams_are_bitwise_equivalent(backend, monkeypatch):
+    """
+    The SpMV and the assembly sweep read the columns either as int32 or as 16-bit (window, offset) codes; slices that
+    need more windows than the table holds use int32.  All three situations (all codes / none / mixed, forced through
+    GLIMS_WIN_LIMIT) must produce the same bits, on a mesh with several thousand slices and on a tiny one.
+    """
+    rng = np.random.default_rng(5)
+    for mesh in (BoxMesh((0, 0, 0), (1.0, 1.3, 0.8), 30, 28, 26), _case(3, ragged=True)[0], _case(2)[0]):
+        lab = (1 + (mesh.cell_midpoints()[:, 0] > mesh.points[:, 0].mean())).astype(np.int32)
+        n = mesh.num_vertices()
+        x = rng.standard_normal(n)
+        c0 = np.exp(-4 * ((mesh.points - mesh.points.mean(0)) ** 2).sum(1))
+        outs = []
+        for env in (dict(GLIMS_IDX16="1"), dict(GLIMS_IDX16="0"), dict(GLIMS_IDX16="1", GLIMS_WIN_LIMIT="2"),
+                    dict(GLIMS_IDX16="1", GLIMS_WIN_LIMIT="0")):
+            monkeypatch.delenv("GLIMS_WIN_LIMIT", raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            h = _handle(backend, mesh, lab, 1.0, mechanics=False)
+            st = h.stats()
+            y = h.apply(1, x)[0]
+            r = h.rd_residual(c0 + 0.1 * x, c0)
+            h.set_state(c0)
+            assert h.step(3) == 0
+            outs.append((st['nnz_idx16'], st['nnz_padded'], y, r, h.get_state(want_u=False)[0]))
+            h.close()
+        assert outs[0][0] == outs[0][1]                       # default: every slice of these meshes is coded
+        assert outs[1][0] == 0 and outs[3][0] == 0
+        if n > 10000:
+            assert 0 < outs[2][0] < outs[2][1]                # genuinely mixed
+        for o in outs[1:]:
+            for a, b in zip(o[2:], outs[0][2:]):
+                assert np.array_equal(a, b)

@@ -15,9 +15,18 @@ h.setup(False)
 st = h.stats()
 b_alg = workloads.b_spmv_bytes(st['nnz'], st['n_rows'])
 x = np.random.default_rng(0).standard_normal(h.n_nodes)
+study = sys.argv[2] if len(sys.argv) > 2 else 'remap'
 variants = [("plain", dict(GLIMS_XCD_REMAP="0")), ("eighths", dict(GLIMS_XCD_REMAP="1")),
             ("chunks of 4", dict(GLIMS_XCD_REMAP="4")), ("chunks of 16", dict(GLIMS_XCD_REMAP="16")),
             ("chunks of 64", dict(GLIMS_XCD_REMAP="64")), ("chunks of 256", dict(GLIMS_XCD_REMAP="256"))]
+if study == 'idx16':
+    variants = [("int32 columns", dict(GLIMS_IDX16="0")), ("16-bit window codes", dict(GLIMS_IDX16="1"))]
+    y0 = None
+    for name, env in variants:           # both index streams must give bitwise the same product
+        os.environ.update(env)
+        y, _ = h.apply(0, x, reps=1)
+        assert y0 is None or np.array_equal(y, y0), "index streams disagree"
+        y0 = y
 res = {n: [] for n, _ in variants}
 for rnd in range(6):
     for name, env in variants:
