@@ -20,6 +20,8 @@ void read_tuning(glims_ctx* h) {
   if (const char* e = getenv("GLIMS_RD_REMAP")) h->tune_rd_remap = atoi(e);
   if (const char* e = getenv("GLIMS_RD_UNROLL")) h->tune_rd_unroll = atoi(e);
   if (const char* e = getenv("GLIMS_IDX16")) h->tune_idx16 = atoi(e);
+  if (const char* e = getenv("GLIMS_DEFER")) h->tune_defer = atoi(e);
+  if (const char* e = getenv("GLIMS_DEFER_EXTRA")) h->tune_defer_extra = std::max(1, atoi(e));
 }
 
 std::mutex g_err_mu;
@@ -138,7 +140,9 @@ int glims_create(glims_ctx** out, int dim, int64_t n_nodes, int64_t n_own, int64
     GL_HIP(hipEventCreate(&h->ev_b));
     GL_HIP(hipEventCreateWithFlags(&h->ev_pack, hipEventDisableTiming));
     GL_HIP(hipEventCreateWithFlags(&h->ev_halo, hipEventDisableTiming));
-    GL_HIP(hipHostMalloc((void**)&h->h_pinned, 32 * sizeof(double)));
+    GL_HIP(hipHostMalloc((void**)&h->h_pinned, 32 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(h->h_pinned, 0, 32 * sizeof(double));
+    GL_HIP(hipHostGetDevicePointer((void**)&h->mail_dev, h->h_pinned, 0));
 
     for (int64_t e = 0; e < n_cells; ++e)
       GL_REQUIRE(cell_label[e] >= 0 && cell_label[e] < GL_MAX_LABELS, "cell label outside [0, 256)");
@@ -252,6 +256,7 @@ int glims_destroy(glims_ctx* h) {
   for (auto* d : h->snapshots) delete d;
   h->snapshots.clear();
   gl_comm_destroy(h);
+  if (getenv("GLIMS_VERBOSE")) fprintf(stderr, "glims: deferred linear solves that ran out of iterations: %lld\n", (long long)h->stats_defer_miss);
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
   if (h->ev_a) (void)hipEventDestroy(h->ev_a);
   if (h->ev_b) (void)hipEventDestroy(h->ev_b);

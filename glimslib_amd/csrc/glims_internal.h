@@ -151,7 +151,8 @@ struct glims_ctx {
   glims_options opt;
   glims_stats stats;
   // tuning knobs (env GLIMS_SPMV_UNROLL = 4|8, GLIMS_XCD_REMAP = 0 plain | 1 eighths | G chunk, GLIMS_SPMV_NT = 0|1), read at glims_create and by glims_apply
-  int tune_spmv_unroll = 4, tune_xcd_remap = 64, tune_rd_remap = 64, tune_spmv_nt = 1, tune_rd_nt = 0, tune_rd_unroll = 24, tune_idx16 = 1;
+  int tune_spmv_unroll = 4, tune_xcd_remap = 64, tune_rd_remap = 64, tune_spmv_nt = 1, tune_rd_nt = 0, tune_rd_unroll = 24, tune_idx16 = 1, tune_defer = 1, tune_defer_extra = 2;
+  int64_t stats_defer_miss = 0;
 
   // scalar operator planes (SELL-64 layout) and block planes
   dvec<double> vM, vS, vA, vKel, vG;
@@ -174,7 +175,9 @@ struct glims_ctx {
   dvec<double> red;                        // [4] reduced sums
   dvec<double> scal;                       // [SC_COUNT] recurrence scalars
   dvec<int> done;                          // [1] 0 running, 1 converged, 2 non-finite, 3 breakdown
-  double* h_pinned = nullptr;              // pinned host mirror (16 doubles)
+  double* h_pinned = nullptr;              // pinned, device-mapped mailbox [seq | red[4] | info[2] | done] (32 doubles)
+  double* mail_dev = nullptr;              // its device address
+  unsigned long long mail_seq = 0;
 
   // multi-GPU
   int rank = 0, world = 1;

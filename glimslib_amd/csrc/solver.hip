@@ -13,6 +13,7 @@
 // sequence; the decision words are computed from all-reduced values and are therefore identical on all ranks.
 #include "glims_internal.h"
 
+#include <atomic>
 #include <cmath>
 #include <cstring>
 
@@ -41,12 +42,16 @@ __device__ __forceinline__ void block_sum2(double a, double b, double* __restric
   if (threadIdx.x < 2) pv[(size_t)blockIdx.x * 2 + threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
 }
 
-// u = Dinv r, p = s = 0, and the first (r.u, r.r) partials
+// u = Dinv r, p = s = 0, and the first (r.u, r.r) partials; also clears the recurrence scalars and the decision word
+// of the previous solve (two memset nodes on the stream cost ~20 us of idle device per solve)
 template <int BS>
 __global__ __launch_bounds__(256) void k_cg_init(int64_t n_own, const double* __restrict__ r,
                                                   const double* __restrict__ dinv, double* __restrict__ u,
                                                   double* __restrict__ p, double* __restrict__ s,
-                                                  double* __restrict__ pv) {
+                                                  double* __restrict__ pv, double* __restrict__ scal,
+                                                  int* __restrict__ done) {
+  if (blockIdx.x == 0 && threadIdx.x < 2 * SC_COUNT + 2) scal[threadIdx.x] = 0.0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *done = 0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   double pg = 0.0, pr = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_own; i += stride) {
@@ -229,10 +234,23 @@ __global__ __launch_bounds__(1024) void k_reduce(int n, int nq, const double* __
   double v[3] = {0.0, 0.0, 0.0};
   const int total = n * nq;   // partials are [n][nq]: walk the flat array with a stride that is a multiple of nq
   const int stride = 1024 * nq;
-  for (int i = threadIdx.x * nq; i < total; i += stride)
+  {
+    // four independent strided chains per thread (the loop is latency-bound: 12 us for 16 k pairs with one chain)
+    double a[4][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+    int i = threadIdx.x * nq;
+    for (; i + 3 * stride < total; i += 4 * stride)
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
-      if (q < nq) v[q] += partials[i + q];
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          if (q < nq) a[c][q] += partials[i + c * stride + q];
+    for (; i < total; i += stride)
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        if (q < nq) a[0][q] += partials[i + q];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) v[q] = (a[0][q] + a[1][q]) + (a[2][q] + a[3][q]);
+  }
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
 #pragma unroll
@@ -273,6 +291,23 @@ __global__ __launch_bounds__(1024) void k_reduce_cg(int ns, const double* __rest
     for (int w = 0; w < 16; ++w) t += sm[w][threadIdx.x];
     red[threadIdx.x] = t;
   }
+}
+
+// Hands the host everything it decides on in ONE store sequence into pinned host memory:
+//   mail = [seq | red[0..3] | Krylov info {iterations, rr} | done], seq written last (system-scope release).
+// The host spins on seq instead of synchronising the stream and copying three scalars back (~25-30 us of idle
+// device per decision point, measured on the 1 M-row configuration).
+__global__ void k_publish(int n, const double* __restrict__ red, const double* __restrict__ info,
+                          const int* __restrict__ done, double* mail, unsigned long long seq) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int i = 0; i < n && i < 4; ++i) mail[1 + i] = red[i];
+  if (info) {
+    mail[5] = info[0];
+    mail[6] = info[1];
+  }
+  mail[7] = done ? (double)*done : 0.0;
+  __threadfence_system();
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(mail), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ void k_pack(int64_t n, int bs, const int32_t* __restrict__ idx, const double* __restrict__ vec,
@@ -456,19 +491,46 @@ static void reduce_partials(glims_ctx* h, int n, int nq, const int* done) {
   GL_HIP(hipGetLastError());
 }
 
-static void poll(glims_ctx* h, int* done, double* info2) {
-  // one small D2H of the decision word + {iterations, last rr}, then the only host sync of a batch
-  GL_HIP(hipMemcpyAsync(h->h_pinned, h->scal.p + 2 * SC_COUNT, 2 * sizeof(double), hipMemcpyDeviceToHost, h->st));
-  GL_HIP(hipMemcpyAsync(h->h_pinned + 2, h->done.p, sizeof(int), hipMemcpyDeviceToHost, h->st));
-  GL_HIP(hipStreamSynchronize(h->st));
-  std::memcpy(info2, h->h_pinned, 2 * sizeof(double));
-  std::memcpy(done, h->h_pinned + 2, sizeof(int));
+// Publishes red[0..n) (+ the Krylov info and decision word) to the pinned mailbox and waits for it.
+struct Mail {
+  double red[4];
+  double info[2];
+  int done;
+};
+static Mail fetch(glims_ctx* h, int n_red, bool with_krylov) {
+  const unsigned long long seq = ++h->mail_seq;
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, h->st, n_red, h->red.p,
+                     with_krylov ? h->scal.p + 2 * SC_COUNT : (const double*)nullptr,
+                     with_krylov ? h->done.p : (const int*)nullptr, h->mail_dev, seq);
+  GL_HIP(hipGetLastError());
+  volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(h->h_pinned);
+  for (long spins = 0; *flag != seq; ++spins) {
+    if ((spins & 0xfff) == 0xfff) {
+      const hipError_t q = hipStreamQuery(h->st);
+      if (q == hipSuccess) {
+        if (*flag == seq) break;
+        throw glims_error(GLIMS_E_HIP, "stream drained without publishing the decision word");
+      }
+      if (q != hipErrorNotReady) throw glims_error(GLIMS_E_HIP, std::string("HIP error while waiting: ") + hipGetErrorString(q));
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  Mail m;
+  for (int i = 0; i < 4; ++i) m.red[i] = h->h_pinned[1 + i];
+  m.info[0] = h->h_pinned[5];
+  m.info[1] = h->h_pinned[6];
+  m.done = (int)h->h_pinned[7];
+  return m;
 }
-
+static void poll(glims_ctx* h, int* done, double* info2) {
+  const Mail m = fetch(h, 0, true);
+  info2[0] = m.info[0];
+  info2[1] = m.info[1];
+  *done = m.done;
+}
 static void read_red(glims_ctx* h, int n, double* out) {
-  GL_HIP(hipMemcpyAsync(h->h_pinned, h->red.p, n * sizeof(double), hipMemcpyDeviceToHost, h->st));
-  GL_HIP(hipStreamSynchronize(h->st));
-  for (int i = 0; i < n; ++i) out[i] = h->h_pinned[i];
+  const Mail m = fetch(h, n, false);
+  for (int i = 0; i < n; ++i) out[i] = m.red[i];
 }
 static double read_red0(glims_ctx* h) {
   double v;
@@ -518,8 +580,12 @@ static void apply_with_halo(glims_ctx* h, const CgVecs& v) {
 
 // `hint`: expected iteration count (0 = unknown).  The first batch is hint + 1 launches (the extra one only detects
 // convergence), later batches are short; every launch after the device-side `done` is a ~2 us no-op.
+// `defer` (needs a hint): enqueue hint + 2 iterations and return WITHOUT asking the device how it went
+// (*its_out = -1); the caller reads {iterations, rr, done} together with its next decision (fetch(.., true)).
+// Only valid where an unconverged linear solve is harmless, i.e. inside the inexact Newton iteration, whose own
+// residual test decides.
 static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, int hint, int64_t* its_out,
-                    double* res_out) {
+                    double* res_out, bool defer = false) {
   const DevPattern& p = h->pat;
   const bool split = h->world > 1 && h->n_peers > 0;
   const int nblocks = split ? (p.n_interior > 0 ? gl_spmv_grid(p.n_interior) : 0) +
@@ -527,8 +593,6 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
                             : gl_spmv_grid(p.n_slices);
   const int64_t n = h->n_own;
   // scal = [ping | pong | info{its, rr}]
-  GL_HIP(hipMemsetAsync(h->scal.p, 0, (2 * SC_COUNT + 2) * sizeof(double), h->st));
-  GL_HIP(hipMemsetAsync(h->done.p, 0, sizeof(int), h->st));
   const unsigned g = grid_for(n);
   const double tol2 = tol_abs * tol_abs;
 #define GL_VEC(K, ...)                                                                  \
@@ -538,7 +602,7 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
     else hipLaunchKernelGGL(K<3>, dim3(g), dim3(256), 0, h->st, __VA_ARGS__);           \
     GL_HIP(hipGetLastError());                                                          \
   } while (0)
-  GL_VEC(k_cg_init, n, v.r, v.dinv, v.u, v.p, v.s, h->partials_v.p);
+  GL_VEC(k_cg_init, n, v.r, v.dinv, v.u, v.p, v.s, h->partials_v.p, h->scal.p, h->done.p);
   int done = 0;
   double info[2] = {0.0, 0.0};
   const int batch = h->opt.check_every > 0 ? h->opt.check_every : 8;
@@ -546,7 +610,7 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
   double* info_dev = h->scal.p + 2 * SC_COUNT;
   while (enq < maxit + 1) {
     int want = batch;
-    if (hint > 0) want = enq == 0 ? hint + 1 : std::max(2, std::min(batch, hint / 4 + 1));
+    if (hint > 0) want = enq == 0 ? hint + (defer ? h->tune_defer_extra : 1) : std::max(2, std::min(batch, hint / 4 + 1));
     const int nb = std::min(want, maxit + 1 - enq);
     for (int j = 0; j < nb; ++j) {
       const double* prev = h->scal.p + ((enq + j) & 1) * SC_COUNT;
@@ -570,6 +634,11 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
              h->partials_v.p);
     }
     enq += nb;
+    if (defer && hint > 0) {
+      *its_out = -1;
+      *res_out = 0.0;
+      return GLIMS_OK;
+    }
     poll(h, &done, info);
     if (done) break;
   }
@@ -587,14 +656,15 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
 // One sweep = Jacobian + right-hand side(s) + their norms.  With b2 the sweep also produces the first residual of
 // the NEXT time step (same operator part 1/2 (A+S) c, different b), so that the convergence check of step n and
 // the first assembly of step n+1 are one pass over the corner lists.
-static void rd_sweep(glims_ctx* h, const double* b2, double* norms /*[2]*/) {
+// `krylov`: also receives {iterations, rr, done} of a deferred linear solve enqueued before the sweep.
+static void rd_sweep(glims_ctx* h, const double* b2, double* norms /*[2]*/, Mail* krylov = nullptr) {
   gl_rd_assemble(h, h->c.p, h->b.p, b2, h->cg_r.p, h->cg_r2.p, h->partials.p);
   reduce_partials(h, gl_rd_grid(h), 2, nullptr);
   allreduce_sum(h, h->red.p, 2);
-  double r2[2];
-  read_red(h, 2, r2);
-  norms[0] = std::sqrt(r2[0]);
-  norms[1] = std::sqrt(r2[1]);
+  const Mail m = fetch(h, 2, krylov != nullptr);
+  norms[0] = std::sqrt(m.red[0]);
+  norms[1] = std::sqrt(m.red[1]);
+  if (krylov) *krylov = m;
   h->stats.rd_assemblies++;
 }
 
@@ -659,11 +729,14 @@ int gl_step(glims_ctx* h, int n_steps) {
       int64_t its = 0;
       double res = 0.0;
       const int slot = std::min(it, 7);
-      const int cs = cg_solve(h, v, tol_lin, o.cg_maxit, h->cg_hint[slot], &its, &res);
-      h->cg_hint[slot] = (int)its;
-      h->stats.cg_its += its;
+      const int cs = cg_solve(h, v, tol_lin, o.cg_maxit, h->cg_hint[slot], &its, &res, /*defer=*/h->tune_defer != 0);
+      const bool deferred = its < 0;
+      if (!deferred) {
+        h->cg_hint[slot] = (int)its;
+        h->stats.cg_its += its;
+        h->stats.last_cg_res = res;
+      }
       h->stats.newton_its++;
-      h->stats.last_cg_res = res;
       gl_halo_exchange(h, h->c.p, 1);   // ghosts of c current again
       if (cs != GLIMS_OK) {
         status = cs;
@@ -676,7 +749,21 @@ int gl_step(glims_ctx* h, int n_steps) {
       if (speculate)
         gl_launch_spmv(h, h->st, p.n_slices, nullptr, h->vM.p, h->c.p, h->b2.p, nullptr, load, nullptr, nullptr, 0,
                        nullptr);
-      rd_sweep(h, speculate ? h->b2.p : nullptr, norms);
+      Mail km;
+      rd_sweep(h, speculate ? h->b2.p : nullptr, norms, deferred ? &km : nullptr);
+      if (deferred) {
+        // the linear solve's outcome arrives with the sweep: a solve that used up its hint + 2 iterations simply
+        // was a slightly weaker Newton step (the residual below decides); give it more room next time
+        h->cg_hint[slot] = km.done == 1 ? (int)km.info[0] : (int)km.info[0] + 2;
+        if (km.done != 1) h->stats_defer_miss++;
+        h->stats.cg_its += (int64_t)km.info[0];
+        h->stats.last_cg_res = std::sqrt(km.info[1]);
+        if (km.done == 2) {
+          status = GLIMS_NAN;
+          break;
+        }
+        if (km.done == 3) h->cg_hint[slot] = 0;   // breakdown: next time take the polled path
+      }
       nr = norms[0];
       if (speculate && std::isfinite(nr) && nr <= target) {
         std::swap(h->b.p, h->b2.p);
