@@ -122,9 +122,17 @@ def main():
     if world > 1:
         part = partition_mesh(w.mesh.points, w.mesh.cells, world, rank)
         h = Handle(part.points, part.cells, w.cell_label[part.cell_ids], n_own=part.n_own, device=local_rank)
-        from glimslib_amd.parallel import broadcast_unique_id
-        h.comm_init(rank, world, broadcast_unique_id(dist, rank))
+        from glimslib_amd.parallel import broadcast_unique_id, HostStagedTransport
+        if forced is not None:      # rehearsal: RCCL refuses several ranks per device, stage the halos through gloo
+            transport = HostStagedTransport(dist)
+            h.set_transport(rank, world, transport.halo_cb, transport.allreduce_cb)
+        else:
+            h.comm_init(rank, world, broadcast_unique_id(dist, rank))
         h.set_halo(part.peer_rank, part.send_ptr, part.send_idx, part.recv_count)
+        from glimslib_amd.parallel import setup_node_mailbox
+        mailbox = setup_node_mailbox(h, dist, rank)
+        if rank == 0:
+            log("[bench] scalar all-reduce: %s" % ("node mailbox (shared host memory)" if mailbox else "RCCL"))
         c0 = w.c0[part.global_ids]
     else:
         part = None

@@ -80,6 +80,8 @@ SIGNATURES = {
     "glims_comm_unique_id": (C.c_int, [C.c_char_p]),
     "glims_comm_init": (C.c_int, [_h, C.c_int, C.c_int, C.c_char_p]),
     "glims_comm_selftest": (C.c_int, [_h]),
+    "glims_comm_mailbox": (C.c_int, [_h, C.c_char_p]),
+    "glims_comm_mailbox_selftest": (C.c_int, [_h]),
     "glims_set_halo": (C.c_int, [_h, C.c_int, _i32p, _i64p, _i32p, _i64p]),
     "glims_set_transport": (C.c_int, [_h, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
@@ -284,6 +286,13 @@ class Handle:
 
     def comm_selftest(self):
         self._check(self.lib.glims_comm_selftest(self._h))
+
+    def comm_mailbox(self, shm_name):
+        """Node-local all-reduce through the POSIX shm object `shm_name` ('/...'); None switches it off."""
+        self._check(self.lib.glims_comm_mailbox(self._h, None if shm_name is None else shm_name.encode()))
+
+    def comm_mailbox_selftest(self):
+        self._check(self.lib.glims_comm_mailbox_selftest(self._h))
 
     def set_transport(self, rank, world, halo_cb, allreduce_cb):
         """halo_cb / allreduce_cb: HALO_FN / ALLREDUCE_FN instances (kept alive by this handle)."""

@@ -1,10 +1,17 @@
 // extern "C" surface of libglimship.so (see include/glims_hip.h for the contract of every entry point).
 #include "glims_internal.h"
 
+#include <cerrno>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+static void mailbox_close(glims_ctx* h);
 
 void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* slice_list, const double* vals,
                     const double* x, double* y, const uint8_t* fixed, const double* addv, const double* r,
@@ -257,6 +264,7 @@ int glims_destroy(glims_ctx* h) {
   h->snapshots.clear();
   gl_comm_destroy(h);
   if (getenv("GLIMS_VERBOSE")) fprintf(stderr, "glims: deferred linear solves that ran out of iterations: %lld\n", (long long)h->stats_defer_miss);
+  mailbox_close(h);
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
   if (h->ev_a) (void)hipEventDestroy(h->ev_a);
   if (h->ev_b) (void)hipEventDestroy(h->ev_b);
@@ -616,6 +624,61 @@ int glims_comm_init(glims_ctx* h, int rank, int world, const char id[GLIMS_UNIQU
     }
     return GLIMS_OK;
   });
+}
+
+static void mailbox_close(glims_ctx* h) {
+  if (h->nm_host) {
+    (void)hipHostUnregister(h->nm_host);
+    (void)munmap(h->nm_host, h->nm_bytes);
+  }
+  h->nm_host = nullptr;
+  h->nm_bytes = 0;
+  h->nm = NodeMail();
+}
+
+int glims_comm_mailbox(glims_ctx* h, const char* shm_name) {
+  return guarded(h, [&]() {
+    GL_HIP(hipStreamSynchronize(h->st));
+    mailbox_close(h);
+    if (!shm_name || h->world <= 1) return GLIMS_OK;
+    GL_REQUIRE(shm_name[0] == '/', "shm_name must start with '/'");
+    GL_REQUIRE(h->world <= GL_WAVE, "node mailbox supports at most 64 ranks");
+    const size_t bytes = ((size_t)2 * h->world * 64 + 4095) / 4096 * 4096;
+    const int fd = shm_open(shm_name, O_CREAT | O_RDWR, 0600);
+    if (fd < 0) throw glims_error(GLIMS_E_USAGE, std::string("shm_open failed: ") + std::strerror(errno));
+    // every rank sizes the object to the same length: the first one zero-fills it, the others change nothing
+    if (ftruncate(fd, (off_t)bytes) != 0) {
+      const std::string m = std::string("ftruncate failed: ") + std::strerror(errno);
+      close(fd);
+      throw glims_error(GLIMS_E_USAGE, m);
+    }
+    void* ptr = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (ptr == MAP_FAILED) throw glims_error(GLIMS_E_USAGE, std::string("mmap failed: ") + std::strerror(errno));
+    h->nm_host = ptr;
+    h->nm_bytes = bytes;
+    const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+    if (e != hipSuccess) {
+      (void)munmap(ptr, bytes);
+      h->nm_host = nullptr;
+      throw glims_error(GLIMS_E_HIP, std::string("hipHostRegister of the node mailbox failed: ") + hipGetErrorString(e));
+    }
+    void* dev = nullptr;
+    GL_HIP(hipHostGetDevicePointer(&dev, ptr, 0));
+    h->nm_seq.alloc_zero(1, h->st);
+    h->nm_err.alloc_zero(1, h->st);
+    GL_HIP(hipStreamSynchronize(h->st));
+    h->nm.slots = static_cast<double*>(dev);
+    h->nm.seq = h->nm_seq.p;
+    h->nm.err = h->nm_err.p;
+    h->nm.rank = h->rank;
+    h->nm.world = h->world;
+    return GLIMS_OK;
+  });
+}
+
+int glims_comm_mailbox_selftest(glims_ctx* h) {
+  return guarded(h, [&]() { return gl_mailbox_selftest(h); });
 }
 
 int glims_comm_selftest(glims_ctx* h) {

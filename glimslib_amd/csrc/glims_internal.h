@@ -129,6 +129,18 @@ struct DevPattern {
   int64_t total_entries = 0, total_corners = 0;
 };
 
+// Node-local all-reduce through a mailbox in host shared memory that every rank's GPU maps (fine-grained): slot
+// [parity][rank] = {seq, v[0..3]} (64 B).  Fused into the final block of the reduction kernels: no extra launch and
+// a few microseconds of PCIe latency instead of an RCCL kernel per Krylov iteration.  `seq` lives on the device and
+// only advances when the kernel really runs (kernels skipped by the `done` word must not consume a number).
+struct NodeMail {
+  double* slots = nullptr;             // device address of the mapping; nullptr = not in use
+  unsigned long long* seq = nullptr;   // device counter
+  int* err = nullptr;                  // device flag: a peer did not arrive in time
+  int rank = 0, world = 1;
+  long long timeout_ticks = 60ll * 100000000ll;   // wall_clock64 runs at 100 MHz
+};
+
 // scalar slots of the Krylov recurrence (device array `scal`)
 enum { SC_ALPHA = 0, SC_BETA, SC_GAMMA, SC_IT, SC_COUNT = 8 };
 
@@ -188,6 +200,11 @@ struct glims_ctx {
   dvec<int32_t> send_idx;
   dvec<double> sendbuf;
   int64_t n_send = 0;
+  NodeMail nm;                              // active when nm.slots != nullptr
+  void* nm_host = nullptr;                  // the mmap'ed segment
+  size_t nm_bytes = 0;
+  dvec<unsigned long long> nm_seq;
+  dvec<int> nm_err;
   glims_halo_fn tr_halo = nullptr;          // host-provided transport (tests / MPI hosts); RCCL when null
   glims_allreduce_fn tr_allreduce = nullptr;
   void* tr_user = nullptr;
@@ -212,4 +229,5 @@ int gl_solve_mechanics(glims_ctx* h, const double* c_dev = nullptr);   // c_dev:
 void gl_halo_exchange(glims_ctx* h, double* vec, int bs);   // blocking w.r.t. h->st (no overlap)
 void gl_comm_destroy(glims_ctx* h);
 int gl_comm_selftest(glims_ctx* h);
+int gl_mailbox_selftest(glims_ctx* h);
 int gl_project(glims_ctx* h, double* rhs_dev /*[n_nodes], overwritten*/, double* x_dev /*[n_nodes]*/, double rtol);

@@ -232,9 +232,19 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
           acc[(k + j) * GL_WAVE + lane] = 0.0;
         }
       }
-      for (; k < len; ++k) {
-        cn[k * GL_WAVE + lane] = c[load_col(k)];
-        acc[k * GL_WAVE + lane] = 0.0;
+      if (k < len) {   // ragged tail as one more batch of 8 (slot index clamped), not as a serial loop
+        int32_t ci8[8];
+        double x8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ci8[j] = load_col(min(k + j, len - 1));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x8[j] = c[ci8[j]];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (k + j < len) {
+            cn[(k + j) * GL_WAVE + lane] = x8[j];
+            acc[(k + j) * GL_WAVE + lane] = 0.0;
+          }
       }
     };
     if (CIDX && win_ok[s]) {   // wave-uniform: 16-bit (window, offset) codes, see spmv_row
@@ -297,12 +307,22 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
           if (k + j == dk) d = Av;
         }
       }
-      for (; k < len; ++k) {
-        const double Sv = sv[(int64_t)k * GL_WAVE];
-        const double Av = Sv + two_dt * acc[k * GL_WAVE + lane];
-        av[(int64_t)k * GL_WAVE] = Av;
-        r += 0.5 * (Av + Sv) * cn[k * GL_WAVE + lane];
-        if (k == dk) d = Av;
+      if (k < len) {   // ragged tail: one more batch, loads issued together
+        double S8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int kk = min(k + j, len - 1);
+          S8[j] = NT ? __builtin_nontemporal_load(sv + (int64_t)kk * GL_WAVE) : sv[(int64_t)kk * GL_WAVE];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (k + j < len) {
+            const double Av = S8[j] + two_dt * acc[(k + j) * GL_WAVE + lane];
+            if (NT) __builtin_nontemporal_store(Av, av + (int64_t)(k + j) * GL_WAVE);
+            else av[(int64_t)(k + j) * GL_WAVE] = Av;
+            r += 0.5 * (Av + S8[j]) * cn[(k + j) * GL_WAVE + lane];
+            if (k + j == dk) d = Av;
+          }
       }
     }
     if (row < n_own) {
@@ -366,14 +386,33 @@ __device__ __forceinline__ double spmv_row(const int32_t* __restrict__ cc, const
 #pragma unroll
     for (int j = 0; j < UNR; ++j) acc += vu[j] * xu[j];
   }
-  for (; k < len; ++k) {
-    int32_t cj;
-    if (COMP)
-      cj = decode_col(NT ? __builtin_nontemporal_load(c16 + (int64_t)k * GL_WAVE) : c16[(int64_t)k * GL_WAVE], wb);
-    else
-      cj = NT ? __builtin_nontemporal_load(cc + (int64_t)k * GL_WAVE) : cc[(int64_t)k * GL_WAVE];
-    const double vj = NT ? __builtin_nontemporal_load(v + (int64_t)k * GL_WAVE) : v[(int64_t)k * GL_WAVE];
-    acc += vj * x[cj];
+  if (k < len) {
+    // ragged tail (len is rarely a multiple of UNR: 15 on the structured 3-D meshes) as ONE more batch with the slot
+    // index clamped and the surplus products zeroed, so that its loads are in flight together like all the others
+    int32_t cu[UNR];
+    double vu[UNR], xu[UNR];
+#pragma unroll
+    for (int j = 0; j < UNR; ++j) {
+      const int kk = min(k + j, len - 1);
+      if (COMP)
+        cu[j] = (int32_t)(NT ? __builtin_nontemporal_load(c16 + (int64_t)kk * GL_WAVE) : c16[(int64_t)kk * GL_WAVE]);
+      else
+        cu[j] = NT ? __builtin_nontemporal_load(cc + (int64_t)kk * GL_WAVE) : cc[(int64_t)kk * GL_WAVE];
+    }
+#pragma unroll
+    for (int j = 0; j < UNR; ++j) {
+      const int kk = min(k + j, len - 1);
+      const double vj = NT ? __builtin_nontemporal_load(v + (int64_t)kk * GL_WAVE) : v[(int64_t)kk * GL_WAVE];
+      vu[j] = (k + j < len) ? vj : 0.0;
+    }
+    if (COMP) {
+#pragma unroll
+      for (int j = 0; j < UNR; ++j) cu[j] = decode_col((uint32_t)cu[j], wb);
+    }
+#pragma unroll
+    for (int j = 0; j < UNR; ++j) xu[j] = x[cu[j]];
+#pragma unroll
+    for (int j = 0; j < UNR; ++j) acc += vu[j] * xu[j];
   }
   return acc;
 }

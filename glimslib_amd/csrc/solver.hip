@@ -205,6 +205,50 @@ __global__ __launch_bounds__(256) void k_cg_update(int64_t n_own, const double* 
   block_sum2(pg, pr, pv);
 }
 
+// Node-local all-reduce of red[0..nq) (see NodeMail): called by every thread of the (single) final reduction block.
+// Sums in rank order on every rank -> the same bits everywhere, hence identical decisions.
+__device__ __forceinline__ void node_allreduce(double* __restrict__ red, int nq, const NodeMail nm) {
+  __syncthreads();   // red[] written by threads < nq
+  if (threadIdx.x >= GL_WAVE) return;
+  const int lane = threadIdx.x;
+  unsigned long long seq = 0;
+  if (lane == 0) {
+    seq = *nm.seq + 1ull;
+    *nm.seq = seq;
+  }
+  seq = __shfl(seq, 0, GL_WAVE);
+  double* bank = nm.slots + (size_t)(seq & 1ull) * nm.world * 8;
+  if (lane == 0) {
+    double* mine = bank + (size_t)nm.rank * 8;
+    for (int q = 0; q < nq; ++q) __hip_atomic_store(mine + 1 + q, red[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(mine), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  bool ok = true;
+  if (lane < nm.world) {
+    const unsigned long long* f = reinterpret_cast<const unsigned long long*>(bank + (size_t)lane * 8);
+    const long long t0 = wall_clock64();   // 100 MHz
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+      __builtin_amdgcn_s_sleep(4);
+      if (wall_clock64() - t0 > nm.timeout_ticks) {   // default: a peer that is a minute late is not coming
+        ok = false;
+        break;
+      }
+    }
+  }
+  ok = __all(ok);
+  __threadfence_system();
+  if (lane < nq) {
+    double t = 0.0;
+    if (ok)
+      for (int r = 0; r < nm.world; ++r)
+        t += __hip_atomic_load(bank + (size_t)r * 8 + 1 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else
+      t = __builtin_nan("");
+    red[lane] = t;
+  }
+  if (!ok && lane == 0) *nm.err = 1;
+}
+
 // red[q] = sum_b partials[b*nq + q] in a fixed order -> bitwise reproducible.  Two stages: `nb1` blocks each sum a
 // contiguous range into tmp[blk*nq + q], then one block sums tmp (a single block over ~1e5 partials took 98 us).
 __global__ __launch_bounds__(256) void k_reduce_stage1(int n, int nq, int per_block,
@@ -228,7 +272,8 @@ __global__ __launch_bounds__(256) void k_reduce_stage1(int n, int nq, int per_bl
 // final stage: ONE block of 1024 threads, every thread keeps nq (<= 3) independent accumulators so that its loads
 // are all in flight together; fixed summation order (thread-strided, then a fixed tree) -> reproducible.
 __global__ __launch_bounds__(1024) void k_reduce(int n, int nq, const double* __restrict__ partials,
-                                                  double* __restrict__ red, const int* __restrict__ done) {
+                                                  double* __restrict__ red, const int* __restrict__ done,
+                                                  const NodeMail nm) {
   if (done && *done) return;
   __shared__ double sm[16][3];
   double v[3] = {0.0, 0.0, 0.0};
@@ -264,12 +309,13 @@ __global__ __launch_bounds__(1024) void k_reduce(int n, int nq, const double* __
     for (int w = 0; w < 16; ++w) t += sm[w][threadIdx.x];
     red[threadIdx.x] = t;
   }
+  if (nm.slots) node_allreduce(red, nq, nm);
 }
 
 // PCG reduction: red = ( sum pv[.][0] , sum ps[.] , sum pv[.][1] ) = (gamma, delta, rr), fixed order
 __global__ __launch_bounds__(1024) void k_reduce_cg(int ns, const double* __restrict__ ps, int nv,
                                                      const double* __restrict__ pv, double* __restrict__ red,
-                                                     const int* __restrict__ done) {
+                                                     const int* __restrict__ done, const NodeMail nm) {
   if (done && *done) return;
   __shared__ double sm[16][3];
   double v[3] = {0.0, 0.0, 0.0};
@@ -291,6 +337,7 @@ __global__ __launch_bounds__(1024) void k_reduce_cg(int ns, const double* __rest
     for (int w = 0; w < 16; ++w) t += sm[w][threadIdx.x];
     red[threadIdx.x] = t;
   }
+  if (nm.slots) node_allreduce(red, 3, nm);
 }
 
 // Hands the host everything it decides on in ONE store sequence into pinned host memory:
@@ -298,7 +345,8 @@ __global__ __launch_bounds__(1024) void k_reduce_cg(int ns, const double* __rest
 // The host spins on seq instead of synchronising the stream and copying three scalars back (~25-30 us of idle
 // device per decision point, measured on the 1 M-row configuration).
 __global__ void k_publish(int n, const double* __restrict__ red, const double* __restrict__ info,
-                          const int* __restrict__ done, double* mail, unsigned long long seq) {
+                          const int* __restrict__ done, const int* __restrict__ comm_err, double* mail,
+                          unsigned long long seq) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   for (int i = 0; i < n && i < 4; ++i) mail[1 + i] = red[i];
   if (info) {
@@ -306,6 +354,7 @@ __global__ void k_publish(int n, const double* __restrict__ red, const double* _
     mail[6] = info[1];
   }
   mail[7] = done ? (double)*done : 0.0;
+  mail[8] = comm_err ? (double)*comm_err : 0.0;
   __threadfence_system();
   __hip_atomic_store(reinterpret_cast<unsigned long long*>(mail), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -463,8 +512,10 @@ void gl_halo_exchange(glims_ctx* h, double* vec, int bs) {
   halo_start(h, vec, bs);
   halo_finish(h);
 }
+// Sum over ranks of the values reduce_partials / k_reduce_cg just left in `dev` (= h->red).  With the node mailbox
+// the final reduction block has already done it.
 static void allreduce_sum(glims_ctx* h, double* dev, int n) {
-  if (h->world <= 1) return;
+  if (h->world <= 1 || h->nm.slots) return;
   if (h->tr_allreduce) {
     const int rc = h->tr_allreduce(h->tr_user, dev, n, (void*)h->st);
     if (rc != 0) throw glims_error(GLIMS_E_RCCL, "transport allreduce callback failed (" + std::to_string(rc) + ")");
@@ -484,9 +535,9 @@ static void reduce_partials(glims_ctx* h, int n, int nq, const int* done) {
     const int per_block = 1024, nb1 = (n + per_block - 1) / per_block;
     hipLaunchKernelGGL(k_reduce_stage1, dim3(nb1), dim3(256), 0, h->st, n, nq, per_block, h->partials.p,
                        h->partials2.p, done);
-    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, nb1, nq, h->partials2.p, h->red.p, done);
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, nb1, nq, h->partials2.p, h->red.p, done, h->nm);
   } else {
-    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, n, nq, h->partials.p, h->red.p, done);
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, n, nq, h->partials.p, h->red.p, done, h->nm);
   }
   GL_HIP(hipGetLastError());
 }
@@ -501,7 +552,7 @@ static Mail fetch(glims_ctx* h, int n_red, bool with_krylov) {
   const unsigned long long seq = ++h->mail_seq;
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, h->st, n_red, h->red.p,
                      with_krylov ? h->scal.p + 2 * SC_COUNT : (const double*)nullptr,
-                     with_krylov ? h->done.p : (const int*)nullptr, h->mail_dev, seq);
+                     with_krylov ? h->done.p : (const int*)nullptr, (const int*)h->nm.err, h->mail_dev, seq);
   GL_HIP(hipGetLastError());
   volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(h->h_pinned);
   for (long spins = 0; *flag != seq; ++spins) {
@@ -515,6 +566,8 @@ static Mail fetch(glims_ctx* h, int n_red, bool with_krylov) {
     }
   }
   std::atomic_thread_fence(std::memory_order_acquire);
+  if (h->h_pinned[8] != 0.0)
+    throw glims_error(GLIMS_E_RCCL, "node mailbox all-reduce timed out: a peer rank did not arrive within 60 s");
   Mail m;
   for (int i = 0; i < 4; ++i) m.red[i] = h->h_pinned[1 + i];
   m.info[0] = h->h_pinned[5];
@@ -628,7 +681,7 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
         ps = h->partials2.p;
       }
       hipLaunchKernelGGL(k_reduce_cg, dim3(1), dim3(1024), 0, h->st, ns, ps, (int)g, h->partials_v.p, h->red.p,
-                         h->done.p);
+                         h->done.p, h->nm);
       allreduce_sum(h, h->red.p, 3);
       GL_VEC(k_cg_update, n, h->red.p, prev, cur, info_dev, h->done.p, tol2, v.p, v.s, v.x, v.r, v.u, v.w, v.dinv,
              h->partials_v.p);
@@ -871,6 +924,30 @@ int gl_solve_mechanics(glims_ctx* h, const double* c_dev) {
   return cs;
 }
 
+
+// One node-mailbox all-reduce of known values (rank + 1, 2 (rank + 1), 1) with a 5 s limit; every rank must call it.
+int gl_mailbox_selftest(glims_ctx* h) {
+  GL_REQUIRE(h->nm.slots, "glims_comm_mailbox_selftest without a mailbox");
+  const double v[3] = {h->rank + 1.0, 2.0 * (h->rank + 1.0), 1.0};
+  GL_HIP(hipMemcpyAsync(h->partials.p, v, sizeof(v), hipMemcpyHostToDevice, h->st));
+  NodeMail nm = h->nm;
+  nm.timeout_ticks = 5ll * 100000000ll;
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, 1, 3, h->partials.p, h->red.p, (const int*)nullptr, nm);
+  GL_HIP(hipGetLastError());
+  double out[3] = {0.0, 0.0, 0.0};
+  int err = 0;
+  GL_HIP(hipMemcpyAsync(out, h->red.p, sizeof(out), hipMemcpyDeviceToHost, h->st));
+  GL_HIP(hipMemcpyAsync(&err, h->nm.err, sizeof(int), hipMemcpyDeviceToHost, h->st));
+  GL_HIP(hipStreamSynchronize(h->st));
+  const double w = h->world, tri = 0.5 * w * (w + 1.0);
+  if (err || out[0] != tri || out[1] != 2.0 * tri || out[2] != w) {
+    GL_HIP(hipMemsetAsync(h->nm.err, 0, sizeof(int), h->st));
+    GL_HIP(hipStreamSynchronize(h->st));
+    throw glims_error(GLIMS_E_RCCL, "node mailbox self-test failed (sum " + std::to_string(out[0]) + ", expected " +
+                                        std::to_string(tri) + (err ? ", timed out)" : ")"));
+  }
+  return GLIMS_OK;
+}
 
 // ===================================================================================================
 // RCCL self-test on a one-rank communicator (see glims_comm_selftest in the header)

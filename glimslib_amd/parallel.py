@@ -55,6 +55,54 @@ def broadcast_unique_id(dist, rank):
     return bytes(buf.numpy().tobytes())
 
 
+def setup_node_mailbox(h, dist, rank):
+    """
+    Switches the scalar all-reduces of `h` (a _backend.Handle with rank / world already set) to the node-local
+    shared-memory mailbox (glims_comm_mailbox), checks it collectively and falls back to RCCL / the transport callback
+    on every rank if any rank's check fails.  GLIMS_ALLREDUCE=rccl skips it.  Returns True when the mailbox is in use.
+    """
+    import torch
+    if os.environ.get("GLIMS_ALLREDUCE", "mailbox").lower() in ("rccl", "nccl", "callback"):
+        return False
+    name = ["/glims_%d_%s" % (os.getpid(), os.urandom(4).hex())] if rank == 0 else [None]
+    dist.broadcast_object_list(name, src=0)
+    ok = 1
+    try:
+        h.comm_mailbox(name[0])
+    except Exception as e:   # noqa: BLE001
+        print("glimslib_amd: node mailbox unavailable on rank %d (%s)" % (rank, e), flush=True)
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32)
+    _all_reduce_cpu(dist, flag, dist.ReduceOp.MIN)
+    if int(flag.item()) == 1:
+        try:
+            h.comm_mailbox_selftest()
+        except Exception as e:   # noqa: BLE001
+            print("glimslib_amd: node mailbox self-test failed on rank %d (%s)" % (rank, e), flush=True)
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32)
+        _all_reduce_cpu(dist, flag, dist.ReduceOp.MIN)
+    if rank == 0:
+        try:
+            os.unlink("/dev/shm" + name[0])   # every rank has mapped it (or given up) by now
+        except OSError:
+            pass
+    if int(flag.item()) != 1:
+        h.comm_mailbox(None)
+        return False
+    return True
+
+
+def _all_reduce_cpu(dist, t, op):
+    try:
+        dist.all_reduce(t, op=op)
+    except Exception:   # process group without a CPU backend
+        import torch
+        g = t.to(torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(g, op=op)
+        t.copy_(g.cpu())
+
+
 class HostStagedTransport:
     """glims_halo_fn / glims_allreduce_fn implemented with hipMemcpy staging + torch.distributed CPU collectives."""
 
@@ -135,6 +183,7 @@ class DistributedHandle:
         else:
             self.h.comm_init(rank, world, broadcast_unique_id(dist, rank))
         self.h.set_halo(p.peer_rank, p.send_ptr, p.send_idx, p.recv_count)
+        self.node_mailbox = setup_node_mailbox(self.h, dist, rank)
         self.g2l_owned = np.full(self.n_global, -1, dtype=np.int64)
         self.g2l_owned[p.global_ids[:p.n_own]] = np.arange(p.n_own)
         self.options = self.h.options

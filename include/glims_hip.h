@@ -187,6 +187,19 @@ int glims_project(glims_ctx* h, const double* rhs, double* x, int ncomp, double 
 int glims_comm_unique_id(char id[GLIMS_UNIQUE_ID_BYTES]);           /* rank 0; broadcast by the host program */
 int glims_comm_init(glims_ctx* h, int rank, int world, const char id[GLIMS_UNIQUE_ID_BYTES]);
 
+/* Node-local all-reduce for the scalars of the Krylov / Newton iterations: all ranks of ONE host map the POSIX
+ * shared-memory object `shm_name` ("/name", created on first use, >= world * 128 bytes) into their GPU's address
+ * space; the final block of each reduction kernel publishes its partial sums there and adds up everybody's in rank
+ * order.  No launch and no RCCL kernel per iteration (the all-reduce of three doubles is pure latency; the halo
+ * exchange stays on RCCL / xGMI).  Call after glims_comm_init or glims_set_transport (they set rank / world), from
+ * every rank with the same name; the caller unlinks the object once every rank has returned.  Without this call the
+ * reductions use ncclAllReduce (or the transport's allreduce callback).  shm_name = NULL switches it off again.
+ * New in this build; the reference's counterpart is PETSc's MPI_Allreduce inside KSP/SNES. */
+int glims_comm_mailbox(glims_ctx* h, const char* shm_name);
+/* Collective check of the mailbox: one all-reduce of known values with a 5 s limit; every rank calls it.  A host
+ * program that gets an error from ANY rank switches the mailbox off on ALL ranks (glims_comm_mailbox(h, NULL)). */
+int glims_comm_mailbox_selftest(glims_ctx* h);
+
 /* Diagnostic: runs the library's RCCL call sequence (pack -> event -> grouped ncclSend/ncclRecv on the communication
  * stream -> event -> compute stream, then ncclAllReduce on the compute stream) on a fresh ONE-rank communicator pair,
  * sending to itself, and checks the data.  Proves that the RCCL library the process resolved is usable with this

@@ -46,7 +46,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir, dim=3):
+def _worker(rank, world, port, out_dir, dim=3, mailbox=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -87,8 +87,11 @@ def _worker(rank, world, port, out_dir, dim=3):
                 print("halo callback failed:", e, flush=True)
                 return 1
 
+        calls = {"allreduce": 0}
+
         def allreduce(user, values, n, stream):
             try:
+                calls["allreduce"] += 1
                 hip.hipStreamSynchronize(stream)
                 t = torch.from_numpy(d2h(values, n))
                 dist.all_reduce(t)
@@ -103,6 +106,10 @@ def _worker(rank, world, port, out_dir, dim=3):
         h = _backend.Handle(part.points, part.cells, label[part.cell_ids], n_own=part.n_own, device=0)
         h.set_transport(rank, world, _backend.HALO_FN(halo), _backend.ALLREDUCE_FN(allreduce))
         h.set_halo(part.peer_rank, part.send_ptr, part.send_idx, part.recv_count)
+        if mailbox:
+            # scalar all-reduces inside the reduction kernels, through shared host memory (glims_comm_mailbox)
+            from glimslib_amd.parallel import setup_node_mailbox
+            assert setup_node_mailbox(h, dist, rank)
         h.set_materials(TABS['D'], TABS['rho'], TABS['gamma'], TABS['E'], TABS['nu'])
         h.set_options(dt=1.0)
         # clamp the owned exterior nodes (Dirichlet data is given for owned dofs only)
@@ -117,6 +124,7 @@ def _worker(rank, world, port, out_dir, dim=3):
         sm = h.solve_mechanics()
         c, u = h.get_state()
         stats = h.stats()
+        assert (calls["allreduce"] == 0) == mailbox
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), gid=part.global_ids, n_own=part.n_own, c=c,
                  u=u.reshape(-1, dim), status=[st1, st2, sm], cg=stats['cg_its'], newton=stats['newton_its'],
                  n_bnd=len(part.peer_rank))
@@ -126,9 +134,9 @@ def _worker(rank, world, port, out_dir, dim=3):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("dim,world", [(3, 2), (2, 3)])
-def test_ranks_on_one_gpu_match_serial(tmp_path, backend, dim, world):
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), dim), nprocs=world, join=True)
+@pytest.mark.parametrize("dim,world,mailbox", [(3, 2, False), (2, 3, False), (3, 2, True), (2, 4, True)])
+def test_ranks_on_one_gpu_match_serial(tmp_path, backend, dim, world, mailbox):
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), dim, mailbox), nprocs=world, join=True)
     mesh, label, bn, c0 = _problem(dim)
     n = mesh.num_vertices()
     c = np.full(n, np.nan)
