@@ -202,8 +202,9 @@ def main():
     except Exception:
         traffic = None
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_spmv<0,4,1> (SELL-64, fp64 values, "
-                "int32 columns)", "algorithmic_bytes_per_launch": b_alg, "avg_launch_us": t_spmv * 1e6,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_spmv<0,4,1,1> (SELL-64, fp64 values, "
+                "columns streamed as 16-bit window codes; algorithmic bytes still count 4-byte CSR columns)",
+                "algorithmic_bytes_per_launch": b_alg, "avg_launch_us": t_spmv * 1e6,
                 "launches_timed": args.spmv_reps}
 
     if rank == 0:

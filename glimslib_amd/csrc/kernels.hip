@@ -358,6 +358,7 @@ template <int COMP, int UNR, int NT>
 __device__ __forceinline__ double spmv_row(const int32_t* __restrict__ cc, const uint16_t* __restrict__ c16,
                                             int32_t wb, const double* __restrict__ v, const double* __restrict__ x,
                                             int len) {
+  constexpr bool NTC = NT == 1, NTV = NT != 0;   // NT = 2: only the 8-byte value stream is non-temporal
   double acc = 0.0;
   int k = 0;
   for (; k + UNR <= len; k += UNR) {
@@ -367,19 +368,19 @@ __device__ __forceinline__ double spmv_row(const int32_t* __restrict__ cc, const
       uint16_t qu[UNR];
 #pragma unroll
       for (int j = 0; j < UNR; ++j)
-        qu[j] = NT ? __builtin_nontemporal_load(c16 + (int64_t)(k + j) * GL_WAVE) : c16[(int64_t)(k + j) * GL_WAVE];
+        qu[j] = NTC ? __builtin_nontemporal_load(c16 + (int64_t)(k + j) * GL_WAVE) : c16[(int64_t)(k + j) * GL_WAVE];
 #pragma unroll
       for (int j = 0; j < UNR; ++j)
-        vu[j] = NT ? __builtin_nontemporal_load(v + (int64_t)(k + j) * GL_WAVE) : v[(int64_t)(k + j) * GL_WAVE];
+        vu[j] = NTV ? __builtin_nontemporal_load(v + (int64_t)(k + j) * GL_WAVE) : v[(int64_t)(k + j) * GL_WAVE];
 #pragma unroll
       for (int j = 0; j < UNR; ++j) cu[j] = decode_col(qu[j], wb);
     } else {
 #pragma unroll
       for (int j = 0; j < UNR; ++j)
-        cu[j] = NT ? __builtin_nontemporal_load(cc + (int64_t)(k + j) * GL_WAVE) : cc[(int64_t)(k + j) * GL_WAVE];
+        cu[j] = NTC ? __builtin_nontemporal_load(cc + (int64_t)(k + j) * GL_WAVE) : cc[(int64_t)(k + j) * GL_WAVE];
 #pragma unroll
       for (int j = 0; j < UNR; ++j)
-        vu[j] = NT ? __builtin_nontemporal_load(v + (int64_t)(k + j) * GL_WAVE) : v[(int64_t)(k + j) * GL_WAVE];
+        vu[j] = NTV ? __builtin_nontemporal_load(v + (int64_t)(k + j) * GL_WAVE) : v[(int64_t)(k + j) * GL_WAVE];
     }
 #pragma unroll
     for (int j = 0; j < UNR; ++j) xu[j] = x[cu[j]];
@@ -395,14 +396,14 @@ __device__ __forceinline__ double spmv_row(const int32_t* __restrict__ cc, const
     for (int j = 0; j < UNR; ++j) {
       const int kk = min(k + j, len - 1);
       if (COMP)
-        cu[j] = (int32_t)(NT ? __builtin_nontemporal_load(c16 + (int64_t)kk * GL_WAVE) : c16[(int64_t)kk * GL_WAVE]);
+        cu[j] = (int32_t)(NTC ? __builtin_nontemporal_load(c16 + (int64_t)kk * GL_WAVE) : c16[(int64_t)kk * GL_WAVE]);
       else
-        cu[j] = NT ? __builtin_nontemporal_load(cc + (int64_t)kk * GL_WAVE) : cc[(int64_t)kk * GL_WAVE];
+        cu[j] = NTC ? __builtin_nontemporal_load(cc + (int64_t)kk * GL_WAVE) : cc[(int64_t)kk * GL_WAVE];
     }
 #pragma unroll
     for (int j = 0; j < UNR; ++j) {
       const int kk = min(k + j, len - 1);
-      const double vj = NT ? __builtin_nontemporal_load(v + (int64_t)kk * GL_WAVE) : v[(int64_t)kk * GL_WAVE];
+      const double vj = NTV ? __builtin_nontemporal_load(v + (int64_t)kk * GL_WAVE) : v[(int64_t)kk * GL_WAVE];
       vu[j] = (k + j < len) ? vj : 0.0;
     }
     if (COMP) {
@@ -680,7 +681,10 @@ void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* s
     if (h->tune_idx16) GL_SPMV3(DOTS, UNR, NT, 1); else GL_SPMV3(DOTS, UNR, NT, 0); \
   } while (0)
   const int unr = h->tune_spmv_unroll;
-  if (h->tune_spmv_nt) {
+  if (h->tune_spmv_nt == 2) {
+    if (r) { if (unr == 8) GL_SPMV(1, 8, 2); else GL_SPMV(1, 4, 2); }
+    else   { if (unr == 8) GL_SPMV(0, 8, 2); else GL_SPMV(0, 4, 2); }
+  } else if (h->tune_spmv_nt) {
     if (r) { if (unr == 8) GL_SPMV(1, 8, 1); else GL_SPMV(1, 4, 1); }
     else   { if (unr == 8) GL_SPMV(0, 8, 1); else GL_SPMV(0, 4, 1); }
   } else {

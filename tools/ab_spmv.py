@@ -27,8 +27,13 @@ if study == 'idx16':
         y, _ = h.apply(0, x, reps=1)
         assert y0 is None or np.array_equal(y, y0), "index streams disagree"
         y0 = y
+if study == 'unroll':
+    variants = [("unroll 4", dict(GLIMS_SPMV_UNROLL="4")), ("unroll 8", dict(GLIMS_SPMV_UNROLL="8"))]
+if study == 'nt':
+    variants = [("nt values+columns", dict(GLIMS_SPMV_NT="1")), ("plain loads", dict(GLIMS_SPMV_NT="0")),
+                ("nt values only", dict(GLIMS_SPMV_NT="2"))]
 res = {n: [] for n, _ in variants}
-for rnd in range(6):
+for rnd in range(9):
     for name, env in variants:
         os.environ.update(env)
         _, ms = h.apply(0, x, reps=30)
