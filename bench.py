@@ -207,6 +207,26 @@ def main():
                 "algorithmic_bytes_per_launch": b_alg, "avg_launch_us": t_spmv * 1e6,
                 "launches_timed": args.spmv_reps}
 
+    # practical HBM ceiling of THIS device next to the nominal peak: streaming scale kernel y = 2 x over
+    # 1 GiB, read + write bytes over the HIP-event time of 10 launches (torch is only the allocator / launcher here;
+    # its memcpy path goes through the copy engines and is much slower than a kernel)
+    try:
+        src = torch.empty(1 << 27, dtype=torch.float64, device="cuda")
+        dst = torch.empty_like(src)
+        src.fill_(1.0)
+        torch.mul(src, 2.0, out=dst)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(10):
+            torch.mul(src, 2.0, out=dst)
+        e1.record()
+        torch.cuda.synchronize()
+        roofline["stream_ceiling"] = 2.0 * src.numel() * 8 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
+    except Exception:   # noqa: BLE001 -- informational only
+        roofline["stream_ceiling"] = None
+
     if rank == 0:
         out = {
             "metric": "DoF-updates/s (implicit RD timestep) on 3D brain mesh",
