@@ -354,10 +354,12 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
 // one lane's row of a slice: UNR independent (column, value, gather) triples in flight
 // NT: values and columns are streamed exactly once per SpMV -> non-temporal, so that they do not displace the
 // gathered x entries from L2 / Infinity Cache
-template <int COMP, int UNR, int NT>
+// DK >= 0 (fused dot product): also returns x at the row's own column through xdiag (slot dk of the row), so that
+// the dot y.x does not read x[row] a second time
+template <int COMP, int UNR, int NT, int WANT_DIAG>
 __device__ __forceinline__ double spmv_row(const int32_t* __restrict__ cc, const uint16_t* __restrict__ c16,
                                             int32_t wb, const double* __restrict__ v, const double* __restrict__ x,
-                                            int len) {
+                                            int len, int dk, double& xdiag) {
   constexpr bool NTC = NT == 1, NTV = NT != 0;   // NT = 2: only the 8-byte value stream is non-temporal
   double acc = 0.0;
   int k = 0;
@@ -386,6 +388,10 @@ __device__ __forceinline__ double spmv_row(const int32_t* __restrict__ cc, const
     for (int j = 0; j < UNR; ++j) xu[j] = x[cu[j]];
 #pragma unroll
     for (int j = 0; j < UNR; ++j) acc += vu[j] * xu[j];
+    if (WANT_DIAG) {
+#pragma unroll
+      for (int j = 0; j < UNR; ++j) xdiag = (k + j == dk) ? xu[j] : xdiag;
+    }
   }
   if (k < len) {
     // ragged tail (len is rarely a multiple of UNR: 15 on the structured 3-D meshes) as ONE more batch with the slot
@@ -414,6 +420,10 @@ __device__ __forceinline__ double spmv_row(const int32_t* __restrict__ cc, const
     for (int j = 0; j < UNR; ++j) xu[j] = x[cu[j]];
 #pragma unroll
     for (int j = 0; j < UNR; ++j) acc += vu[j] * xu[j];
+    if (WANT_DIAG) {
+#pragma unroll
+      for (int j = 0; j < UNR; ++j) xdiag = (k + j == dk) ? xu[j] : xdiag;
+    }
   }
   return acc;
 }
@@ -423,7 +433,8 @@ __global__ __launch_bounds__(256) void k_spmv(int n_launch, int chunk, const int
                                                int64_t n_own, const int64_t* __restrict__ slice_ptr,
                                                const int32_t* __restrict__ cols, const uint16_t* __restrict__ cols16,
                                                const int32_t* __restrict__ win_base,
-                                               const uint8_t* __restrict__ win_ok, const double* __restrict__ vals,
+                                               const uint8_t* __restrict__ win_ok,
+                                               const uint8_t* __restrict__ diag_k, const double* __restrict__ vals,
                                                const double* __restrict__ x, double* __restrict__ y,
                                                const uint8_t* __restrict__ fixed, const double* __restrict__ addv,
                                                const double* __restrict__ r, double* __restrict__ partials,
@@ -441,18 +452,19 @@ __global__ __launch_bounds__(256) void k_spmv(int n_launch, int chunk, const int
     const int64_t base = slice_ptr[s];
     const int len = (int)((slice_ptr[s + 1] - base) >> 6);
     const double* v = vals + base + lane;
-    double acc;
+    double acc, xd = 0.0;
+    const int dk = DOTS ? (int)diag_k[row] : -1;   // diag_k covers the padded rows of the last slice as well
     if (CIDX && win_ok[s]) {   // wave-uniform
       const int32_t wb = win_base[(int64_t)s * GL_N_WIN + (lane & (GL_N_WIN - 1))];
-      acc = spmv_row<1, UNR, NT>(nullptr, cols16 + base + lane, wb, v, x, len);
+      acc = spmv_row<1, UNR, NT, DOTS>(nullptr, cols16 + base + lane, wb, v, x, len, dk, xd);
     } else {
-      acc = spmv_row<0, UNR, NT>(cols + base + lane, nullptr, 0, v, x, len);
+      acc = spmv_row<0, UNR, NT, DOTS>(cols + base + lane, nullptr, 0, v, x, len, dk, xd);
     }
     if (row < n_own) {
       if (fixed && fixed[row]) acc = 0.0;
       if (addv) acc += addv[row];
       y[row] = acc;
-      if (DOTS) pd += acc * x[row];
+      if (DOTS) pd += acc * xd;   // xd = x[row], picked up from the gather of the diagonal entry
     }
   }
   if (DOTS) {
@@ -674,7 +686,8 @@ void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* s
   const int remap = slice_list ? 0 : h->tune_xcd_remap;   // 0 plain, 1 contiguous eighths, G > 1 chunks of G blocks
 #define GL_SPMV3(DOTS, UNR, NT, CIDX)                                                                              \
   hipLaunchKernelGGL((k_spmv<DOTS, UNR, NT, CIDX>), dim3(grid), dim3(256), 0, st, n_launch, chunk, slice_list,      \
-                     h->n_own, p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, p.win_ok.p, vals, x, y, fixed,     \
+                     h->n_own, p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, p.win_ok.p, p.diag_k.p, vals, x, y, \
+                     fixed,                                                                                         \
                      addv, r, partials, partial_off, done, remap)
 #define GL_SPMV(DOTS, UNR, NT)                                                       \
   do {                                                                               \
