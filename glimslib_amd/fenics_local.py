@@ -273,6 +273,49 @@ class CellFunction:
 MeshFunctionSizet = CellFunction
 
 
+class FiniteElement:
+    """Scalar Lagrange element descriptor (dolfin.FiniteElement as the reference's setup code uses it,
+    simulation_tumor_growth.py:67-69); only P1 is implemented by the device path."""
+    value_size_hint = 1
+
+    def __init__(self, family="Lagrange", cell=None, degree=1):
+        if degree != 1 or str(family) not in ("Lagrange", "CG", "P"):
+            raise NotImplementedError("only P1 Lagrange elements are supported by the HIP path")
+        self.family, self.cell, self.degree = "Lagrange", cell, 1
+
+    def value_size(self, dim):
+        return 1
+
+    def __eq__(self, other):
+        return type(other) is type(self) and other.cell == self.cell
+
+    def __hash__(self):
+        return hash((type(self).__name__, self.cell))
+
+
+class VectorElement(FiniteElement):
+    """dolfin.VectorElement: one P1 component per space dimension."""
+
+    def value_size(self, dim):
+        return dim
+
+
+class MixedElement:
+    """dolfin.MixedElement([e0, e1, ...]); sub-element i belongs to subspace id i."""
+
+    def __init__(self, elements):
+        self.elements = list(elements)
+
+    def sub_elements(self):
+        return list(self.elements)
+
+    def __eq__(self, other):
+        return isinstance(other, MixedElement) and other.elements == self.elements
+
+    def __hash__(self):
+        return hash(tuple(self.elements))
+
+
 class _Vector:
     def __init__(self, owner):
         self._o = owner
@@ -301,16 +344,21 @@ class Function:
     ``{0: displacement [N, d], 1: concentration [N]}`` (simulation_tumor_growth.py:67-72).
     """
 
-    def __init__(self, mesh, components, names=None, name="f"):
+    def __init__(self, mesh, components, names=None, name="f", space=None):
         self.mesh = mesh
         self.components = {k: np.array(v, dtype=np.float64) for k, v in components.items()}
         self.names = names or {}
         self._name = name
         self.label = name
+        self._space = space
+
+    def function_space(self):
+        """The space object this function was created in (identity is what callers compare)."""
+        return self._space
 
     # -- dolfin-flavoured accessors --------------------------------------------------------------------
     def copy(self, deepcopy=True):
-        f = Function(self.mesh, self.components, dict(self.names), self._name)
+        f = Function(self.mesh, self.components, dict(self.names), self._name, space=self._space)
         f.label = self.label
         return f
 

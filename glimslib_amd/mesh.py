@@ -50,6 +50,10 @@ class Mesh:
     def mpi_comm(self):
         return None
 
+    def ufl_cell(self):
+        """Cell name as DOLFIN reports it; only consumed by the element descriptors of fenics_local."""
+        return "triangle" if self.points.shape[1] == 2 else "tetrahedron"
+
     @property
     def dim(self):
         return self.points.shape[1]

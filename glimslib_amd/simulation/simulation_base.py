@@ -112,7 +112,8 @@ class FenicsSimulation(ABC):
     def run(self, keep_nth=1, save_method='xdmf', clear_all=False, plot=True,
             output_dir=config.output_dir_simulation_tmp, results_on_device=None):
         """
-        simulation_base.py:236-317.  ``save_method``: None, 'vtk' or 'xdmf' (both write .vtu files here).
+        simulation_base.py:236-317.  ``save_method``: None, 'vtk' (<field>/<field>_<step>.pvd + .vtu, the reference's
+        layout) or 'xdmf' (solution.xdmf + solution.bin instead of solution.h5).
         Returns ``self.solution`` (mixed Function {0: displacement, 1: concentration}).
 
         ``results_on_device`` (extension): keep the recorded steps in HBM and materialise them lazily -- the

@@ -23,6 +23,7 @@ import copy
 import itertools
 import logging
 import os
+import shutil
 
 import numpy as np
 
@@ -87,12 +88,18 @@ class Measure:
 
 # ---------------------------------------------------------------------------------------------------
 class SubSpaces:
-    """helper_classes.py:66-232 (bookkeeping only)."""
+    """
+    helper_classes.py:66-232.  Per-subspace bookkeeping: names plus optional per-subspace attributes (elements,
+    function spaces, initial-value expressions, Dirichlet / Neumann BC lists), each stored as
+    ``{subspace_id: item}`` under ``_<attribute>``; lists are enumerated, an existing attribute is only replaced
+    when asked to, wrong lengths / types are logged and ignored -- all as in the reference.
+    """
 
     def __init__(self, names=None):
         self.logger = logging.getLogger(__name__)
         self.names = dict(names or {})
         self.n = len(self.names)
+        self._attribute_prefix = '_'
 
     def get_subspace_names(self):
         return self.names.values()
@@ -110,11 +117,112 @@ class SubSpaces:
         self.logger.warning("Functionspace does not have '%s' subspace." % subspace_name)
         return None
 
+    # -- generic attribute store ---------------------------------------------------------------------------
+    def _set_subspace_attribute(self, name, content, replace=False):
+        internal = self._attribute_prefix + name
+        if not isinstance(content, (list, dict)):
+            self.logger.error('Expect either list or dictionary')
+            return
+        if len(content) != self.n:
+            self.logger.error('Expect content with %i items, but this has %i items.' % (self.n, len(content)))
+            return
+        as_dict = dict(enumerate(content)) if isinstance(content, list) else content
+        if hasattr(self, internal) and not replace:
+            self.logger.warning("Attribute '%s' already exists ... do nothing." % internal)
+            return
+        setattr(self, internal, as_dict)
+
+    def _get_subspace_attribute(self, name, subspace_id=None, subspace_name=None):
+        if subspace_id is None and subspace_name is None:
+            self.logger.error("No subspace or subspace name specified")
+        elif subspace_id is None:
+            subspace_id = self.get_subspace_id(subspace_name)
+        store = getattr(self, self._attribute_prefix + name, None)
+        if store is None:
+            self.logger.warning("Attribute '%s' does not exist." % name)
+            return None
+        if subspace_id in store:
+            return store[subspace_id]
+        self.logger.warning("Attribute '%s' has no information for subspace '%s'" % (name, subspace_id))
+        return None
+
+    def get_element(self, subspace_id=None, subspace_name=None):
+        return self._get_subspace_attribute('elements', subspace_id, subspace_name)
+
+    def get_inital_value_expression(self, subspace_id=None, subspace_name=None):
+        return self._get_subspace_attribute('inital_value_expressions', subspace_id, subspace_name)
+
+    def get_functionspace(self, subspace_id=None, subspace_name=None):
+        return self._get_subspace_attribute('functionspaces', subspace_id, subspace_name)
+
+    def get_dirichlet_bcs(self, subspace_id=None, subspace_name=None):
+        return self._get_subspace_attribute('bcs_dirichlet', subspace_id, subspace_name)
+
+    def get_von_neumann_bcs(self, subspace_id=None, subspace_name=None):
+        return self._get_subspace_attribute('bcs_von_neumann', subspace_id, subspace_name)
+
+    def set_elements(self, content, replace=False):
+        self._set_subspace_attribute('elements', content, replace=replace)
+
+    def set_inital_value_expressions(self, content, replace=False):
+        self._set_subspace_attribute('inital_value_expressions', content, replace=replace)
+
+    def set_functionspaces(self, content, replace=False):
+        self._set_subspace_attribute('functionspaces', content, replace=replace)
+
+    def _rearrange_dict_by_subspace(self, dict_in):
+        """{bc name: {..., 'subspace_id': i}} -> {i: [bc dict + 'name']}, an (empty) list for every subspace."""
+        by_subspace = {sid: [] for sid in self.names}
+        for bc_name, item in dict_in.items():
+            sid = item.get('subspace_id')
+            if sid in by_subspace:
+                item['name'] = bc_name
+                by_subspace[sid].append(item)
+        return by_subspace
+
+    def set_dirichlet_bcs(self, content, replace=False):
+        self._set_subspace_attribute('bcs_dirichlet', self._rearrange_dict_by_subspace(content), replace=replace)
+
+    def set_von_neumann_bcs(self, content, replace=False):
+        self._set_subspace_attribute('bcs_von_neumann', self._rearrange_dict_by_subspace(content), replace=replace)
+
+    def project_over_subspace(self, function_expr, subspace_id=None, subspace_name=None, **kwargs):
+        if subspace_id is None and subspace_name is None:
+            self.logger.error("No subspace or subspace name specified")
+            return None
+        if subspace_id is None:
+            subspace_id = self.get_subspace_id(subspace_name)
+        space = self.get_functionspace(subspace_id=subspace_id)
+        if space is None:
+            return None
+        try:
+            return space.project_over_space(function_expr)
+        except Exception as e:   # noqa: BLE001 -- the reference logs and returns None
+            self.logger.warning("Cannot project functions over subspace %s: %r" % (subspace_id, e))
+            return None
+
+
+class _CollapsedSpace:
+    """Stand-alone space of one subspace of a mixed FunctionSpace (the reference builds
+    ``fenics.FunctionSpace(mesh, sub_element)`` per subspace, helper_classes.py:258-269)."""
+
+    def __init__(self, mesh, element, value_size, name):
+        self._mesh, self.element, self._vs, self.name = mesh, element, value_size, name
+
+    def ufl_element(self):
+        return self.element
+
+    def project_over_space(self, function_expr):
+        return Function(self._mesh, {None: interpolate_nodal(function_expr, self._mesh, self._vs)}, name=self.name,
+                        space=self)
+
 
 class FunctionSpace:
     """
-    helper_classes.py:234-383.  The "element" is reduced to what the P1 path needs: a dict
-    {subspace_id: value_size}; the mixed tumour-growth space is {0: dim, 1: 1}.
+    helper_classes.py:234-383.  ``element`` is either the reference's own description -- a
+    ``fenics.MixedElement([VectorElement, FiniteElement])`` / a single element (fenics_local supplies P1 descriptors)
+    -- or the short form this package uses internally, ``{subspace_id: value_size}`` / an int.  The mixed
+    tumour-growth space is {0: dim, 1: 1}.
     """
 
     def __init__(self, mesh, projection_parameters=None):
@@ -126,15 +234,45 @@ class FunctionSpace:
 
     def init_function_space(self, element, name):
         self.element = element
+        dim = self.dim_geo
         if isinstance(name, dict):
             self.has_subspaces = True
             self.subspaces = SubSpaces(name)
-            self.value_sizes = dict(element)
+            if isinstance(element, dict):
+                self.value_sizes = {k: int(v) for k, v in element.items()}
+                sub_elements = dict(element)
+            else:
+                subs = element.sub_elements()
+                self.value_sizes = {i: int(e.value_size(dim)) for i, e in enumerate(subs)}
+                sub_elements = dict(enumerate(subs))
+            self.subspaces.set_elements(sub_elements)
+            self.subspaces.set_functionspaces({i: _CollapsedSpace(self._mesh, sub_elements[i], vs, name.get(i))
+                                               for i, vs in self.value_sizes.items()})
         else:
             self.has_subspaces = False
             self.name = name
-            self.value_sizes = {None: int(element)}
+            vs = int(element) if isinstance(element, (int, np.integer)) else int(element.value_size(dim))
+            self.value_sizes = {None: vs}
         self.function_space = self
+
+    # -- accessors of the reference ---------------------------------------------------------------------------
+    def get_element(self, subspace_id=None, subspace_name=None):
+        if self.has_subspaces and not (subspace_id is None and subspace_name is None):
+            return self.subspaces.get_element(subspace_id=subspace_id, subspace_name=subspace_name)
+        return self.element
+
+    def get_functionspace(self, subspace_id=None, subspace_name=None):
+        if self.has_subspaces and not (subspace_id is None and subspace_name is None):
+            return self.subspaces.get_functionspace(subspace_id=subspace_id, subspace_name=subspace_name)
+        return self.function_space
+
+    def get_functionspace_orig_subspace(self, subspace_id=None, subspace_name=None):
+        if subspace_id is None and subspace_name is None:
+            self.logger.error("No subspace or subspace name specified")
+            return None
+        if subspace_id is None:
+            subspace_id = self.get_subspace_id(subspace_name)
+        return (self, subspace_id)
 
     def get_subspace_id(self, subspace_name):
         return self.subspaces.get_subspace_id(subspace_name)
@@ -145,7 +283,7 @@ class FunctionSpace:
     def new_function(self, name="f"):
         n = self._mesh.num_vertices()
         comps = {k: (np.zeros(n) if vs == 1 else np.zeros((n, vs))) for k, vs in self.value_sizes.items()}
-        return Function(self._mesh, comps, names=getattr(self, 'subspaces', SubSpaces()).names, name=name)
+        return Function(self._mesh, comps, names=getattr(self, 'subspaces', SubSpaces()).names, name=name, space=self)
 
     def project_over_space(self, function_expr, subspace_id=None, subspace_name=None, **kwargs):
         """
@@ -165,7 +303,8 @@ class FunctionSpace:
                 return function_expr.sub(subspace_id)
             return function_expr.copy()
         vs = self.value_sizes[subspace_id] if subspace_id in self.value_sizes else 1
-        return Function(self._mesh, {None: interpolate_nodal(function_expr, self._mesh, vs)})
+        space = self.subspaces.get_functionspace(subspace_id) if self.has_subspaces and subspace_id is not None else self
+        return Function(self._mesh, {None: interpolate_nodal(function_expr, self._mesh, vs)}, space=space)
 
     def split_function(self, function, subspace_id=None, subspace_name=None):
         """helper_classes.py:362-383"""
@@ -174,7 +313,9 @@ class FunctionSpace:
                 return function
             if subspace_id is None:
                 subspace_id = self.subspaces.get_subspace_id(subspace_name)
-            return function.sub(subspace_id)
+            sub = function.sub(subspace_id)
+            sub._space = self.subspaces.get_functionspace(subspace_id)
+            return sub
         return function
 
 
@@ -824,27 +965,89 @@ class Results:
     def get_recording_steps(self):
         return self.data.get_all_recording_steps(self.ts_name)
 
-    # -- file output (the reference writes XDMF/VTK through DOLFIN; here: ASCII .vtu + .npz) ------------------
-    def save_solution_start(self, method='xdmf', clear_all=False):
-        if method is not None and self.output_dir is not None:
-            os.makedirs(self.output_dir, exist_ok=True)
+    # -- file output: the reference's layout (helper_classes.py:1350-1452) -------------------------------------
+    #   'vtk'  : <output_dir>/<field>/<field>_<step:05d>.pvd  (+ the .vtu piece DOLFIN's File writes next to it)
+    #   'xdmf' : <output_dir>/solution.xdmf, every subspace an Attribute of a temporal grid collection; the heavy
+    #            data goes to solution.bin instead of solution.h5 (no HDF5 library here, see utils/xdmf_io.py)
+    def get_function_save_name(self, function_name, recording_step, method='vtk'):
+        if method == 'xdmf':
+            return "solution_xdmf"
+        return "%s_%05d" % (function_name, recording_step)
+
+    def save_function(self, function, function_name, function_save_name, time, subspace_id=None, method='xdmf'):
+        from ..utils.vtu_io import write_vtu
+        from ..utils.xdmf_io import XDMFFile
+        mesh = self._functionspace._mesh
+        is_cell_data = isinstance(function, np.ndarray) or hasattr(function, 'array')
+        if not is_cell_data and not isinstance(function, Function):
+            function = self._functionspace.project_over_space(function, subspace_id=subspace_id)
+        if method == 'xdmf':
+            if not hasattr(self, 'output_xdmf_file'):
+                self.output_xdmf_file = XDMFFile(os.path.join(self.output_dir, function_save_name + '.xdmf'))
+                self.output_xdmf_file.write(mesh)
+            if is_cell_data:
+                self.logger.warning("cell functions are not written to XDMF")
+                return
+            self.output_xdmf_file.write_checkpoint(function, function_name, time)
+        elif method == 'vtk':
+            folder = os.path.join(self.output_dir, function_name)
+            os.makedirs(folder, exist_ok=True)
+            piece = function_save_name + '000000.vtu'
+            if is_cell_data:
+                vals = np.asarray(function.array() if hasattr(function, 'array') else function)
+                write_vtu(os.path.join(folder, piece), mesh.points, mesh.cells, {}, {function_name: vals})
+            else:
+                write_vtu(os.path.join(folder, piece), mesh.points, mesh.cells, {function_name: function.values()}, {})
+            with open(os.path.join(folder, function_save_name + '.pvd'), 'w') as f:
+                f.write('<?xml version="1.0"?>\n<VTKFile type="Collection" version="0.1">\n<Collection>\n'
+                        '<DataSet timestep="%.17g" part="0" file="%s" />\n</Collection>\n</VTKFile>\n' %
+                        (float(time), piece))
+        else:
+            self.logger.warning("Save method '%s' is not defined" % method)
 
     def save_solution(self, recording_step, time, function=None, method='xdmf'):
         if method is None or self.output_dir is None:
             return
         if function is None:
             function = self.get_solution_function(recording_step=recording_step)
-        from ..utils.vtu_io import write_vtu
-        names = getattr(self._functionspace, 'subspaces', SubSpaces({None: 'solution'})).names
-        fields = {names.get(k, 'solution'): v for k, v in function.components.items()}
-        cell_fields = {}
-        if hasattr(self, '_subdomains') and hasattr(self._subdomains, 'subdomains'):
-            cell_fields['label_map'] = self._subdomains.subdomains.array()
-        path = os.path.join(self.output_dir, "solution_%05d.vtu" % recording_step)
-        write_vtu(path, function.mesh.points, function.mesh.cells, fields, cell_fields)
+        fs = self._functionspace
+        if fs.has_subspaces:
+            for sid in fs.subspaces.get_subspace_ids():
+                name = fs.subspaces.get_subspace_name(sid)
+                self.save_function(fs.split_function(function, subspace_id=sid), name,
+                                   self.get_function_save_name(name, recording_step, method=method), time, sid,
+                                   method=method)
+        else:
+            self.save_function(function, fs.name, self.get_function_save_name(fs.name, recording_step, method=method),
+                               time, method=method)
+
+    def save_label_function(self, recording_step, time, method='xdmf'):
+        name = 'label_map'
+        self.save_function(self._subdomains.subdomains, name, self.get_function_save_name(name, recording_step, method),
+                           time, method=method)
+
+    def save_solution_start(self, method='xdmf', clear_all=False):
+        """Careful with clear_all: it removes the whole output directory, as in the reference."""
+        if method is None or self.output_dir is None:
+            return
+        if os.path.exists(self.output_dir) and clear_all:
+            shutil.rmtree(self.output_dir, ignore_errors=True)
+        os.makedirs(self.output_dir, exist_ok=True)
+        if method == 'xdmf':
+            from ..utils.xdmf_io import XDMFFile
+            for ext in ('.xdmf', '.bin'):
+                try:
+                    os.remove(os.path.join(self.output_dir, 'solution' + ext))
+                except OSError:
+                    pass
+            self.output_xdmf_file = XDMFFile(os.path.join(self.output_dir, 'solution.xdmf'))
+            self.output_xdmf_file.write(self._functionspace._mesh)
+        if hasattr(self, '_subdomains') and hasattr(self._subdomains, 'subdomains') and method == 'vtk':
+            self.save_label_function(0, 0, method=method)
 
     def save_solution_end(self, method='xdmf'):
-        pass
+        if method == 'xdmf' and hasattr(self, 'output_xdmf_file'):
+            self.output_xdmf_file.close()
 
     def save_solution_hdf5(self, save_path=None):
         if save_path is None:

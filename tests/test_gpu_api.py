@@ -69,8 +69,10 @@ def test_keep_nth_vtk_output_and_rerun_with_new_parameters(tmp_path):
     sim.run(keep_nth=3, save_method='vtk', plot=False, output_dir=str(tmp_path))
     assert sim.results.get_recording_steps() == [0, 1, 2]                 # t = 0, 3, 6
     assert sim.solver_statistics()['mech_solves'] == 2                    # displacement only at recorded steps
-    assert sorted(f for f in os.listdir(str(tmp_path)) if f.endswith('.vtu')) == \
-        ['solution_%05d.vtu' % k for k in range(3)]
+    for field in ('concentration', 'displacement'):                        # the reference's layout (hc:1376-1380)
+        assert sorted(f for f in os.listdir(os.path.join(str(tmp_path), field)) if f.endswith('.pvd')) == \
+            ['%s_%05d.pvd' % (field, k) for k in range(3)]
+    assert os.path.exists(os.path.join(str(tmp_path), 'label_map', 'label_map_00000.pvd'))
     assert os.path.exists(os.path.join(str(tmp_path), 'solution_timeseries.npz'))
     c_first = sim.solution.components[1].copy()
     # run_for_adjoint: same mesh / space / device discretisation, new scalar parameters (stg:142-155)
@@ -201,7 +203,7 @@ def test_config_2d_uniform_script(tmp_path):
     um, cm = o.run(iv(mesh.points), 5.0, monolithic=True)
     assert rel_l2(sol.components[1], co) < 1e-9 and rel_l2(sol.components[0].reshape(-1), uo) < 1e-8
     assert rel_l2(sol.components[1], cm) < 1e-9 and rel_l2(sol.components[0].reshape(-1), um) < 1e-8
-    assert len([p for p in os.listdir(str(tmp_path)) if p.endswith('.vtu')]) == 6
+    assert len([p for p in os.listdir(os.path.join(str(tmp_path), 'concentration')) if p.endswith('.pvd')]) == 6
     sim.close()
 
 

@@ -221,8 +221,11 @@ def test_results_roundtrip(tmp_path):
     assert res2.get_recording_steps() == [0, 1, 2]
     assert (res2.get_solution_function(subspace_id=1, recording_step=2).values() == 2).all()
     res.save_solution(2, 2.0, method='vtk')
-    txt = open(os.path.join(str(tmp_path), 'solution_00002.vtu')).read()
-    assert 'concentration' in txt and 'displacement' in txt and 'NumberOfPoints="16"' in txt
+    txt = open(os.path.join(str(tmp_path), 'concentration', 'concentration_00002000000.vtu')).read()
+    assert 'concentration' in txt and 'NumberOfPoints="16"' in txt
+    assert 'concentration_00002000000.vtu' in open(os.path.join(str(tmp_path), 'concentration',
+                                                                'concentration_00002.pvd')).read()
+    assert os.path.isfile(os.path.join(str(tmp_path), 'displacement', 'displacement_00002.pvd'))
 
 
 def test_partition_plans_are_mutually_consistent():
