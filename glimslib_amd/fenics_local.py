@@ -425,6 +425,47 @@ class Function:
         return out[0] if len(out) == 1 else out
 
 
+class DG1Function:
+    """Piecewise-linear discontinuous scalar: one value per (cell, vertex).  What ``project(expr, FunctionSpace(mesh,
+    "DG", 1))`` returns; the reference builds its label functions that way (test_baseImplementation.py:18-20,
+    test_unit_subDomains.py:14-16).  For data that is P1 on every cell the L2 projection onto DG1 is the cell-wise
+    interpolant, which is what is stored."""
+
+    def __init__(self, mesh, cell_vertex_values):
+        self.mesh = mesh
+        self.cell_vertex_values = np.asarray(cell_vertex_values, dtype=np.float64)
+
+    def __array__(self, dtype=None, copy=None):
+        return self.cell_vertex_values if dtype is None else self.cell_vertex_values.astype(dtype)
+
+    def at_midpoints(self):
+        return self.cell_vertex_values.mean(axis=1)
+
+
+class FunctionSpace:
+    """``fenics.FunctionSpace(mesh, family, degree)`` descriptor: Lagrange ("CG" / "Lagrange" / "P") or "DG", degree 1
+    (scalar).  The mixed solution space of the models is simulation_helpers.helper_classes.FunctionSpace."""
+
+    def __init__(self, mesh, family, degree=1):
+        fam = {"Lagrange": "CG", "P": "CG", "CG": "CG", "DG": "DG", "Discontinuous Lagrange": "DG"}.get(str(family))
+        if fam is None or int(degree) != 1:
+            raise NotImplementedError("only CG1 / DG1 spaces are available")
+        self._mesh, self.family, self.degree = mesh, fam, 1
+
+    def mesh(self):
+        return self._mesh
+
+
+def project(expr, space, **kwargs):
+    """``fenics.project`` for the two spaces above: nodal interpolation on CG1 (see interpolate_nodal), cell-wise
+    interpolation on DG1.  Solver keyword arguments of the reference's calls are accepted and ignored."""
+    mesh = space.mesh() if callable(getattr(space, "mesh", None)) else space._mesh
+    if getattr(space, "family", "CG") == "DG":
+        nodal = interpolate_nodal(expr, mesh, 1)
+        return DG1Function(mesh, nodal[mesh.cells])
+    return Function(mesh, {None: interpolate_nodal(expr, mesh, 1)}, space=space)
+
+
 def interpolate_nodal(expr, mesh, value_size=1):
     """Nodal values of a Constant / Expression / callable / array / Function on the mesh vertices."""
     n = mesh.num_vertices()

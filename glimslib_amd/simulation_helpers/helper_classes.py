@@ -362,6 +362,8 @@ class SubDomains:
         cells = self._mesh.cells
         if isinstance(label_function, Function):
             vals = label_function.values()[cells]
+        elif isinstance(label_function, fenics.DG1Function):
+            vals = label_function.cell_vertex_values
         elif isinstance(label_function, (Expression, Constant)) or callable(label_function):
             vals = np.asarray(label_function(self._mesh.points), dtype=np.float64)[cells]
         else:

@@ -208,10 +208,10 @@ def read_mha(path):
     return dict(array=arr.reshape(shape).astype(dtype.newbyteorder('=')), origin=origin, spacing=spacing)
 
 
-def write_mha(path, array, origin=None, spacing=None, compressed=False):
+def write_mha(path, array, origin=None, spacing=None, compressed=False, channels=False):
     array = np.ascontiguousarray(array)
     met = {v: k for k, v in _MET.items()}[array.dtype.type]
-    dims = list(reversed(array.shape))
+    dims = list(reversed(array.shape[:-1] if channels else array.shape))
     origin = origin or [0.0] * len(dims)
     spacing = spacing or [1.0] * len(dims)
     data = array.tobytes()
@@ -219,7 +219,9 @@ def write_mha(path, array, origin=None, spacing=None, compressed=False):
            "CompressedData = %s" % ("True" if compressed else "False"),
            "Offset = %s" % " ".join(repr(float(v)) for v in origin),
            "ElementSpacing = %s" % " ".join(repr(float(v)) for v in spacing),
-           "DimSize = %s" % " ".join(str(v) for v in dims), "ElementType = %s" % met, "ElementDataFile = LOCAL"]
+           "DimSize = %s" % " ".join(str(v) for v in dims)] + \
+          (["ElementNumberOfChannels = %d" % array.shape[-1]] if channels else []) + \
+          ["ElementType = %s" % met, "ElementDataFile = LOCAL"]
     with open(path, 'wb') as f:
         f.write(("\n".join(hdr) + "\n").encode())
         f.write(zlib.compress(data) if compressed else data)
@@ -252,6 +254,113 @@ def sample_image_at_points(image, points, order='nearest'):
     for k in range(d):
         ijk[:, k] = np.clip(ijk[:, k], 0, a.shape[d - 1 - k] - 1)
     return a[tuple(ijk[:, k] for k in reversed(range(d)))]
+
+
+# ---- functions <-> images (data_io.py:101-227, 363-411) ------------------------------------------------------------------
+class Image:
+    """What the reference passes around as a SimpleITK image, reduced to the parts its converters touch: a voxel array
+    in sitk.GetArrayFromImage order ([z,] y, x [, component]), origin, spacing.  Files: MetaImage (.mha)."""
+
+    def __init__(self, array, origin=None, spacing=None, is_vector=False):
+        self.array = np.asarray(array)
+        self.is_vector = bool(is_vector)
+        self.dim = self.array.ndim - (1 if self.is_vector else 0)
+        self.origin = tuple(float(v) for v in (origin if origin is not None else [0.0] * self.dim))
+        self.spacing = tuple(float(v) for v in (spacing if spacing is not None else [1.0] * self.dim))
+
+    # SimpleITK-flavoured accessors used by the reference's helpers
+    def GetOrigin(self):
+        return self.origin
+
+    def GetSpacing(self):
+        return self.spacing
+
+    def GetDimension(self):
+        return self.dim
+
+    def GetSize(self):
+        return tuple(reversed(self.array.shape[:self.dim]))
+
+    def GetNumberOfComponentsPerPixel(self):
+        return self.array.shape[-1] if self.is_vector else 1
+
+    def write(self, path, compressed=False):
+        write_mha(path, self.array, list(self.origin), list(self.spacing), compressed, channels=self.is_vector)
+
+    @staticmethod
+    def read(path):
+        d = read_mha(path)
+        return Image(d['array'], d['origin'], d['spacing'], is_vector=d['array'].ndim > len(d['spacing']))
+
+
+def compute_spacing(number_list):
+    diff = np.diff(np.asarray(number_list, dtype=np.float64))
+    if len(diff) and np.allclose(diff, diff[0], 1e-4):
+        return float(diff[0])
+    return 0.0
+
+
+def get_measures_from_structured_mesh(mesh):
+    """origin, size (points per axis), spacing, extent [2, dim], dim of a structured (box) mesh."""
+    coords = mesh.points
+    dim = coords.shape[1]
+    size = np.zeros(dim, dtype=int)
+    spacing = np.zeros(dim)
+    extent = np.zeros((2, dim))
+    for i in range(dim):
+        u = np.unique(np.round(coords[:, i], 12))
+        size[i], extent[0, i], extent[1, i], spacing[i] = len(u), u.min(), u.max(), compute_spacing(u)
+    return extent[0].copy(), size, spacing, extent, dim
+
+
+def get_measures_from_function(function):
+    origin, size, spacing, extent, dim = get_measures_from_structured_mesh(function.mesh)
+    v = function.values()
+    return origin, size, spacing, extent, dim, (1 if v.ndim == 1 else v.shape[1])
+
+
+def get_measures_from_image(image):
+    origin, spacing, dim = np.array(image.GetOrigin()), np.array(image.GetSpacing()), image.GetDimension()
+    size = np.array(image.GetSize(), dtype=int)
+    extent = np.stack([origin, origin + spacing * (size - 1)])
+    return origin, size, spacing, extent, dim, image.GetNumberOfComponentsPerPixel()
+
+
+def create_image_from_fenics_function(function, size_new=None):
+    """Samples a P1 function of a structured mesh on the regular grid of its vertices (or on `size_new` points per
+    axis) -> Image.  On the mesh's own grid the samples are the nodal values (one sort, no point location)."""
+    origin, size, spacing, extent, dim, vdim = get_measures_from_function(function)
+    vals = function.values()
+    if size_new is None or tuple(size_new) == tuple(size):
+        ijk = np.rint((function.mesh.points - origin) / spacing).astype(np.int64)
+        shape = tuple(reversed(size)) + ((vdim,) if vdim > 1 else ())
+        arr = np.full(shape, np.nan)
+        arr[tuple(ijk[:, k] for k in reversed(range(dim)))] = vals
+        return Image(arr, origin, spacing, is_vector=vdim > 1)
+    size_new = np.asarray(size_new, dtype=int)
+    axes = [np.linspace(extent[0, i], extent[1, i], size_new[i]) for i in range(dim)]
+    grid = np.stack(np.meshgrid(*axes, indexing='ij'), axis=-1).reshape(-1, dim)
+    sampled = np.asarray(function(grid))                         # P1 evaluation (small grids only)
+    arr = sampled.reshape(tuple(size_new) + ((vdim,) if vdim > 1 else ()))
+    arr = np.swapaxes(arr, 0, dim - 1) if dim > 1 else arr
+    return Image(arr, origin, [compute_spacing(a) for a in axes], is_vector=vdim > 1)
+
+
+def create_fenics_function_from_image(image):
+    """One vertex per voxel: Rectangle/BoxMesh with (size - 1) cells per axis over the image extent, voxel values as
+    nodal values (scalar or vector)."""
+    from ..fenics_local import Function
+    from ..mesh import BoxMesh
+    origin, size, spacing, extent, dim, vdim = get_measures_from_image(image)
+    n = [int(s) - 1 for s in size]
+    mesh = RectangleMesh(tuple(extent[0]), tuple(extent[1]), *n) if dim == 2 else \
+        BoxMesh(tuple(extent[0]), tuple(extent[1]), *n)
+    a = np.asarray(image.array, dtype=np.float64)
+    vals = a.reshape(-1, vdim) if vdim > 1 else a.reshape(-1)     # [z,] y, x order == DOLFIN's vertex order of box meshes
+    return Function(mesh, {None: vals})
+
+
+create_fenics_function_from_image_quick = create_fenics_function_from_image
 
 
 # ---- containers --------------------------------------------------------------------------------------------------------

@@ -196,3 +196,84 @@ def test_function_space():
     assert double.subspaces.project_over_subspace(spot, subspace_name='concentration').values().shape == (36,)
     with pytest.raises(NotImplementedError):
         fenics.FiniteElement("Lagrange", mesh.ufl_cell(), 2)            # the device path is P1 only
+
+
+# ---- glimslib/simulation/test_baseImplementation.py ---------------------------------------------------------------
+class _Boundary(fenics.SubDomain):
+    def inside(self, x, on_boundary):
+        return on_boundary
+
+
+def test_base_implementation_setup():
+    """setup_global_parameters / setup_model_parameters with the reference's own arguments, including its DG1 label
+    function and its stale BC keys ('boundary_id', 'boundary_name'): the BC dictionaries keep all entries, only
+    the recognisable ones become constraints (warnings for the others)."""
+    from glimslib_amd.simulation.simulation_tumor_growth import TumorGrowth
+    mesh = fenics.RectangleMesh(fenics.Point(-2, -2), fenics.Point(2, 2), 10, 10)
+    sim = TumorGrowth(mesh)
+    labels = fenics.project(fenics.Expression('(x[0]>=0.5) ? (1.0) : (2.0)', degree=1),
+                            fenics.FunctionSpace(mesh, "DG", 1))
+    tissue_map = {0: 'outside', 1: 'tissue', 2: 'tumor'}
+    dirichlet = {'clamped_0': {'bc_value': fenics.Constant((0.0, 0.0)), 'boundary': _Boundary(), 'subspace_id': 0},
+                 'clamped_1': {'bc_value': fenics.Constant((0.0, 0.0)), 'boundary_id': 0, 'subspace_id': 0},
+                 'clamped_2': {'bc_value': fenics.Constant((0.0, 0.0)), 'boundary_name': 'boundary_1', 'subspace_id': 0}}
+    neumann = {'no_flux': {'bc_value': fenics.Constant(0.0), 'boundary_id': 0, 'subspace_id': 1},
+               'no_flux_2': {'bc_value': fenics.Constant(0.0), 'boundary_name': 'boundary_1', 'subspace_id': 1}}
+    sim.setup_global_parameters(label_function=labels, domain_names=tissue_map,
+                                boundaries={'boundary_1': _Boundary(), 'boundary_2': _Boundary()},
+                                dirichlet_bcs=dirichlet, von_neumann_bcs=neumann)
+    assert hasattr(sim, 'subdomains') and hasattr(sim.subdomains, 'subdomain_boundaries')
+    assert hasattr(sim.functionspace, 'element') and hasattr(sim.functionspace, 'subspaces')
+    # The reference's test expects 3 Dirichlet / 2 Neumann conditions, but at this commit its own constructors only
+    # recognise 'boundary' / 'subdomain_boundary' / 'named_boundary' (helper_classes.py:684-721, 812-828): the
+    # 'boundary_id' / 'boundary_name' entries are logged as incomplete and dropped.  Same here.
+    assert len(sim.bcs.dirichlet_bcs_dict) == 3 and len(sim.bcs.dirichlet_bcs) == 1
+    assert len(sim.bcs.von_neumann_bcs_dict) == 2 and len(sim.bcs.von_neumann_bcs) == 0
+    assert set(np.unique(sim.subdomains.subdomains.array())) == {1, 2}
+    spot = fenics.Expression('sqrt(pow(x[0]-x0,2)+pow(x[1]-y0,2)) < 0.1 ? (1.0) : (0.0)', degree=1, x0=0.25, y0=0.5)
+    disp0 = fenics.Constant((0.0, 0.0))
+    youngmod = {'outside': 10E6, 'tissue': 1, 'tumor': 1000}
+    poisson = {'outside': 0.4, 'tissue': 0.4, 'tumor': 0.49}
+    sim.setup_model_parameters(iv_expression={0: disp0, 1: spot}, diffusion=1, coupling=1, proliferation=1,
+                               E=youngmod, poisson=poisson, otherparam=1, sim_time=10, sim_time_step=1)
+    assert sim.params.get_iv(0) is disp0
+    assert hasattr(sim.params, 'E') and not hasattr(sim.params, 'otherparam')
+    assert sim.params.sim_time == 10 and sim.params.sim_time_step == 1
+
+
+# ---- glimslib/utils/test_unit_data_io.py --------------------------------------------------------------------------
+@pytest.mark.parametrize("dim,vector", [(2, False), (2, True), (3, False), (3, True)])
+def test_function_image_round_trips(tmp_path, dim, vector):
+    """function -> image -> file -> image -> function, nine times over, stays within 1e-5 (the reference's bound) --
+    here it is exact, since nodal values are copied.  SimpleITK / .nii become the Image container / .mha."""
+    import glimslib_amd.utils.data_io as dio
+    if dim == 2:
+        mesh = fenics.RectangleMesh(fenics.Point(-2, -2), fenics.Point(2, 2), 40, 20)
+        spot = fenics.Expression('sqrt(pow(x[0]-x0,2)+pow(x[1]-y0,2)) < 1 ? (1.0) : (0.0)', degree=1, x0=1, y0=1)
+        const = fenics.Constant((1.0, 1.0))
+    else:
+        mesh = fenics.BoxMesh(fenics.Point(-2, -2, -2), fenics.Point(2, 2, 2), 10, 20, 30)
+        spot = fenics.Expression('sqrt(pow(x[0]-x0,2)+pow(x[1]-y0,2)+pow(x[2]-z0,2)) < 1 ? (1.0) : (0.0)', degree=1,
+                                 x0=1, y0=1, z0=1)
+        const = fenics.Constant((1.0, 1.0, 1.0))
+    if vector:
+        vals = fenics.interpolate_nodal(const, mesh, dim) * (1.0 + 0.1 * mesh.points[:, :1])     # not just a constant
+    else:
+        vals = fenics.interpolate_nodal(spot, mesh, 1)
+    funs = [fenics.Function(mesh, {None: vals})]
+    for i in range(1, 10):
+        img = dio.create_image_from_fenics_function(funs[i - 1], size_new=None)
+        path = os.path.join(str(tmp_path), 'image_from_function_%d.mha' % i)
+        img.write(path, compressed=(i % 2 == 0))
+        img_read = dio.Image.read(path)
+        assert img_read.GetSize() == tuple(n + 1 for n in ((40, 20) if dim == 2 else (10, 20, 30)))
+        assert img_read.GetNumberOfComponentsPerPixel() == (dim if vector else 1)
+        funs.append(dio.create_fenics_function_from_image(img_read))
+        assert fenics.errornorm(funs[i - 1], funs[i]) < 1e-5
+        assert np.allclose(funs[i].mesh.points, mesh.points) and np.array_equal(funs[i].mesh.cells, mesh.cells)
+    assert np.array_equal(funs[-1].values(), vals)
+    # resampling on a coarser grid goes through P1 evaluation
+    if dim == 2 and not vector:
+        coarse = dio.create_image_from_fenics_function(funs[0], size_new=(21, 11))
+        assert coarse.GetSize() == (21, 11) and np.allclose(coarse.GetSpacing(), (0.2, 0.4))
+        assert np.allclose(coarse.array, dio.create_image_from_fenics_function(funs[0]).array[::2, ::2])
