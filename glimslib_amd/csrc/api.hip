@@ -27,6 +27,7 @@ void read_tuning(glims_ctx* h) {
   if (const char* e = getenv("GLIMS_RD_REMAP")) h->tune_rd_remap = atoi(e);
   if (const char* e = getenv("GLIMS_RD_UNROLL")) h->tune_rd_unroll = atoi(e);
   if (const char* e = getenv("GLIMS_IDX16")) h->tune_idx16 = atoi(e);
+  if (const char* e = getenv("GLIMS_BLK_VARIANT")) h->tune_blk_variant = atoi(e);
   if (const char* e = getenv("GLIMS_DEFER")) h->tune_defer = atoi(e);
   if (const char* e = getenv("GLIMS_DEFER_EXTRA")) h->tune_defer_extra = std::max(1, atoi(e));
 }

@@ -163,7 +163,7 @@ struct glims_ctx {
   glims_options opt;
   glims_stats stats;
   // tuning knobs (env GLIMS_SPMV_UNROLL = 4|8, GLIMS_XCD_REMAP = 0 plain | 1 eighths | G chunk, GLIMS_SPMV_NT = 0|1), read at glims_create and by glims_apply
-  int tune_spmv_unroll = 4, tune_xcd_remap = 64, tune_rd_remap = 64, tune_spmv_nt = 1, tune_rd_nt = 0, tune_rd_unroll = 24, tune_idx16 = 1, tune_defer = 1, tune_defer_extra = 2;
+  int tune_spmv_unroll = 4, tune_xcd_remap = 64, tune_rd_remap = 64, tune_spmv_nt = 1, tune_rd_nt = 0, tune_rd_unroll = 24, tune_idx16 = 1, tune_defer = 1, tune_defer_extra = 2, tune_blk_variant = 1;
   int64_t stats_defer_miss = 0;
 
   // scalar operator planes (SELL-64 layout) and block planes

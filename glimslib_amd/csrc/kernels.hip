@@ -531,6 +531,74 @@ __global__ __launch_bounds__(256) void k_spmv_block(int n_launch, int chunk,
   }
 }
 
+// Pipelined block SpMV: KB block entries per batch -- all column loads, then all KB*BS*BS value loads (non-temporal:
+// streamed once), then the gathers, then the FMAs; ragged tail as one clamped batch; blocks dealt to the XCDs in
+// chunks like the scalar kernel (the contiguous-eighths mapping of the first version costs 15 % on the scalar SpMV).
+template <int BS, int DOTS, int KB>
+__global__ __launch_bounds__(256) void k_spmv_block2(int n_launch, int chunk, const int32_t* __restrict__ slice_list,
+                                                      int64_t n_own, const int64_t* __restrict__ slice_ptr,
+                                                      const int32_t* __restrict__ cols,
+                                                      const double* __restrict__ vals, const double* __restrict__ x,
+                                                      double* __restrict__ y, const uint8_t* __restrict__ fixed,
+                                                      const double* __restrict__ r, double* __restrict__ partials,
+                                                      int partial_off, const int* __restrict__ done, int remap) {
+  if (done && *done) return;
+  constexpr int B2 = BS * BS;
+  const int b = remap > 1 ? xcd_chunk_remap(blockIdx.x, gridDim.x, remap) : blockIdx.x;
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int s_end = min(n_launch, (b + 1) * chunk);
+  double pd = 0.0;
+  for (int si = b * chunk + wid; si < s_end; si += 4) {
+    const int s = slice_list ? slice_list[si] : si;
+    const int64_t row = (int64_t)s * GL_WAVE + lane;
+    const int64_t base = slice_ptr[s];
+    const int len = (int)((slice_ptr[s + 1] - base) >> 6);
+    const int32_t* cc = cols + base + lane;
+    const double* vb = vals + base * B2 + lane;
+    double acc[BS];
+#pragma unroll
+    for (int a = 0; a < BS; ++a) acc[a] = 0.0;
+    for (int k = 0; k < len; k += KB) {
+      int32_t cj[KB];
+      double v[KB][B2], xj[KB][BS];
+#pragma unroll
+      for (int j = 0; j < KB; ++j) cj[j] = __builtin_nontemporal_load(cc + (int64_t)min(k + j, len - 1) * GL_WAVE);
+#pragma unroll
+      for (int j = 0; j < KB; ++j) {
+        const double* vk = vb + (int64_t)min(k + j, len - 1) * (GL_WAVE * B2);
+#pragma unroll
+        for (int e = 0; e < B2; ++e) v[j][e] = __builtin_nontemporal_load(vk + e * GL_WAVE);
+      }
+#pragma unroll
+      for (int j = 0; j < KB; ++j)
+#pragma unroll
+        for (int bb = 0; bb < BS; ++bb) xj[j][bb] = (k + j < len) ? x[(int64_t)cj[j] * BS + bb] : 0.0;
+#pragma unroll
+      for (int j = 0; j < KB; ++j)
+#pragma unroll
+        for (int a = 0; a < BS; ++a)
+#pragma unroll
+          for (int bb = 0; bb < BS; ++bb) acc[a] += v[j][a * BS + bb] * xj[j][bb];
+    }
+    if (row < n_own) {
+#pragma unroll
+      for (int a = 0; a < BS; ++a) {
+        double v = acc[a];
+        if (fixed && fixed[row * BS + a]) v = 0.0;
+        y[row * BS + a] = v;
+        if (DOTS) pd += v * x[row * BS + a];
+      }
+    }
+  }
+  if (DOTS) {
+    __shared__ double red[4];
+    pd = wave_sum(pd);
+    if (lane == 0) red[wid] = pd;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[(size_t)(partial_off + b)] = red[0] + red[1] + red[2] + red[3];
+  }
+}
+
 // y[(row,a)] = sum_k G[(row,a),col_k] c[col_k]
 template <int BS>
 __global__ __launch_bounds__(256) void k_apply_G(int n_slices, int64_t n_own, const int64_t* __restrict__ slice_ptr,
@@ -718,8 +786,20 @@ void gl_launch_spmv_block(glims_ctx* h, hipStream_t st, int n_launch, const int3
   const int chunk = (n_launch + grid - 1) / grid;
   const int remap = slice_list ? 0 : 1;
 #define GL_BLK(BS, DOTS)                                                                                         \
-  hipLaunchKernelGGL((k_spmv_block<BS, DOTS>), dim3(grid), dim3(256), 0, st, n_launch, chunk, slice_list,         \
-                     h->n_own, p.slice_ptr.p, p.cols.p, h->vKel.p, x, y, fixed, r, partials, partial_off, done, remap)
+  do {                                                                                                           \
+    if (h->tune_blk_variant == 1)                                                                                \
+      hipLaunchKernelGGL((k_spmv_block2<BS, DOTS, 2>), dim3(grid), dim3(256), 0, st, n_launch, chunk, slice_list, \
+                         h->n_own, p.slice_ptr.p, p.cols.p, h->vKel.p, x, y, fixed, r, partials, partial_off,     \
+                         done, slice_list ? 0 : h->tune_xcd_remap);                                              \
+    else if (h->tune_blk_variant == 2)                                                                           \
+      hipLaunchKernelGGL((k_spmv_block2<BS, DOTS, 4>), dim3(grid), dim3(256), 0, st, n_launch, chunk, slice_list, \
+                         h->n_own, p.slice_ptr.p, p.cols.p, h->vKel.p, x, y, fixed, r, partials, partial_off,     \
+                         done, slice_list ? 0 : h->tune_xcd_remap);                                              \
+    else                                                                                                         \
+      hipLaunchKernelGGL((k_spmv_block<BS, DOTS>), dim3(grid), dim3(256), 0, st, n_launch, chunk, slice_list,     \
+                         h->n_own, p.slice_ptr.p, p.cols.p, h->vKel.p, x, y, fixed, r, partials, partial_off,     \
+                         done, remap);                                                                           \
+  } while (0)
   if (h->dim == 2) {
     if (r) GL_BLK(2, 1); else GL_BLK(2, 0);
   } else {

@@ -453,3 +453,24 @@ def test_column_index_streams_are_bitwise_equivalent(backend, monkeypatch):
         for o in outs[1:]:
             for a, b in zip(o[2:], outs[0][2:]):
                 assert np.array_equal(a, b)
+
+
+def test_headline_config_c4_matches_the_c_oracle(backend):
+    """BASELINE config C4 at its full size (10 077 696 DoF, 59.6 M tetrahedra): two implicit steps on the device against
+    the independent C/OpenMP oracle run on the host cores (about half a minute of CPU work)."""
+    from oracle.c_port import COracle
+    w = workloads.config_c4()
+    co = COracle(w.mesh.points, w.mesh.cells, w.per_cell('D'), w.per_cell('rho'), w.dt)
+    ref = co.step(w.c0, 2, rtol=1e-11, cg_rtol=1e-4)
+    del co
+    h = _handle(backend, w.mesh, w.cell_label, w.dt, w.tables, mechanics=False)
+    h.set_state(w.c0)
+    assert h.step(2) == 0
+    c = h.get_state(want_u=False)[0]
+    st = h.stats()
+    h.close()
+    err = rel_l2(c, ref)
+    print("C4: 2 steps, rel-L2 vs C oracle %.2e (%d rows, %d of %d entries with 16-bit column codes)" %
+          (err, st['n_rows'], st['nnz_idx16'], st['nnz_padded']))
+    assert st['n_rows'] == 10077696 and st['nnz_idx16'] == st['nnz_padded']
+    assert err < 1e-9
