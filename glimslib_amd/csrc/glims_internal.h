@@ -162,8 +162,19 @@ struct glims_ctx {
 
   glims_options opt;
   glims_stats stats;
-  // tuning knobs (env GLIMS_SPMV_UNROLL = 4|8, GLIMS_XCD_REMAP = 0 plain | 1 eighths | G chunk, GLIMS_SPMV_NT = 0|1), read at glims_create and by glims_apply
-  int tune_spmv_unroll = 4, tune_xcd_remap = 64, tune_rd_remap = 64, tune_spmv_nt = 1, tune_rd_nt = 0, tune_rd_unroll = 24, tune_idx16 = 1, tune_defer = 1, tune_defer_extra = 2, tune_blk_variant = 1;
+  // Tuning knobs, defaults = the measured best; environment overrides are read at glims_create
+  // and again by glims_apply (so that tools/ab_*.py can interleave variants in one process):
+  //   GLIMS_SPMV_UNROLL 4|8        entries in flight per lane in the scalar SpMV
+  //   GLIMS_XCD_REMAP   0|1|G      block -> XCD mapping: plain | contiguous eighths | chunks of G blocks (64)
+  //   GLIMS_SPMV_NT     0|1|2      non-temporal loads: none | values + columns | values only
+  //   GLIMS_IDX16       0|1        columns as int32 | as 16-bit (window, offset) codes where a slice allows it
+  //   GLIMS_RD_NT / GLIMS_RD_REMAP / GLIMS_RD_UNROLL (4|8|12|24)   the same for the assembly sweep
+  //   GLIMS_BLK_VARIANT 0|1|2      block SpMV: first version | pipelined, 2 | 4 block entries per batch
+  //   GLIMS_DEFER 0|1, GLIMS_DEFER_EXTRA n   read the linear solve's outcome with the next Newton sweep (1) after
+  //                                enqueuing hint + n iterations, or poll after every batch (0)
+  // setup_host.cpp reads GLIMS_SIGMA (row-sort window) and GLIMS_WIN_LIMIT (max windows per slice, tests).
+  int tune_spmv_unroll = 4, tune_xcd_remap = 64, tune_rd_remap = 64, tune_spmv_nt = 1, tune_rd_nt = 0,
+      tune_rd_unroll = 24, tune_idx16 = 1, tune_defer = 1, tune_defer_extra = 2, tune_blk_variant = 1;
   int64_t stats_defer_miss = 0;
 
   // scalar operator planes (SELL-64 layout) and block planes
