@@ -94,6 +94,16 @@ class FenicsSimulation(ABC):
                 obj.t = time
 
     # -- backend lifetime ----------------------------------------------------------------------------------
+    def _update_mesh_displacements(self, displacement):
+        """
+        simulation_base.py:228-234 (``fenics.ALE.move``): adds the nodal displacement to the mesh coordinates.
+        As in the reference this changes the current mesh and repeated calls add up; the device discretisation of a
+        running simulation is not rebuilt (the reference only uses this for plotting deformed configurations).
+        """
+        u = displacement.values() if hasattr(displacement, 'values') else np.asarray(displacement, dtype=np.float64)
+        self.mesh.points += u.reshape(self.mesh.points.shape)
+        self.mesh._facets = None
+
     def _close_backend(self):
         if self._backend is not None:
             self._backend.close()
