@@ -28,6 +28,7 @@ void read_tuning(glims_ctx* h) {
   if (const char* e = getenv("GLIMS_RD_UNROLL")) h->tune_rd_unroll = atoi(e);
   if (const char* e = getenv("GLIMS_IDX16")) h->tune_idx16 = atoi(e);
   if (const char* e = getenv("GLIMS_BLK_VARIANT")) h->tune_blk_variant = atoi(e);
+  if (const char* e = getenv("GLIMS_LIN_MARGIN")) h->tune_lin_margin = atof(e);
   if (const char* e = getenv("GLIMS_DEFER")) h->tune_defer = atoi(e);
   if (const char* e = getenv("GLIMS_DEFER_EXTRA")) h->tune_defer_extra = std::max(1, atoi(e));
 }

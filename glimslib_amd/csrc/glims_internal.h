@@ -175,6 +175,7 @@ struct glims_ctx {
   // setup_host.cpp reads GLIMS_SIGMA (row-sort window) and GLIMS_WIN_LIMIT (max windows per slice, tests).
   int tune_spmv_unroll = 4, tune_xcd_remap = 64, tune_rd_remap = 64, tune_spmv_nt = 1, tune_rd_nt = 0,
       tune_rd_unroll = 24, tune_idx16 = 1, tune_defer = 1, tune_defer_extra = 2, tune_blk_variant = 1;
+  double tune_lin_margin = 0.5;   // GLIMS_LIN_MARGIN: the last linear solve of a step stops at margin * Newton target
   int64_t stats_defer_miss = 0;
 
   // scalar operator planes (SELL-64 layout) and block planes

@@ -763,7 +763,7 @@ int gl_step(glims_ctx* h, int n_steps) {
         break;
       }
       // A(c_k) delta = -R(c_k);  the update is accumulated straight into c (x0 = 0  <=>  x = c_k)
-      const double tol_lin = std::max(std::max(o.cg_atol, 0.1 * target), o.cg_rtol * nr);
+      const double tol_lin = std::max(std::max(o.cg_atol, h->tune_lin_margin * target), o.cg_rtol * nr);
       if (it == 0 && (o.flags & GLIMS_FLAG_WARM_START) && !extrapolate) {   // both options own the c_old buffer
         // initial guess of the first linear solve = the previous step's total increment: same linear system, same
         // solution, the Krylov iteration just starts closer.  One SpMV with the already assembled A(c^n).

@@ -129,7 +129,9 @@ def test_K1_uniform_field_recurrence_and_K2_mass_conservation(backend):
     m0 = h.apply(2, c0)[0].sum()
     assert h.step(6) == 0
     c, _ = h.get_state(want_u=False)
-    assert abs(h.apply(2, c)[0].sum() - m0) < 1e-11 * abs(m0)
+    # exact with a direct solve; with the iterative one the defect is bounded by the linear residuals, which stop at
+    # half the Newton target (1e-10 relative)
+    assert abs(h.apply(2, c)[0].sum() - m0) < 1e-10 * abs(m0)
     h.close()
 
 
