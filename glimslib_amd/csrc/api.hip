@@ -7,6 +7,8 @@
 #include <cstring>
 #include <mutex>
 
+#include <omp.h>
+
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <unistd.h>
@@ -156,8 +158,17 @@ int glims_create(glims_ctx** out, int dim, int64_t n_nodes, int64_t n_own, int64
     for (int64_t e = 0; e < n_cells; ++e)
       GL_REQUIRE(cell_label[e] >= 0 && cell_label[e] < GL_MAX_LABELS, "cell label outside [0, 256)");
 
+    const bool verbose = getenv("GLIMS_VERBOSE") != nullptr;
+    double t_last = omp_get_wtime();
+    auto lap = [&](const char* what) {
+      if (!verbose) return;
+      const double t = omp_get_wtime();
+      fprintf(stderr, "glims create: %-43s %7.3f s\n", what, t - t_last);
+      t_last = t;
+    };
     HostPattern hp;
     build_host_pattern(hp, dim, n_nodes, n_own, n_cells, xyz, cells);
+    lap("host pattern (total)");
     h->old2new = hp.old2new;
     h->new2old = hp.new2old;
     h->nnz = hp.nnz;
@@ -197,6 +208,7 @@ int glims_create(glims_ctx** out, int dim, int64_t n_nodes, int64_t n_own, int64
       p.bucket_slices.push_back(dv);
     }
 
+    lap("pattern upload");
     std::vector<uint8_t> lab(n_cells);
     for (int64_t e = 0; e < n_cells; ++e) lab[e] = (uint8_t)cell_label[e];
     h->label.upload(lab, h->st);
@@ -210,6 +222,7 @@ int glims_create(glims_ctx** out, int dim, int64_t n_nodes, int64_t n_own, int64
       GL_HIP(hipStreamSynchronize(h->st));
     }
 
+    lap("labels, geometry");
     const size_t nn = (size_t)n_nodes, nd = (size_t)n_nodes * dim;
     h->c.alloc_zero(nn, h->st);
     h->c_old.alloc_zero(nn, h->st);

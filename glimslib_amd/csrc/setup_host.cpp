@@ -55,6 +55,14 @@ struct KeyIdx {
 
 void build_host_pattern(HostPattern& hp, int dim, int64_t n_nodes, int64_t n_own, int64_t n_cells,
                         const double* xyz, const int32_t* cells) {
+  const bool verbose = getenv("GLIMS_VERBOSE") != nullptr;
+  double t_last = omp_get_wtime();
+  auto lap = [&](const char* what) {
+    if (!verbose) return;
+    const double t = omp_get_wtime();
+    fprintf(stderr, "glims setup: %-44s %7.3f s\n", what, t - t_last);
+    t_last = t;
+  };
   GL_REQUIRE(dim == 2 || dim == 3, "dim must be 2 or 3");
   GL_REQUIRE(n_own > 0 && n_own <= n_nodes, "need 0 < n_own <= n_nodes");
   GL_REQUIRE(n_nodes < (int64_t(1) << 31) - 64, "too many nodes for 32-bit local indices");
@@ -69,11 +77,14 @@ void build_host_pattern(HostPattern& hp, int dim, int64_t n_nodes, int64_t n_own
   for (int64_t i = 0; i < n_cells * nv; ++i)
     GL_REQUIRE(cells[i] >= 0 && cells[i] < n_nodes, "cell vertex index out of range");
 
+  lap("validate connectivity");
   // ---- 1. node -> cell adjacency of owned nodes (cells ascending inside each list) ------------------
+  // (serial on purpose: 24 M scattered increments take 0.45 s at C4; the same loops with OpenMP atomics on the
+  //  box's 128 hardware threads took 1.0 s)
   std::vector<int64_t> adj_ptr(n_own + 1, 0);
   for (int64_t e = 0; e < n_cells; ++e)
     for (int m = 0; m < nv; ++m) {
-      int32_t v = cells[e * nv + m];
+      const int32_t v = cells[e * nv + m];
       if (v < n_own) adj_ptr[v + 1]++;
     }
   for (int64_t i = 0; i < n_own; ++i) adj_ptr[i + 1] += adj_ptr[i];
@@ -83,46 +94,58 @@ void build_host_pattern(HostPattern& hp, int dim, int64_t n_nodes, int64_t n_own
     std::vector<int64_t> fill(adj_ptr.begin(), adj_ptr.end() - 1);
     for (int64_t e = 0; e < n_cells; ++e)
       for (int m = 0; m < nv; ++m) {
-        int32_t v = cells[e * nv + m];
+        const int32_t v = cells[e * nv + m];
         if (v < n_own) adj[fill[v]++] = (int32_t)e;
       }
   }
   for (int64_t i = 0; i < n_own; ++i)
     GL_REQUIRE(adj_ptr[i + 1] > adj_ptr[i], "owned node " + std::to_string(i) + " belongs to no cell (orphaned vertex)");
 
+  lap("node -> cell adjacency");
   // ---- 2. neighbour lists (old numbering, sorted, diagonal included) ---------------------------------
+  // one pass: every thread collects the lists of a contiguous range of rows into its own arena; the global
+  // offsets follow from a prefix sum of the lengths, then the arenas are copied into place
   std::vector<int64_t> nbr_ptr(n_own + 1, 0);
-  auto collect = [&](int64_t i, int32_t* buf) -> int {
-    int cnt = 0;
-    for (int64_t q = adj_ptr[i]; q < adj_ptr[i + 1]; ++q) {
-      const int32_t* cv = cells + (int64_t)adj[q] * nv;
-      for (int m = 0; m < nv; ++m) buf[cnt++] = cv[m];
-    }
-    std::sort(buf, buf + cnt);
-    return (int)(std::unique(buf, buf + cnt) - buf);
-  };
   int64_t max_adj = 0;
   for (int64_t i = 0; i < n_own; ++i) max_adj = std::max(max_adj, adj_ptr[i + 1] - adj_ptr[i]);
-#pragma omp parallel
+  std::vector<int32_t> nbr;
   {
-    std::vector<int32_t> buf(max_adj * nv + 4);
-#pragma omp for schedule(static)
-    for (int64_t i = 0; i < n_own; ++i) nbr_ptr[i + 1] = collect(i, buf.data());
+    const int nt = omp_get_max_threads();
+    std::vector<std::vector<int32_t>> arena(nt);
+    std::vector<int64_t> lo_row(nt + 1, 0);
+#pragma omp parallel num_threads(nt)
+    {
+      const int t = omp_get_thread_num(), nth = omp_get_num_threads();
+      const int64_t r0 = n_own * t / nth, r1 = n_own * (t + 1) / nth;
+      lo_row[t] = r0;
+      if (t == nth - 1)
+        for (int q = nth; q <= nt; ++q) lo_row[q] = n_own;
+      std::vector<int32_t>& out = arena[t];
+      out.reserve((size_t)((adj_ptr[r1] - adj_ptr[r0]) * 3 / 4 + 64));
+      std::vector<int32_t> buf(max_adj * nv + 4);
+      for (int64_t i = r0; i < r1; ++i) {
+        int cnt = 0;
+        for (int64_t q = adj_ptr[i]; q < adj_ptr[i + 1]; ++q) {
+          const int32_t* cv = cells + (int64_t)adj[q] * nv;
+          for (int m = 0; m < nv; ++m) buf[cnt++] = cv[m];
+        }
+        std::sort(buf.begin(), buf.begin() + cnt);
+        const int len = (int)(std::unique(buf.begin(), buf.begin() + cnt) - buf.begin());
+        nbr_ptr[i + 1] = len;
+        out.insert(out.end(), buf.begin(), buf.begin() + len);
+      }
+    }
+    for (int64_t i = 0; i < n_own; ++i) nbr_ptr[i + 1] += nbr_ptr[i];
+    nbr.resize(nbr_ptr[n_own]);
+#pragma omp parallel for schedule(static, 1)
+    for (int t = 0; t < nt; ++t)
+      if (!arena[t].empty())
+        std::memcpy(nbr.data() + nbr_ptr[lo_row[t]], arena[t].data(), sizeof(int32_t) * arena[t].size());
   }
-  for (int64_t i = 0; i < n_own; ++i) nbr_ptr[i + 1] += nbr_ptr[i];
   hp.nnz = nbr_ptr[n_own];
   hp.n_corners = n_corners;
-  std::vector<int32_t> nbr(hp.nnz);
-#pragma omp parallel
-  {
-    std::vector<int32_t> buf(max_adj * nv + 4);
-#pragma omp for schedule(static)
-    for (int64_t i = 0; i < n_own; ++i) {
-      int len = collect(i, buf.data());
-      std::memcpy(nbr.data() + nbr_ptr[i], buf.data(), sizeof(int32_t) * len);
-    }
-  }
 
+  lap("neighbour lists");
   // ---- 3. renumbering: Morton order, then length sort inside sigma windows ---------------------------
   double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
   for (int64_t i = 0; i < n_nodes; ++i)
@@ -170,6 +193,7 @@ void build_host_pattern(HostPattern& hp, int dim, int64_t n_nodes, int64_t n_own
   keys.clear();
   keys.shrink_to_fit();
 
+  lap("Morton + sigma sort");
   // ---- 4. SELL-64 matrix pattern + corner lists ------------------------------------------------------
   const int32_t n_slices = (int32_t)((n_own + GL_WAVE - 1) / GL_WAVE);
   hp.n_slices = n_slices;
@@ -248,6 +272,7 @@ void build_host_pattern(HostPattern& hp, int dim, int64_t n_nodes, int64_t n_own
     }
   }
   for (int32_t s = 0; s < n_slices; ++s) (is_boundary[s] ? hp.boundary_slices : hp.interior_slices).push_back(s);
+  lap("SELL-64 + corner packing");
   // 16-bit (window, offset) column codes: greedy cover of each slice's sorted distinct columns by windows of
   // 2^GL_WIN_BITS columns (optimal for fixed-length intervals); see glims_internal.h
   hp.cols16.assign(hp.cols.size(), 0);
@@ -286,6 +311,7 @@ void build_host_pattern(HostPattern& hp, int dim, int64_t n_nodes, int64_t n_own
     }
   }
   hp.n_compressed = n_comp;
+  lap("16-bit column codes");
   // length classes for the assembly sweep (its LDS footprint is 2 * cap * 64 * 8 B per wave)
   hp.bucket_cap = {16, 24, 32, 48, 64, 96, 128, 255};
   hp.bucket_slices.assign(hp.bucket_cap.size(), {});
