@@ -107,6 +107,8 @@ def main():
             dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
 
+    # HIP events around the Krylov SpMV launches of the timed steps (read by the library at glims_create)
+    os.environ.setdefault("GLIMS_TIME_SPMV", "1")
     from glimslib_amd import workloads
     from glimslib_amd._backend import Handle, GLIMS_OK, FLAG_EXTRAPOLATE_GUESS
     from glimslib_amd.partition import partition_mesh
@@ -187,11 +189,17 @@ def main():
     # ---- roofline of the dominant kernel: SELL-64 SpMV with the RD Jacobian A(c) ------------------------
     # algorithmic bytes per launch = 12*nnz + 20*rows of THIS rank's operator;
     # duration = HIP events on the library's own stream around `reps` back-to-back launches (glims_apply).
+    # (a) inside the timed region: HIP events around every Krylov SpMV launch of the steps (GLIMS_TIME_SPMV, single
+    #     GPU); (b) after it: `spmv_reps` back-to-back launches of the same operator without the fused dot product.
     x = np.random.default_rng(0).standard_normal(h.n_nodes)
     h.apply(0, x, reps=5)
     _, ms = h.apply(0, x, reps=args.spmv_reps)
     t_spmv = ms * 1e-3 / args.spmv_reps
     b_alg = workloads.b_spmv_bytes(st['nnz'], st['n_rows'])
+    t_isolated = t_spmv
+    in_step = st.get('n_spmv_steps', 0) > 0
+    if in_step:
+        t_spmv = st['ms_spmv_steps'] * 1e-3 / st['n_spmv_steps']
     achieved = b_alg / t_spmv / 1e9
     # HBM-side bytes per launch from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate rocprofv3 runs,
     # calibrated on kernels with exactly known byte counts): profiles/r01_pmc_c4.json.  Only reported when this
@@ -200,15 +208,18 @@ def main():
     try:
         pmc = json.load(open(os.path.join(HERE, "profiles", "r01_pmc_c4.json")))
         if world == 1 and pmc["n_rows"] == st['n_rows'] and pmc["nnz"] == st['nnz']:
-            key = [k for k in pmc["kernels"] if k.startswith("k_spmv<0")][0]
+            key = [k for k in pmc["kernels"] if k.startswith("k_spmv<1" if in_step else "k_spmv<0")][0]
             traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
     except Exception:
         traffic = None
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_spmv<0,4,1,1> (SELL-64, fp64 values, "
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": ("k_spmv<1, 4, 1, 1>" if in_step else "k_spmv<0, 4, 1, 1>") + " (SELL-64, fp64 values, "
                 "columns streamed as 16-bit window codes; algorithmic bytes still count 4-byte CSR columns)",
                 "algorithmic_bytes_per_launch": b_alg, "avg_launch_us": t_spmv * 1e6,
-                "launches_timed": args.spmv_reps}
+                "launches_timed": int(st['n_spmv_steps']) if in_step else args.spmv_reps,
+                "timed": "inside the timed steps (k_spmv<1,..>, fused dot product)" if in_step
+                         else "back-to-back launches after the timed steps (k_spmv<0,..>)",
+                "isolated_launch_us": t_isolated * 1e6}
 
     # practical HBM ceiling of THIS device next to the nominal peak: streaming scale kernel y = 2 x over
     # 1 GiB, read + write bytes over the HIP-event time of the fastest of 10 launches (torch is only the allocator / launcher here;

@@ -39,7 +39,8 @@ class Stats(C.Structure):
                 ("cg_its", C.c_int64), ("mech_solves", C.c_int64), ("mech_cg_its", C.c_int64),
                 ("last_newton_res", C.c_double), ("last_cg_res", C.c_double), ("last_mech_res", C.c_double),
                 ("ms_steps", C.c_double), ("ms_spmv", C.c_double), ("n_rows", C.c_int64), ("nnz", C.c_int64),
-                ("nnz_padded", C.c_int64), ("n_corners", C.c_int64), ("nnz_idx16", C.c_int64)]
+                ("nnz_padded", C.c_int64), ("n_corners", C.c_int64), ("nnz_idx16", C.c_int64),
+                ("ms_spmv_steps", C.c_double), ("n_spmv_steps", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

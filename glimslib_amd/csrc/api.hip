@@ -29,6 +29,7 @@ void read_tuning(glims_ctx* h) {
   if (const char* e = getenv("GLIMS_RD_REMAP")) h->tune_rd_remap = atoi(e);
   if (const char* e = getenv("GLIMS_RD_UNROLL")) h->tune_rd_unroll = atoi(e);
   if (const char* e = getenv("GLIMS_IDX16")) h->tune_idx16 = atoi(e);
+  if (const char* e = getenv("GLIMS_TIME_SPMV")) h->time_spmv = atoi(e) != 0;
   if (const char* e = getenv("GLIMS_BLK_VARIANT")) h->tune_blk_variant = atoi(e);
   if (const char* e = getenv("GLIMS_LIN_MARGIN")) h->tune_lin_margin = atof(e);
   if (const char* e = getenv("GLIMS_DEFER")) h->tune_defer = atoi(e);
@@ -280,6 +281,7 @@ int glims_destroy(glims_ctx* h) {
   gl_comm_destroy(h);
   if (getenv("GLIMS_VERBOSE")) fprintf(stderr, "glims: deferred linear solves that ran out of iterations: %lld\n", (long long)h->stats_defer_miss);
   mailbox_close(h);
+  for (hipEvent_t e : h->tev) (void)hipEventDestroy(e);
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
   if (h->ev_a) (void)hipEventDestroy(h->ev_a);
   if (h->ev_b) (void)hipEventDestroy(h->ev_b);
@@ -484,6 +486,7 @@ int glims_reset_stats(glims_ctx* h) {
   h->stats.nnz_padded = keep.nnz_padded;
   h->stats.n_corners = keep.n_corners;
   h->stats.nnz_idx16 = keep.nnz_idx16;
+  h->tev_used = 0;
   h->stats.steps = keep.steps;   // step counter drives the extrapolated guess; keep it
   return GLIMS_OK;
 }

@@ -177,6 +177,10 @@ struct glims_ctx {
       tune_rd_unroll = 24, tune_idx16 = 1, tune_defer = 1, tune_defer_extra = 2, tune_blk_variant = 1;
   double tune_lin_margin = 0.5;   // GLIMS_LIN_MARGIN: the last linear solve of a step stops at margin * Newton target
   int64_t stats_defer_miss = 0;
+  // GLIMS_TIME_SPMV=1: event pairs around the Krylov SpMV launches of glims_step (bench.py's in-step roofline figure)
+  bool time_spmv = false;
+  std::vector<hipEvent_t> tev;
+  size_t tev_used = 0;
 
   // scalar operator planes (SELL-64 layout) and block planes
   dvec<double> vM, vS, vA, vKel, vG;

@@ -606,10 +606,13 @@ static void apply_with_halo(glims_ctx* h, const CgVecs& v) {
   const DevPattern& p = h->pat;
   const bool split = h->world > 1 && h->n_peers > 0;
   if (!split) {
-    if (v.vals)
+    if (v.vals) {
+      const bool timed = h->time_spmv && h->tev_used + 2 <= h->tev.size();
+      if (timed) GL_HIP(hipEventRecord(h->tev[h->tev_used++], h->st));
       gl_launch_spmv(h, h->st, p.n_slices, nullptr, v.vals, v.u, v.w, v.fixed, nullptr, v.r, h->partials.p, 0,
                      h->done.p);
-    else
+      if (timed) GL_HIP(hipEventRecord(h->tev[h->tev_used++], h->st));
+    } else
       gl_launch_spmv_block(h, h->st, p.n_slices, nullptr, v.u, v.w, v.fixed, v.r, h->partials.p, 0, h->done.p);
     return;
   }
@@ -730,6 +733,11 @@ int gl_step(glims_ctx* h, int n_steps) {
   const bool extrapolate = (o.flags & GLIMS_FLAG_EXTRAPOLATE_GUESS) != 0;
   const double* load = h->have_load_rd ? h->load_rd.p : nullptr;
   int status = GLIMS_OK;
+  if (h->time_spmv && h->tev.empty()) {
+    h->tev.resize(8192);
+    for (hipEvent_t& e : h->tev) GL_HIP(hipEventCreate(&e));
+  }
+  h->tev_used = 0;
   GL_HIP(hipEventRecord(h->ev_a, h->st));
   for (int step = 0; step < n_steps && status == GLIMS_OK; ++step) {
     double norms[2] = {0.0, 0.0};
@@ -834,6 +842,21 @@ int gl_step(glims_ctx* h, int n_steps) {
   float ms = 0.f;
   GL_HIP(hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
   h->stats.ms_steps += ms;
+  if (h->tev_used >= 2) {
+    // launches that the decision word turned into no-ops last a few microseconds: leave them out of the average
+    std::vector<float> d(h->tev_used / 2);
+    float dmax = 0.f;
+    for (size_t q = 0; q < d.size(); ++q) {
+      GL_HIP(hipEventElapsedTime(&d[q], h->tev[2 * q], h->tev[2 * q + 1]));
+      dmax = std::max(dmax, d[q]);
+    }
+    for (float t : d)
+      if (t > 0.2f * dmax) {
+        h->stats.ms_spmv_steps += t;
+        h->stats.n_spmv_steps++;
+      }
+    h->tev_used = 0;
+  }
   return status;
 }
 

@@ -78,12 +78,14 @@ typedef struct glims_stats {
   double  last_cg_res;
   double  last_mech_res;
   double  ms_steps;         /* device time of glims_step calls (HIP events on the handle's stream) */
-  double  ms_spmv;          /* accumulated by glims_spmv / glims_bench_* only */
+  double  ms_spmv;          /* accumulated by glims_apply only */
   int64_t n_rows;           /* owned rows */
   int64_t nnz;              /* structural nonzeros of the scalar operator (unpadded) */
   int64_t nnz_padded;       /* stored SELL-64 entries */
   int64_t n_corners;        /* (row, cell) incidences */
   int64_t nnz_idx16;        /* stored entries whose column is streamed as a 16-bit (window, offset) code */
+  double  ms_spmv_steps;    /* GLIMS_TIME_SPMV=1 only: HIP-event time of the Krylov SpMV launches inside glims_step */
+  int64_t n_spmv_steps;     /*   ... and how many of them really ran (launches skipped behind the decision word excluded) */
 } glims_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------------------- */
