@@ -30,6 +30,7 @@ void read_tuning(glims_ctx* h) {
   if (const char* e = getenv("GLIMS_RD_UNROLL")) h->tune_rd_unroll = atoi(e);
   if (const char* e = getenv("GLIMS_IDX16")) h->tune_idx16 = atoi(e);
   if (const char* e = getenv("GLIMS_TIME_SPMV")) h->time_spmv = atoi(e) != 0;
+  if (const char* e = getenv("GLIMS_UPD_NT")) h->tune_upd_nt = atoi(e);
   if (const char* e = getenv("GLIMS_BLK_VARIANT")) h->tune_blk_variant = atoi(e);
   if (const char* e = getenv("GLIMS_LIN_MARGIN")) h->tune_lin_margin = atof(e);
   if (const char* e = getenv("GLIMS_DEFER")) h->tune_defer = atoi(e);

@@ -169,12 +169,13 @@ struct glims_ctx {
   //   GLIMS_SPMV_NT     0|1|2      non-temporal loads: none | values + columns | values only
   //   GLIMS_IDX16       0|1        columns as int32 | as 16-bit (window, offset) codes where a slice allows it
   //   GLIMS_RD_NT / GLIMS_RD_REMAP / GLIMS_RD_UNROLL (4|8|12|24)   the same for the assembly sweep
+  //   GLIMS_UPD_NT      0|1        non-temporal streams in the PCG vector update (everything but u)
   //   GLIMS_BLK_VARIANT 0|1|2      block SpMV: first version | pipelined, 2 | 4 block entries per batch
   //   GLIMS_DEFER 0|1, GLIMS_DEFER_EXTRA n   read the linear solve's outcome with the next Newton sweep (1) after
   //                                enqueuing hint + n iterations, or poll after every batch (0)
   // setup_host.cpp reads GLIMS_SIGMA (row-sort window) and GLIMS_WIN_LIMIT (max windows per slice, tests).
   int tune_spmv_unroll = 4, tune_xcd_remap = 64, tune_rd_remap = 64, tune_spmv_nt = 1, tune_rd_nt = 0,
-      tune_rd_unroll = 24, tune_idx16 = 1, tune_defer = 1, tune_defer_extra = 2, tune_blk_variant = 1;
+      tune_rd_unroll = 24, tune_idx16 = 1, tune_defer = 1, tune_defer_extra = 2, tune_blk_variant = 1, tune_upd_nt = 0;
   double tune_lin_margin = 0.5;   // GLIMS_LIN_MARGIN: the last linear solve of a step stops at margin * Newton target
   int64_t stats_defer_miss = 0;
   // GLIMS_TIME_SPMV=1: event pairs around the Krylov SpMV launches of glims_step (bench.py's in-step roofline figure)

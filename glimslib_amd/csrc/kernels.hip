@@ -468,11 +468,9 @@ __global__ __launch_bounds__(256) void k_spmv(int n_launch, int chunk, const int
     }
   }
   if (DOTS) {
-    __shared__ double red[4];
+    // one partial per WAVE (4 slots per block): no LDS, no block barrier at the end of the kernel
     pd = wave_sum(pd);
-    if (lane == 0) red[wid] = pd;
-    __syncthreads();
-    if (threadIdx.x == 0) partials[(size_t)(partial_off + b)] = red[0] + red[1] + red[2] + red[3];
+    if (lane == 0) partials[(size_t)(partial_off + b) * 4 + wid] = pd;
   }
 }
 
@@ -523,11 +521,9 @@ __global__ __launch_bounds__(256) void k_spmv_block(int n_launch, int chunk,
     }
   }
   if (DOTS) {
-    __shared__ double red[4];
+    // one partial per WAVE (4 slots per block): no LDS, no block barrier at the end of the kernel
     pd = wave_sum(pd);
-    if (lane == 0) red[wid] = pd;
-    __syncthreads();
-    if (threadIdx.x == 0) partials[(size_t)(partial_off + b)] = red[0] + red[1] + red[2] + red[3];
+    if (lane == 0) partials[(size_t)(partial_off + b) * 4 + wid] = pd;
   }
 }
 
@@ -591,11 +587,9 @@ __global__ __launch_bounds__(256) void k_spmv_block2(int n_launch, int chunk, co
     }
   }
   if (DOTS) {
-    __shared__ double red[4];
+    // one partial per WAVE (4 slots per block): no LDS, no block barrier at the end of the kernel
     pd = wave_sum(pd);
-    if (lane == 0) red[wid] = pd;
-    __syncthreads();
-    if (threadIdx.x == 0) partials[(size_t)(partial_off + b)] = red[0] + red[1] + red[2] + red[3];
+    if (lane == 0) partials[(size_t)(partial_off + b) * 4 + wid] = pd;
   }
 }
 
@@ -738,7 +732,8 @@ void gl_rd_assemble(glims_ctx* h, const double* c, const double* b, const double
   GL_HIP(hipGetLastError());
 }
 
-// Blocks per SpMV launch: every block owns a contiguous chunk of slices and emits ONE partial-sum triple.
+// Blocks per SpMV launch: every block owns a contiguous chunk of slices; with fused dots each of its 4 waves emits
+// one partial sum, i.e. a launch fills 4 * gl_spmv_grid() slots.
 // (one slice per wave: ~16x more blocks than fit on the chip, so the dispatcher balances the tail; equal-length
 // persistent blocks measured 25 % slower because 2048 blocks do not fit a residency of 7 blocks/CU in one round)
 int gl_spmv_grid(int n_launch) { return std::max(1, (n_launch + 3) / 4); }

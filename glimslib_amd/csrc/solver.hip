@@ -82,6 +82,17 @@ __global__ __launch_bounds__(256) void k_cg_init(int64_t n_own, const double* __
   block_sum2(pg, pr, pv);
 }
 
+__device__ __forceinline__ double2 ntload2(const double2* p) {
+  double2 v;
+  v.x = __builtin_nontemporal_load(&p->x);
+  v.y = __builtin_nontemporal_load(&p->y);
+  return v;
+}
+__device__ __forceinline__ void ntstore2(double2* p, const double2 v) {
+  __builtin_nontemporal_store(v.x, &p->x);
+  __builtin_nontemporal_store(v.y, &p->y);
+}
+
 // Chronopoulos-Gear recurrence + vector update in one kernel.
 //   red = (gamma = r.u, delta = w.u, rr = r.r), already global sums (gamma, rr from the previous launch of this kernel
 //   or k_cg_init, delta from the SpMV).  Every thread derives alpha/beta from `red`
@@ -95,7 +106,7 @@ __global__ __launch_bounds__(256) void k_cg_update(int64_t n_own, const double* 
                                                     double* __restrict__ p, double* __restrict__ s,
                                                     double* __restrict__ x, double* __restrict__ r,
                                                     double* __restrict__ u, const double* __restrict__ w,
-                                                    const double* __restrict__ dinv, double* __restrict__ pv) {
+                                                    const double* __restrict__ dinv, double* __restrict__ pv, int nt) {
   if (*done) return;
   const double gamma = red[0], delta = red[1], rr = red[2];
   const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
@@ -139,8 +150,15 @@ __global__ __launch_bounds__(256) void k_cg_update(int64_t n_own, const double* 
     const double2* w2 = reinterpret_cast<const double2*>(w);
     const double2* d2 = reinterpret_cast<const double2*>(dinv);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
-      const double2 uu = u2[i], pp = p2[i], ww = w2[i], ss = s2[i], rr2 = r2[i], dd = d2[i];
-      double2 xx = x2[i], pn, sn, rn, un;
+      // nt != 0: p, s, x, r, w, dinv are streamed once per iteration -> non-temporal, so that u -- the only vector the
+      // following SpMV gathers from -- is what stays in L2 / Infinity Cache
+      double2 uu, pp, ww, ss, rr2, dd, xx, pn, sn, rn, un;
+      if (nt) {
+        uu = ntload2(u2 + i); pp = ntload2(p2 + i); ww = ntload2(w2 + i);
+        ss = ntload2(s2 + i); rr2 = ntload2(r2 + i); dd = ntload2(d2 + i); xx = ntload2(x2 + i);
+      } else {
+        uu = u2[i]; pp = p2[i]; ww = w2[i]; ss = s2[i]; rr2 = r2[i]; dd = d2[i]; xx = x2[i];
+      }
       pn.x = uu.x + beta * pp.x;
       pn.y = uu.y + beta * pp.y;
       sn.x = ww.x + beta * ss.x;
@@ -153,10 +171,11 @@ __global__ __launch_bounds__(256) void k_cg_update(int64_t n_own, const double* 
       un.y = dd.y * rn.y;
       pg += rn.x * un.x + rn.y * un.y;
       pr += rn.x * rn.x + rn.y * rn.y;
-      p2[i] = pn;
-      s2[i] = sn;
-      x2[i] = xx;
-      r2[i] = rn;
+      if (nt) {
+        ntstore2(p2 + i, pn); ntstore2(s2 + i, sn); ntstore2(x2 + i, xx); ntstore2(r2 + i, rn);
+      } else {
+        p2[i] = pn; s2[i] = sn; x2[i] = xx; r2[i] = rn;
+      }
       u2[i] = un;
     }
     if ((n_own & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -644,9 +663,10 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
                     double* res_out, bool defer = false) {
   const DevPattern& p = h->pat;
   const bool split = h->world > 1 && h->n_peers > 0;
-  const int nblocks = split ? (p.n_interior > 0 ? gl_spmv_grid(p.n_interior) : 0) +
-                                  (p.n_boundary > 0 ? gl_spmv_grid(p.n_boundary) : 0)
-                            : gl_spmv_grid(p.n_slices);
+  // delta partials: one per wave of the SpMV launch(es)
+  const int nblocks = 4 * (split ? (p.n_interior > 0 ? gl_spmv_grid(p.n_interior) : 0) +
+                                       (p.n_boundary > 0 ? gl_spmv_grid(p.n_boundary) : 0)
+                                 : gl_spmv_grid(p.n_slices));
   const int64_t n = h->n_own;
   // scal = [ping | pong | info{its, rr}]
   const unsigned g = grid_for(n);
@@ -672,11 +692,11 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
       const double* prev = h->scal.p + ((enq + j) & 1) * SC_COUNT;
       double* cur = h->scal.p + ((enq + j + 1) & 1) * SC_COUNT;
       apply_with_halo(h, v);
-      // delta partials: one per SpMV block (stage 1 only when there are very many); gamma / rr partials: one pair
-      // per block of the previous vector kernel
+      // delta partials: one per SpMV wave (a first reduction stage only above 64 k of them); gamma / rr partials: one
+      // pair per block of the previous vector kernel
       const double* ps = h->partials.p;
       int ns = nblocks;
-      if (nblocks > 16384) {
+      if (nblocks > 65536) {
         const int per_block = 1024;
         ns = (nblocks + per_block - 1) / per_block;
         hipLaunchKernelGGL(k_reduce_stage1, dim3(ns), dim3(256), 0, h->st, nblocks, 1, per_block, h->partials.p,
@@ -687,7 +707,7 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
                          h->done.p, h->nm);
       allreduce_sum(h, h->red.p, 3);
       GL_VEC(k_cg_update, n, h->red.p, prev, cur, info_dev, h->done.p, tol2, v.p, v.s, v.x, v.r, v.u, v.w, v.dinv,
-             h->partials_v.p);
+             h->partials_v.p, h->tune_upd_nt);
     }
     enq += nb;
     if (defer && hint > 0) {
