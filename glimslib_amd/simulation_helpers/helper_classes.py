@@ -430,10 +430,14 @@ class SubDomains:
                 mask = bdef
             else:
                 fn = bdef.inside_vectorized if isinstance(bdef, SubDomain) else bdef
-                mask = np.ones(nf, dtype=bool)
+                # successive tests only on the facets that passed the previous ones: after the first vertex a typical
+                # `on_boundary and ...` subdomain has ~1 % of the facets left (1.0 s -> 0.2 s at 12 M facets)
+                idx = np.arange(nf)
                 for j in range(k):
-                    mask &= np.asarray(fn(pts[verts[:, j]], ext), dtype=bool)
-                mask &= np.asarray(fn(pts[verts].mean(axis=1), ext), dtype=bool)
+                    idx = idx[np.asarray(fn(pts[verts[idx, j]], ext[idx]), dtype=bool)]
+                idx = idx[np.asarray(fn(pts[verts[idx]].mean(axis=1), ext[idx]), dtype=bool)]
+                mask = np.zeros(nf, dtype=bool)
+                mask[idx] = True
             values[mask] = boundary_id
             boundary_id_dict[name] = boundary_id
         self.named_boundaries_id_dict = boundary_id_dict
