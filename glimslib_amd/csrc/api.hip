@@ -496,7 +496,7 @@ int glims_apply(glims_ctx* h, int which, const double* x, double* y, int reps, d
   return guarded(h, [&]() {
     GL_REQUIRE(h->is_setup, "glims_apply before glims_setup");
     GL_REQUIRE(x && y && reps >= 1, "bad arguments");
-    GL_REQUIRE(which >= 0 && which <= 4, "unknown operator");
+    GL_REQUIRE(which >= 0 && which <= 5, "unknown operator");
     read_tuning(h);
     const int d = h->dim;
     const bool blk_in = which == 3, blk_out = which == 3 || which == 4;
@@ -509,7 +509,10 @@ int glims_apply(glims_ctx* h, int which, const double* x, double* y, int reps, d
     h->have_mload = false;
     GL_HIP(hipEventRecord(h->ev_a, h->st));
     for (int r = 0; r < reps; ++r) {
-      if (which <= 2)
+      if (which == 5)   // A x with the fused dot product of the Krylov iteration (timing studies)
+        gl_launch_spmv(h, h->st, h->pat.n_slices, nullptr, h->vA.p, xin.p, yout.p, nullptr, nullptr, xin.p,
+                       h->partials.p, 0, nullptr);
+      else if (which <= 2)
         gl_spmv_scalar(h, which == 0 ? h->vA.p : which == 1 ? h->vS.p : h->vM.p, xin.p, yout.p, false);
       else if (which == 3)
         gl_spmv_block(h, xin.p, yout.p, false);

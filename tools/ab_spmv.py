@@ -32,11 +32,15 @@ if study == 'unroll':
 if study == 'nt':
     variants = [("nt values+columns", dict(GLIMS_SPMV_NT="1")), ("plain loads", dict(GLIMS_SPMV_NT="0")),
                 ("nt values only", dict(GLIMS_SPMV_NT="2"))]
+which = {}
+if study == 'dots':
+    variants = [("plain (k_spmv<0,..>)", {}), ("fused dot (k_spmv<1,..>)", {})]
+    which = {"fused dot (k_spmv<1,..>)": 5}
 res = {n: [] for n, _ in variants}
 for rnd in range(9):
     for name, env in variants:
         os.environ.update(env)
-        _, ms = h.apply(0, x, reps=30)
+        _, ms = h.apply(which.get(name, 0), x, reps=30)
         if rnd > 0:
             res[name].append(ms / 30 * 1e3)
 for name, v in res.items():
