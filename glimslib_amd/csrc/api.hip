@@ -205,6 +205,7 @@ int glims_create(glims_ctx** out, int dim, int64_t n_nodes, int64_t n_own, int64
         cap = std::max(cap, (int)((hp.slice_ptr[sl + 1] - hp.slice_ptr[sl]) / GL_WAVE));
       p.bucket_cap.push_back(cap);
       p.bucket_count.push_back((int32_t)hp.bucket_slices[b].size());
+      p.bucket_interior.push_back(hp.bucket_interior[b]);
       auto* dv = new dvec<int32_t>();
       dv->upload(hp.bucket_slices[b], h->st);
       p.bucket_slices.push_back(dv);

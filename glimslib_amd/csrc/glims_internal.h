@@ -99,6 +99,7 @@ struct HostPattern {
   // bucket_cap[b-1] < len <= bucket_cap[b]
   std::vector<int> bucket_cap;
   std::vector<std::vector<int32_t>> bucket_slices;
+  std::vector<int32_t> bucket_interior;      // leading entries of bucket_slices[b] that are interior slices
   int max_len = 0, max_clen = 0;
   int64_t nnz = 0, n_corners = 0;
 };
@@ -124,6 +125,7 @@ struct DevPattern {
   int32_t n_interior = 0, n_boundary = 0;
   std::vector<int> bucket_cap;
   std::vector<int32_t> bucket_count;
+  std::vector<int32_t> bucket_interior;
   std::vector<dvec<int32_t>*> bucket_slices;   // owned; released in ~DevPattern
   ~DevPattern() { for (auto* b : bucket_slices) delete b; }
   int64_t total_entries = 0, total_corners = 0;
@@ -234,8 +236,9 @@ void gl_compute_egeo(glims_ctx* h, const double* d_xyz, const int32_t* d_cells);
 void gl_assemble_static(glims_ctx* h, int with_mechanics);
 int gl_rd_grid(const glims_ctx* h);
 int gl_spmv_grid(int n_launch);
+enum { GL_PART_ALL = 0, GL_PART_INTERIOR = 1, GL_PART_BOUNDARY = 2 };   // slices without / with ghost columns
 void gl_rd_assemble(glims_ctx* h, const double* c, const double* b, const double* b2, double* r_out, double* r2_out,
-                    double* partials /*[gl_rd_grid][2]*/);
+                    double* partials /*[gl_rd_grid][2]*/, int part = GL_PART_ALL);
 void gl_spmv_scalar(glims_ctx* h, const double* vals, const double* x, double* y, bool masked);
 void gl_apply_G(glims_ctx* h, const double* c, double* y);
 void gl_spmv_block(glims_ctx* h, const double* x, double* y, bool masked);

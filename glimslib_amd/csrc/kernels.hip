@@ -691,7 +691,7 @@ int gl_rd_grid(const glims_ctx* h) { return h->pat.n_slices; }
 
 // Assembles A(c) and the Newton right-hand side(s).  partials: [gl_rd_grid][2] = (|b - ..|^2, |b2 - ..|^2).
 void gl_rd_assemble(glims_ctx* h, const double* c, const double* b, const double* b2, double* r_out, double* r2_out,
-                    double* partials) {
+                    double* partials, int part) {
   const DevPattern& p = h->pat;
   const uint8_t* fx = h->have_fixed_c ? h->fixed_c.p : nullptr;
 #define GL_RD3(NV, NT, CU, CIDX)                                                                                   \
@@ -717,8 +717,11 @@ void gl_rd_assemble(glims_ctx* h, const double* c, const double* b, const double
   // (few) long rows of an unstructured mesh must not size it for everybody
   for (size_t bk = 0; bk < p.bucket_cap.size(); ++bk) {
     const int cap = p.bucket_cap[bk];
-    const int grid = p.bucket_count[bk];
-    const int32_t* list = p.bucket_slices[bk]->p;
+    const int n_int = p.bucket_interior[bk];
+    const int grid = part == GL_PART_ALL ? p.bucket_count[bk]
+                     : part == GL_PART_INTERIOR ? n_int : p.bucket_count[bk] - n_int;
+    if (grid <= 0) continue;
+    const int32_t* list = p.bucket_slices[bk]->p + (part == GL_PART_BOUNDARY ? n_int : 0);
     const size_t lds = (size_t)2 * cap * GL_WAVE * sizeof(double);
     if (h->nv == 3) {
       if (h->tune_rd_nt) GL_RD(3, 1); else GL_RD(3, 0);

@@ -315,10 +315,16 @@ void build_host_pattern(HostPattern& hp, int dim, int64_t n_nodes, int64_t n_own
   // length classes for the assembly sweep (its LDS footprint is 2 * cap * 64 * 8 B per wave)
   hp.bucket_cap = {16, 24, 32, 48, 64, 96, 128, 255};
   hp.bucket_slices.assign(hp.bucket_cap.size(), {});
-  for (int32_t s = 0; s < n_slices; ++s) {
-    const int len = (int)((hp.slice_ptr[s + 1] - hp.slice_ptr[s]) / GL_WAVE);
-    size_t b = 0;
-    while (hp.bucket_cap[b] < len) ++b;
-    hp.bucket_slices[b].push_back(s);
-  }
+  // inside a class the interior slices (no ghost column) come first, so that a partitioned run can sweep them while
+  // the halo of c is still in flight (bucket_interior[b] of them), then the rest
+  hp.bucket_interior.assign(hp.bucket_cap.size(), 0);
+  for (int pass = 0; pass < 2; ++pass)
+    for (int32_t s = 0; s < n_slices; ++s) {
+      if ((int)is_boundary[s] != pass) continue;
+      const int len = (int)((hp.slice_ptr[s + 1] - hp.slice_ptr[s]) / GL_WAVE);
+      size_t b = 0;
+      while (hp.bucket_cap[b] < len) ++b;
+      hp.bucket_slices[b].push_back(s);
+      if (pass == 0) hp.bucket_interior[b]++;
+    }
 }

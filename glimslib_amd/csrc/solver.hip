@@ -733,8 +733,31 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
 // the NEXT time step (same operator part 1/2 (A+S) c, different b), so that the convergence check of step n and
 // the first assembly of step n+1 are one pass over the corner lists.
 // `krylov`: also receives {iterations, rr, done} of a deferred linear solve enqueued before the sweep.
-static void rd_sweep(glims_ctx* h, const double* b2, double* norms /*[2]*/, Mail* krylov = nullptr) {
-  gl_rd_assemble(h, h->c.p, h->b.p, b2, h->cg_r.p, h->cg_r2.p, h->partials.p);
+// `exchange_c`: the ghosts of c are stale (a linear solve has just updated the owned values): in a partitioned run
+// the interior slices -- mass SpMV for b2 and sweep -- run while the halo is in flight, the boundary slices after it.
+static void rd_sweep(glims_ctx* h, const double* b2, double* norms /*[2]*/, Mail* krylov = nullptr,
+                     bool exchange_c = false, bool mass_for_b2 = false) {
+  const DevPattern& p = h->pat;
+  const double* load = h->have_load_rd ? h->load_rd.p : nullptr;
+  const bool split = exchange_c && h->world > 1 && h->n_peers > 0;
+  if (!split) {
+    if (exchange_c) gl_halo_exchange(h, h->c.p, 1);
+    if (mass_for_b2)
+      gl_launch_spmv(h, h->st, p.n_slices, nullptr, h->vM.p, h->c.p, h->b2.p, nullptr, load, nullptr, nullptr, 0,
+                     nullptr);
+    gl_rd_assemble(h, h->c.p, h->b.p, b2, h->cg_r.p, h->cg_r2.p, h->partials.p);
+  } else {
+    halo_start(h, h->c.p, 1);
+    if (mass_for_b2)
+      gl_launch_spmv(h, h->st, p.n_interior, p.interior_slices.p, h->vM.p, h->c.p, h->b2.p, nullptr, load, nullptr,
+                     nullptr, 0, nullptr);
+    gl_rd_assemble(h, h->c.p, h->b.p, b2, h->cg_r.p, h->cg_r2.p, h->partials.p, GL_PART_INTERIOR);
+    halo_finish(h);
+    if (mass_for_b2)
+      gl_launch_spmv(h, h->st, p.n_boundary, p.boundary_slices.p, h->vM.p, h->c.p, h->b2.p, nullptr, load, nullptr,
+                     nullptr, 0, nullptr);
+    gl_rd_assemble(h, h->c.p, h->b.p, b2, h->cg_r.p, h->cg_r2.p, h->partials.p, GL_PART_BOUNDARY);
+  }
   reduce_partials(h, gl_rd_grid(h), 2, nullptr);
   allreduce_sum(h, h->red.p, 2);
   const Mail m = fetch(h, 2, krylov != nullptr);
@@ -818,8 +841,8 @@ int gl_step(glims_ctx* h, int n_steps) {
         h->stats.last_cg_res = res;
       }
       h->stats.newton_its++;
-      gl_halo_exchange(h, h->c.p, 1);   // ghosts of c current again
       if (cs != GLIMS_OK) {
+        gl_halo_exchange(h, h->c.p, 1);   // ghosts of c current again
         status = cs;
         break;
       }
@@ -827,11 +850,9 @@ int gl_step(glims_ctx* h, int n_steps) {
       // solve was below ~sqrt(rtol) of the initial one, the next sweep will almost surely only confirm convergence,
       // so let it also assemble the next step (costs one extra mass SpMV, saves a whole sweep per step).
       const bool speculate = !extrapolate && nr <= 1e-4 * std::sqrt(o.newton_rtol / 1e-10) * r0;
-      if (speculate)
-        gl_launch_spmv(h, h->st, p.n_slices, nullptr, h->vM.p, h->c.p, h->b2.p, nullptr, load, nullptr, nullptr, 0,
-                       nullptr);
       Mail km;
-      rd_sweep(h, speculate ? h->b2.p : nullptr, norms, deferred ? &km : nullptr);
+      rd_sweep(h, speculate ? h->b2.p : nullptr, norms, deferred ? &km : nullptr, /*exchange_c=*/true,
+               /*mass_for_b2=*/speculate);
       if (deferred) {
         // the linear solve's outcome arrives with the sweep: a solve that used up its hint + 2 iterations simply
         // was a slightly weaker Newton step (the residual below decides); give it more room next time
