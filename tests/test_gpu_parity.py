@@ -470,6 +470,22 @@ def test_headline_config_c4_matches_the_c_oracle(backend):
     assert h.step(2) == 0
     c = h.get_state(want_u=False)[0]
     st = h.stats()
+    # oracle-free checks at the same size: symmetry and linearity of A(c), the dot-fused SpMV variant gives the same
+    # product, and a uniform field follows the scalar backward-Euler logistic recurrence exactly (K1; rho = 0.05 in
+    # both tissues)
+    n = w.mesh.num_vertices()
+    rng = np.random.default_rng(4)
+    x, y = rng.standard_normal(n), rng.standard_normal(n)
+    Ax, Ay = h.apply(0, x)[0], h.apply(0, y)[0]
+    assert abs(x @ Ay - y @ Ax) < 1e-11 * abs(x @ Ay)
+    assert rel_l2(h.apply(0, 2 * x - 3 * y)[0], 2 * Ax - 3 * Ay) < 1e-14
+    assert np.array_equal(h.apply(5, x)[0], Ax)
+    h.set_state(np.full(n, 0.25))
+    assert h.step(2) == 0
+    cn = 0.25
+    for _ in range(2):
+        cn = (-(1 - .05) + np.sqrt((1 - .05) ** 2 + 4 * .05 * cn)) / (2 * .05)
+    assert np.abs(h.get_state(want_u=False)[0] - cn).max() < 1e-9      # max norm over 10 M values at Newton rtol 1e-10
     h.close()
     err = rel_l2(c, ref)
     print("C4: 2 steps, rel-L2 vs C oracle %.2e (%d rows, %d of %d entries with 16-bit column codes)" %
