@@ -3,6 +3,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -66,3 +68,27 @@ def test_no_device_is_a_loud_error_not_a_fallback():
             assert e.code in (_backend.GLIMS_E_NO_DEVICE, _backend.GLIMS_E_HIP)
         else:
             raise AssertionError("glims_create succeeded without a GPU")
+
+
+def test_bench_and_public_api_refuse_to_run_without_a_gpu(tmp_path):
+    """No CPU fallback anywhere on the product path: on a box without a GPU bench.py exits with a message and a
+    non-zero status, and a simulation's run() raises instead of computing something else."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this box has a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "c1", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "no GPU" in r.stderr and not r.stdout.strip()
+    from glimslib_amd import fenics_local as fenics
+    from glimslib_amd.simulation import TumorGrowth
+    mesh = fenics.RectangleMesh(fenics.Point(0, 0), fenics.Point(1, 1), 4, 4)
+    sim = TumorGrowth(mesh)
+    sim.setup_global_parameters()
+    sim.setup_model_parameters(iv_expression={0: fenics.Constant((0.0, 0.0)), 1: fenics.Constant(0.1)}, diffusion=0.1,
+                               coupling=0.1, proliferation=0.1, E=1.0, poisson=0.3, sim_time=1, sim_time_step=1)
+    with pytest.raises(Exception) as ei:
+        sim.run(save_method=None, plot=False, output_dir=str(tmp_path))
+    assert "HIP" in str(ei.value) or "device" in str(ei.value).lower()
