@@ -30,6 +30,7 @@ void read_tuning(glims_ctx* h) {
   if (const char* e = getenv("GLIMS_RD_UNROLL")) h->tune_rd_unroll = atoi(e);
   if (const char* e = getenv("GLIMS_IDX16")) h->tune_idx16 = atoi(e);
   if (const char* e = getenv("GLIMS_TIME_SPMV")) h->time_spmv = atoi(e) != 0;
+  if (const char* e = getenv("GLIMS_MHIST")) h->mh_depth = std::max(0, std::min((int)glims_ctx::MHIST, atoi(e)));
   if (const char* e = getenv("GLIMS_UPD_NT")) h->tune_upd_nt = atoi(e);
   if (const char* e = getenv("GLIMS_BLK_VARIANT")) h->tune_blk_variant = atoi(e);
   if (const char* e = getenv("GLIMS_LIN_MARGIN")) h->tune_lin_margin = atof(e);
@@ -298,6 +299,7 @@ int glims_destroy(glims_ctx* h) {
 int glims_set_materials(glims_ctx* h, int n_labels, const double* D, const double* rho, const double* gamma,
                         const double* E, const double* nu) {
   return guarded(h, [&]() {
+    h->mh_count = h->mh_next = 0;   // the elasticity solve history belongs to one operator
     GL_REQUIRE(n_labels > 0 && n_labels <= GL_MAX_LABELS, "n_labels out of range");
     GL_REQUIRE(D && rho && gamma && E && nu, "null material table");
     std::vector<double> m(5 * GL_MAX_LABELS, 0.0);
@@ -357,6 +359,7 @@ int glims_set_dirichlet_c(glims_ctx* h, int64_t n, const int64_t* node_ids, cons
 
 int glims_set_dirichlet_u(glims_ctx* h, int64_t n, const int64_t* dof_ids, const double* values) {
   return guarded(h, [&]() {
+    h->mh_count = h->mh_next = 0;   // the elasticity solve history belongs to one operator
     if (n <= 0) {
       h->have_fixed_u = false;
       return GLIMS_OK;
@@ -410,6 +413,7 @@ int glims_set_mech_load(glims_ctx* h, const double* f) {
 
 int glims_setup(glims_ctx* h, int with_mechanics) {
   return guarded(h, [&]() {
+    h->mh_count = h->mh_next = 0;   // the elasticity solve history belongs to one operator
     GL_REQUIRE(h->have_materials, "glims_setup before glims_set_materials");
     if (with_mechanics) {
       const size_t nd = (size_t)h->n_nodes * h->dim;

@@ -171,6 +171,7 @@ struct glims_ctx {
   //   GLIMS_SPMV_NT     0|1|2      non-temporal loads: none | values + columns | values only
   //   GLIMS_IDX16       0|1        columns as int32 | as 16-bit (window, offset) codes where a slice allows it
   //   GLIMS_RD_NT / GLIMS_RD_REMAP / GLIMS_RD_UNROLL (4|8|12|24)   the same for the assembly sweep
+  //   GLIMS_MHIST       0..8       depth of the elasticity solve history used for the initial guess (6)
   //   GLIMS_UPD_NT      0|1        non-temporal streams in the PCG vector update (everything but u)
   //   GLIMS_BLK_VARIANT 0|1|2      block SpMV: first version | pipelined, 2 | 4 block entries per batch
   //   GLIMS_DEFER 0|1, GLIMS_DEFER_EXTRA n   read the linear solve's outcome with the next Newton sweep (1) after
@@ -192,6 +193,11 @@ struct glims_ctx {
   dvec<double> cg_p, cg_s, cg_u, cg_w, cg_r, cg_r2, b2;     // scalar CG work vectors; r2/b2: speculative next step
   int cg_hint[8] = {0, 0, 0, 0, 0, 0, 0, 0};                  // PCG iterations of the k-th Newton solve of the previous step
   int mech_hint = 0;
+  // history of solved elasticity problems (right-hand side, free-dof solution): the operator is linear and time
+  // independent, so the least-squares fit of a new right-hand side by the stored ones gives the initial guess
+  static constexpr int MHIST = 8;   // GLIMS_MHIST <= 8 limits the depth actually used
+  dvec<double> mh_rhs[MHIST], mh_x[MHIST];
+  int mh_count = 0, mh_next = 0, mh_depth = 6;
   bool have_c_old = false;                                    // c_old holds the state at the start of the previous step
   bool pending = false;                                      // cg_r / b / vA already hold the first assembly of the next step
   double pending_r0 = 0.0;

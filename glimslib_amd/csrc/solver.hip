@@ -438,6 +438,19 @@ __global__ __launch_bounds__(256) void k_dot_partials(int64_t n, const double* _
   if (threadIdx.x == 0) partials[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
 }
 
+// y = sum_k a[k] x_k  (k < m <= 8)
+struct LinComb {
+  const double* x[8];
+  double a[8];
+};
+__global__ void k_lincomb(int64_t n, int m, const LinComb lc, double* __restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double v = 0.0;
+  for (int k = 0; k < m; ++k) v += lc.a[k] * lc.x[k][i];
+  y[i] = v;
+}
+
 // inverse of the (Dirichlet-modified) diagonal BS x BS blocks of K_el
 template <int BS>
 __global__ void k_block_dinv(int64_t n_own, const int64_t* __restrict__ slice_ptr, const uint8_t* __restrict__ diag_k,
@@ -966,7 +979,80 @@ int gl_solve_mechanics(glims_ctx* h, const double* c_dev) {
   const double nb = std::sqrt(read_red0(h));
   if (!std::isfinite(nb)) return GLIMS_NAN;
   const double tol = std::max(h->opt.mech_atol, h->opt.mech_rtol * nb);
-  // warm start from the previous displacement: x = U on free dofs, 0 on constrained ones
+  // Initial guess.  K_el is linear and does not change in time, so if rhs ~ sum_k a_k rhs_k for previously solved
+  // right-hand sides then x ~ sum_k a_k x_k with residual rhs - sum_k a_k rhs_k: least-squares fit over the last
+  // (up to 4) solves; the concentration evolves smoothly, the fit removes several decades of the initial residual.
+  // Falls back to the previous displacement (the fit with a = e_last) when that is better or the history is empty.
+  if (h->world == 1 && h->mh_count > 0 && h->mh_depth > 0) {
+    const int m = h->mh_count;
+    // Gram matrix G_kl = (rhs_k, rhs_l) and g_k = (rhs_k, rhs): deterministic reductions, one value at a time
+    double G[glims_ctx::MHIST][glims_ctx::MHIST], g[glims_ctx::MHIST];
+    auto dot = [&](const double* a, const double* b) {
+      hipLaunchKernelGGL(k_dot_partials, dim3(gd), dim3(256), 0, h->st, nd, a, b, h->partials.p);
+      reduce_partials(h, (int)gd, 1, nullptr);
+      return read_red0(h);
+    };
+    for (int k = 0; k < m; ++k) {
+      g[k] = dot(h->mh_rhs[k].p, h->m_rhs.p);
+      for (int l = k; l < m; ++l) G[k][l] = G[l][k] = dot(h->mh_rhs[k].p, h->mh_rhs[l].p);
+    }
+    // normal equations with a small ridge (the right-hand sides of consecutive steps are nearly parallel)
+    double a[glims_ctx::MHIST] = {0.0};
+    {
+      double A[glims_ctx::MHIST][glims_ctx::MHIST + 1];
+      double tr = 0.0;
+      for (int k = 0; k < m; ++k) tr += G[k][k];
+      for (int k = 0; k < m; ++k) {
+        for (int l = 0; l < m; ++l) A[k][l] = G[k][l] + (k == l ? 1e-13 * tr : 0.0);
+        A[k][m] = g[k];
+      }
+      bool ok = true;
+      for (int c = 0; c < m && ok; ++c) {   // Gaussian elimination with partial pivoting on the m x m system
+        int piv = c;
+        for (int r = c + 1; r < m; ++r)
+          if (std::fabs(A[r][c]) > std::fabs(A[piv][c])) piv = r;
+        if (!(std::fabs(A[piv][c]) > 0.0)) {
+          ok = false;
+          break;
+        }
+        for (int q = 0; q <= m; ++q) std::swap(A[c][q], A[piv][q]);
+        for (int r = c + 1; r < m; ++r) {
+          const double f = A[r][c] / A[c][c];
+          for (int q = c; q <= m; ++q) A[r][q] -= f * A[c][q];
+        }
+      }
+      if (ok)
+        for (int c = m - 1; c >= 0; --c) {
+          double v = A[c][m];
+          for (int q = c + 1; q < m; ++q) v -= A[c][q] * a[q];
+          a[c] = v / A[c][c];
+        }
+      // predicted squared residual of the fit against the plain warm start (most recent solution alone)
+      auto res2 = [&](const double* coef) {
+        double v = nb * nb;
+        for (int k = 0; k < m; ++k) {
+          v -= 2.0 * coef[k] * g[k];
+          for (int l = 0; l < m; ++l) v += coef[k] * coef[l] * G[k][l];
+        }
+        return v;
+      };
+      double e_last[glims_ctx::MHIST] = {0.0};
+      const int last = (h->mh_next + h->mh_depth - 1) % h->mh_depth;
+      e_last[last] = 1.0;
+      bool finite = ok;
+      for (int k = 0; k < m; ++k) finite = finite && std::isfinite(a[k]);
+      if (!finite || !(res2(a) <= res2(e_last)))
+        for (int k = 0; k < m; ++k) a[k] = e_last[k];
+    }
+    LinComb lc;
+    for (int k = 0; k < 8; ++k) {
+      lc.x[k] = h->mh_x[k < m ? k : 0].p;
+      lc.a[k] = k < m ? a[k] : 0.0;
+    }
+    hipLaunchKernelGGL(k_lincomb, dim3(grid_exact(nd)), dim3(256), 0, h->st, nd, m, lc, h->U.p);
+    GL_HIP(hipGetLastError());
+  }
+  // x = guess on the free dofs (previous displacement if there is no history), 0 on constrained ones
   if (fx) hipLaunchKernelGGL(k_mask_assign, dim3(grid_exact(nd)), dim3(256), 0, h->st, nd, h->U.p, fx,
                              (const double*)nullptr);
   gl_halo_exchange(h, h->U.p, bs);
@@ -981,6 +1067,15 @@ int gl_solve_mechanics(glims_ctx* h, const double* c_dev) {
   h->stats.mech_cg_its += its;
   h->stats.mech_solves++;
   h->stats.last_mech_res = res;
+  if (cs == GLIMS_OK && h->world == 1 && h->mh_depth > 0) {   // remember (rhs, free-dof solution) for the next initial guess
+    const int slot = h->mh_next;
+    h->mh_rhs[slot].alloc((size_t)h->n_nodes * bs);
+    h->mh_x[slot].alloc((size_t)h->n_nodes * bs);
+    GL_HIP(hipMemcpyAsync(h->mh_rhs[slot].p, h->m_rhs.p, (size_t)nd * sizeof(double), hipMemcpyDeviceToDevice, h->st));
+    GL_HIP(hipMemcpyAsync(h->mh_x[slot].p, h->U.p, (size_t)nd * sizeof(double), hipMemcpyDeviceToDevice, h->st));
+    h->mh_next = (slot + 1) % h->mh_depth;
+    h->mh_count = std::min(h->mh_count + 1, h->mh_depth);
+  }
   if (fx) hipLaunchKernelGGL(k_mask_assign, dim3(grid_exact(nd)), dim3(256), 0, h->st, nd, h->U.p, fx,
                              (const double*)h->m_uD.p);
   gl_halo_exchange(h, h->U.p, bs);

@@ -492,3 +492,34 @@ def test_headline_config_c4_matches_the_c_oracle(backend):
           (err, st['n_rows'], st['nnz_idx16'], st['nnz_padded']))
     assert st['n_rows'] == 10077696 and st['nnz_idx16'] == st['nnz_padded']
     assert err < 1e-9
+
+
+def test_elasticity_history_guess_changes_only_the_iteration_count(backend, monkeypatch):
+    """Consecutive displacement solves start from the least-squares combination of the previous solutions (K_el is
+    linear and time independent).  Same answers as without the history and as the oracle, far fewer iterations."""
+    mesh = BoxMesh((0, 0, 0), (10.0, 9.0, 8.0), 16, 14, 12)
+    lab = (1 + (mesh.cell_midpoints()[:, 0] > 5.0)).astype(np.int32)
+    f = mesh.facets()
+    bn = np.unique(f['vertices'][f['exterior']])
+    dofs = (bn[:, None] * 3 + np.arange(3)).ravel()
+    vals = 1e-3 * np.cos(np.arange(len(dofs)))                     # inhomogeneous Dirichlet data
+    c0 = np.exp(-0.2 * ((mesh.points - np.array([5.0, 4.5, 4.0])) ** 2).sum(1))
+    o = _oracle(mesh, lab, 1.0, dirichlet_u=(dofs, vals))
+    out = {}
+    for depth in ("0", "6"):
+        monkeypatch.setenv("GLIMS_MHIST", depth)
+        h = _handle(backend, mesh, lab, 1.0)
+        h.set_dirichlet_u(dofs, vals)
+        h.set_state(c0)
+        us = []
+        for _ in range(8):
+            assert h.step(1) == 0 and h.solve_mechanics() == 0
+            us.append(h.get_state()[1].copy())
+        out[depth] = (us, h.stats()['mech_cg_its'])
+        c_last = h.get_state()[0]
+        h.close()
+    for a, b in zip(out["0"][0], out["6"][0]):
+        assert rel_l2(a, b) < 1e-8
+    assert rel_l2(out["6"][0][-1], o.mech_solve(c_last)) < 1e-8
+    assert out["6"][1] < 0.9 * out["0"][1]
+    print("elasticity PCG iterations over 8 solves: %d without history, %d with" % (out["0"][1], out["6"][1]))
