@@ -983,13 +983,14 @@ int gl_solve_mechanics(glims_ctx* h, const double* c_dev) {
   // right-hand sides then x ~ sum_k a_k x_k with residual rhs - sum_k a_k rhs_k: least-squares fit over the last
   // (up to 4) solves; the concentration evolves smoothly, the fit removes several decades of the initial residual.
   // Falls back to the previous displacement (the fit with a = e_last) when that is better or the history is empty.
-  if (h->world == 1 && h->mh_count > 0 && h->mh_depth > 0) {
+  if (h->mh_count > 0 && h->mh_depth > 0) {
     const int m = h->mh_count;
     // Gram matrix G_kl = (rhs_k, rhs_l) and g_k = (rhs_k, rhs): deterministic reductions, one value at a time
     double G[glims_ctx::MHIST][glims_ctx::MHIST], g[glims_ctx::MHIST];
     auto dot = [&](const double* a, const double* b) {
       hipLaunchKernelGGL(k_dot_partials, dim3(gd), dim3(256), 0, h->st, nd, a, b, h->partials.p);
       reduce_partials(h, (int)gd, 1, nullptr);
+      allreduce_sum(h, h->red.p, 1);   // partitioned run: every rank gets the same sums, hence the same coefficients
       return read_red0(h);
     };
     for (int k = 0; k < m; ++k) {
@@ -1067,7 +1068,7 @@ int gl_solve_mechanics(glims_ctx* h, const double* c_dev) {
   h->stats.mech_cg_its += its;
   h->stats.mech_solves++;
   h->stats.last_mech_res = res;
-  if (cs == GLIMS_OK && h->world == 1 && h->mh_depth > 0) {   // remember (rhs, free-dof solution) for the next initial guess
+  if (cs == GLIMS_OK && h->mh_depth > 0) {   // remember (rhs, free-dof solution) for the next initial guess
     const int slot = h->mh_next;
     h->mh_rhs[slot].alloc((size_t)h->n_nodes * bs);
     h->mh_x[slot].alloc((size_t)h->n_nodes * bs);

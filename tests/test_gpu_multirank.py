@@ -120,8 +120,9 @@ def _worker(rank, world, port, out_dir, dim=3, mailbox=False):
         h.setup(True)
         h.set_state(c0[part.global_ids])
         st1 = h.step(2)
+        sm0 = h.solve_mechanics()             # an intermediate displacement: the next solve starts from its history
         st2 = h.step(2)                       # second call continues from the carried (speculative) assembly
-        sm = h.solve_mechanics()
+        sm = h.solve_mechanics() | sm0
         c, u = h.get_state()
         stats = h.stats()
         assert (calls["allreduce"] == 0) == mailbox
