@@ -69,7 +69,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=os.environ.get("GLIMS_BENCH_WORKLOAD", "c4"))
-    ap.add_argument("--n", type=int, default=0, help="cells per edge (overrides the workload's size)")
+    ap.add_argument("--size", "--n", dest="n", type=int, default=0,
+                    help="cells per edge (overrides the workload's size); use --size under torchrun, which claims --n*")
     ap.add_argument("--spmv-reps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extrapolate", type=int, default=0)
@@ -153,7 +154,21 @@ def main():
     if args.warm_start is not None:
         flags = (flags | 2) if args.warm_start else (flags & ~2)
     h.set_options(dt=w.dt, flags=flags, **extra)
-    h.setup(with_mechanics=False)
+    # coupled configs (C5): the displacement is solved after EVERY step, as the reference's monolithic solve does; the
+    # unknown count is then (d + 1) per node.  (The simulation classes solve it lazily)
+    coupled = bool(w.mechanics)
+    dim = w.mesh.points.shape[1] if w.mesh is not None else 3
+    if coupled and w.dirichlet_nodes is not None:
+        if part is None:
+            nodes = np.asarray(w.dirichlet_nodes, dtype=np.int64)
+        else:
+            g2l = np.full(n_global, -1, dtype=np.int64)
+            g2l[part.global_ids[:part.n_own]] = np.arange(part.n_own)
+            nodes = g2l[np.asarray(w.dirichlet_nodes, dtype=np.int64)]
+            nodes = nodes[nodes >= 0]
+        dofs = (nodes[:, None] * dim + np.arange(dim)).ravel()
+        h.set_dirichlet_u(dofs, np.zeros(len(dofs)))
+    h.setup(with_mechanics=coupled)
     h.set_state(c0)
     st0 = h.stats()
     if rank == 0:
@@ -168,12 +183,21 @@ def main():
         torch.cuda.synchronize()
 
     # ---- warm-up, then EXACTLY K timed steps ---------------------------------------------------------
-    status = h.step(args.warmup) if args.warmup > 0 else GLIMS_OK
+    def advance(k):
+        if not coupled:
+            return h.step(k)
+        st_ = GLIMS_OK
+        for _ in range(k):
+            st_ |= h.step(1)
+            st_ |= h.solve_mechanics()
+        return st_
+
+    status = advance(args.warmup) if args.warmup > 0 else GLIMS_OK
     h.reset_stats()
     steps_before = h.stats()['steps']
     barrier()
     t0 = time.perf_counter()
-    status |= h.step(args.steps)
+    status |= advance(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -247,7 +271,7 @@ def main():
     if rank == 0:
         out = {
             "metric": "DoF-updates/s (implicit RD timestep) on 3D brain mesh",
-            "value": n_global * steps_done / elapsed,
+            "value": n_global * (dim + 1 if coupled else 1) * steps_done / elapsed,
             "unit": "DoF-updates/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -258,7 +282,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": w.name, "dofs": n_global, "dt": w.dt,
+            "config": {"workload": w.name, "dofs": n_global * (dim + 1 if coupled else 1), "dt": w.dt,
+                       "mech_cg_its_per_step": st['mech_cg_its'] / max(1, steps_done) if coupled else None,
                        "partition": "morton-node x%d" % world if world > 1 else "single GPU",
                        "newton_its_per_step": st['newton_its'] / max(1, steps_done),
                        "cg_its_per_step": st['cg_its'] / max(1, steps_done),
