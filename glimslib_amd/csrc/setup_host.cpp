@@ -17,6 +17,8 @@
 #include "glims_internal.h"
 
 #include <omp.h>
+#include <sched.h>
+#include <cstdio>
 #include <parallel/algorithm>
 #include <algorithm>
 #include <cmath>
@@ -53,9 +55,43 @@ struct KeyIdx {
 
 }  // namespace
 
+// OpenMP team for the symbolic phase: the hardware threads the process may really use.  A container often reports all
+// threads of the host while its CPU quota is a fraction of them; oversubscribed teams are slower, not faster (C4 on a
+// 16-core share of a 128-thread host: 3.4 s with 128 threads, 2.3 s with 16).  GLIMS_HOST_THREADS overrides.
+static int host_threads() {
+  if (const char* e = getenv("GLIMS_HOST_THREADS")) return std::max(1, atoi(e));
+  long n = omp_get_num_procs();
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min<long>(n, std::max(1, CPU_COUNT(&set)));
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2: "<quota> <period>" or "max <period>"
+    char q[64];
+    long period = 0;
+    if (fscanf(f, "%63s %ld", q, &period) == 2 && period > 0 && std::strcmp(q, "max") != 0) {
+      const long quota = atol(q);
+      if (quota > 0) n = std::min(n, std::max(1l, (quota + period - 1) / period));
+    }
+    fclose(f);
+  }
+  // one process per GPU under torchrun / mpirun: the ranks of this host share the cores (torchrun's default
+  // OMP_NUM_THREADS=1 is deliberately not taken as the limit here -- the symbolic phase is a one-off)
+  for (const char* v : {"LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MPI_LOCALNRANKS"})
+    if (const char* e = getenv(v)) {
+      n = std::max(1l, n / std::max(1, atoi(e)));
+      break;
+    }
+  return (int)std::min(n, 64l);
+}
+
 void build_host_pattern(HostPattern& hp, int dim, int64_t n_nodes, int64_t n_own, int64_t n_cells,
                         const double* xyz, const int32_t* cells) {
   const bool verbose = getenv("GLIMS_VERBOSE") != nullptr;
+  const int saved_threads = omp_get_max_threads();
+  omp_set_num_threads(host_threads());
+  struct Restore {
+    int n;
+    ~Restore() { omp_set_num_threads(n); }
+  } restore{saved_threads};
+  if (verbose) fprintf(stderr, "glims setup: OpenMP team of %d (runtime default %d)\n", omp_get_max_threads(), saved_threads);
   double t_last = omp_get_wtime();
   auto lap = [&](const char* what) {
     if (!verbose) return;
