@@ -28,7 +28,7 @@ def lib():
         L.oc_set_threads.argtypes = [C.c_int]
         # a GPU box gives one job a share of ~16 cores although it reports many more; oversubscribed OpenMP barriers
         # are catastrophic for the small configs, so cap the team (GLIMS_ORACLE_THREADS overrides)
-        n = int(os.environ.get("GLIMS_ORACLE_THREADS", min(os.cpu_count() or 1, 16)))
+        n = int(os.environ.get("GLIMS_ORACLE_THREADS", _usable_cpus()))
         L.oc_set_threads(n)
         _lib = L
     return _lib
