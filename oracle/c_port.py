@@ -8,6 +8,22 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _lib = None
 
 
+def _usable_cpus(cap=16):
+    """CPUs this process may really use: affinity mask and cgroup-v2 quota, at most `cap`."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max" and int(period) > 0:
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
+
+
 def lib():
     global _lib
     if _lib is None:
