@@ -41,7 +41,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 // ---------------------------------------------------------------------------------------------------
 template <int D>
 __global__ void k_egeo(int64_t n_cells, const double* __restrict__ xyz, const int32_t* __restrict__ cells,
-                       double* __restrict__ egeo) {
+                       double* __restrict__ egeo, unsigned long long* __restrict__ bad /*[2]: count, first index + 1*/) {
   constexpr int NV = D + 1, GE = 1 + NV * D;
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_cells) return;
@@ -88,6 +88,10 @@ __global__ void k_egeo(int64_t n_cells, const double* __restrict__ xyz, const in
       g[1 + 2 * 3 + a] = g2;
       g[1 + 3 * 3 + a] = g3;
     }
+  }
+  if (!(g[0] > 0.0) || !isfinite(1.0 / g[0])) {   // degenerate (zero-volume) or non-finite cell
+    atomicAdd(bad, 1ull);
+    atomicMin(bad + 1, (unsigned long long)e);
   }
 }
 
@@ -633,13 +637,22 @@ static void set_lds(K kern, size_t bytes) {
 void gl_compute_egeo(glims_ctx* h, const double* d_xyz, const int32_t* d_cells) {
   const int GE = 1 + h->nv * h->dim;
   h->egeo.alloc((size_t)h->n_cells * GE);
+  dvec<unsigned long long> bad;
+  const unsigned long long init[2] = {0ull, ~0ull};
+  bad.upload(init, 2, h->st);
   const int bs = 256;
   const unsigned grid = (unsigned)((h->n_cells + bs - 1) / bs);
   if (h->dim == 2)
-    hipLaunchKernelGGL(k_egeo<2>, dim3(grid), dim3(bs), 0, h->st, h->n_cells, d_xyz, d_cells, h->egeo.p);
+    hipLaunchKernelGGL(k_egeo<2>, dim3(grid), dim3(bs), 0, h->st, h->n_cells, d_xyz, d_cells, h->egeo.p, bad.p);
   else
-    hipLaunchKernelGGL(k_egeo<3>, dim3(grid), dim3(bs), 0, h->st, h->n_cells, d_xyz, d_cells, h->egeo.p);
+    hipLaunchKernelGGL(k_egeo<3>, dim3(grid), dim3(bs), 0, h->st, h->n_cells, d_xyz, d_cells, h->egeo.p, bad.p);
   GL_HIP(hipGetLastError());
+  unsigned long long res[2];
+  GL_HIP(hipMemcpyAsync(res, bad.p, sizeof(res), hipMemcpyDeviceToHost, h->st));
+  GL_HIP(hipStreamSynchronize(h->st));
+  if (res[0] != 0)
+    throw glims_error(GLIMS_E_USAGE, std::to_string(res[0]) + " degenerate cell(s) (zero volume or non-finite geometry), "
+                                         "the first one is cell " + std::to_string(res[1]));
 }
 
 template <int D>

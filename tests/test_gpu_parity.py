@@ -323,6 +323,18 @@ def test_orphaned_vertex_is_rejected_with_a_message(backend):
         backend.Handle(pts, mesh.cells, lab)
 
 
+def test_degenerate_cell_is_rejected_with_a_message(backend):
+    """A zero-volume cell would put inf / NaN into every operator; glims_create names it instead."""
+    mesh, lab = _case(3)
+    pts = mesh.points.copy()
+    c = mesh.cells[17]
+    pts[c[3]] = (pts[c[0]] + pts[c[1]] + pts[c[2]]) / 3.0          # fourth vertex into the plane of the other three
+    flat = np.flatnonzero(np.abs(np.linalg.det(pts[mesh.cells][:, 1:] - pts[mesh.cells][:, :1])) < 1e-14)
+    with pytest.raises(backend.BackendError, match="degenerate cell") as ei:
+        backend.Handle(pts, mesh.cells, lab)
+    assert ("cell %d" % flat[0]) in str(ei.value)
+
+
 def test_edge_cases_empty_and_degenerate_inputs(backend):
     """Zero steps, an all-zero state (||R_0|| = 0), a single-cell mesh (one slice of 61-62 padding rows), the largest
     admissible tissue id, and a mesh where every cell has rho = D = 0 (the sweep skips every incidence)."""
