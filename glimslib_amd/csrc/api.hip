@@ -313,6 +313,9 @@ int glims_set_materials(glims_ctx* h, int n_labels, const double* D, const doubl
       // math_linear_elasticity.py:6-10
       m[3 * GL_MAX_LABELS + l] = E[l] / (2.0 * (1.0 + nu[l]));
       m[4 * GL_MAX_LABELS + l] = E[l] * nu[l] / ((1.0 + nu[l]) * (1.0 - 2.0 * nu[l]));
+      GL_REQUIRE(std::isfinite(m[3 * GL_MAX_LABELS + l]) && std::isfinite(m[4 * GL_MAX_LABELS + l]),
+                 "Poisson ratio " + std::to_string(nu[l]) + " of label " + std::to_string(l) +
+                     " gives infinite Lame constants (need -1 < nu < 0.5)");
     }
     h->mat.upload(m, h->st);
     GL_HIP(hipStreamSynchronize(h->st));

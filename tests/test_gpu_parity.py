@@ -202,6 +202,8 @@ def test_failure_semantics_and_usage_errors(backend):
     bad[0, 0] = 10 ** 6
     with pytest.raises(backend.BackendError):
         backend.Handle(mesh.points, bad, lab)
+    with pytest.raises(backend.BackendError, match="Lame"):
+        h.set_materials(TABS['D'], TABS['rho'], TABS['gamma'], TABS['E'], [0.3, 0.5, 0.45, 0.1])   # incompressible
     h.close()
 
 
