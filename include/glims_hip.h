@@ -53,13 +53,14 @@ typedef struct glims_options {
   double newton_atol;     /*                                                               default 1e-13 */
   int    newton_maxit;    /*                                                               default 50    */
   double cg_rtol;         /* RD linear solve: ||r||_2 <= max(cg_atol, cg_rtol*||R_k||_2,
-                             0.1*newton target)   (inexact Newton forcing term)            default 1e-3  */
+                             0.5*newton target)   (inexact Newton forcing term)            default 1e-3  */
   double cg_atol;         /*                                                               default 0     */
   int    cg_maxit;        /*                                                               default 5000  */
   double mech_rtol;       /* mechanics PCG: ||r||_2 <= max(mech_atol, mech_rtol*||b||_2)    default 1e-10 */
   double mech_atol;       /*                                                               default 0     */
   int    mech_maxit;      /*                                                               default 200000*/
-  int    check_every;     /* Krylov iterations enqueued between host convergence polls      default 8     */
+  int    check_every;     /* Krylov iterations enqueued between host convergence polls when the
+                             iteration count cannot be predicted from the previous solve    default 8     */
   int    flags;           /* GLIMS_FLAG_*                                                   default WARM_START */
 } glims_options;
 
