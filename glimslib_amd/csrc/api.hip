@@ -30,6 +30,7 @@ void read_tuning(glims_ctx* h) {
   if (const char* e = getenv("GLIMS_RD_UNROLL")) h->tune_rd_unroll = atoi(e);
   if (const char* e = getenv("GLIMS_IDX16")) h->tune_idx16 = atoi(e);
   if (const char* e = getenv("GLIMS_TIME_SPMV")) h->time_spmv = atoi(e) != 0;
+  if (const char* e = getenv("GLIMS_MECH_MIXED")) h->mech_mixed = atoi(e);
   if (const char* e = getenv("GLIMS_MHIST")) h->mh_depth = std::max(0, std::min((int)glims_ctx::MHIST, atoi(e)));
   if (const char* e = getenv("GLIMS_UPD_NT")) h->tune_upd_nt = atoi(e);
   if (const char* e = getenv("GLIMS_BLK_VARIANT")) h->tune_blk_variant = atoi(e);

@@ -171,6 +171,7 @@ struct glims_ctx {
   //   GLIMS_SPMV_NT     0|1|2      non-temporal loads: none | values + columns | values only
   //   GLIMS_IDX16       0|1        columns as int32 | as 16-bit (window, offset) codes where a slice allows it
   //   GLIMS_RD_NT / GLIMS_RD_REMAP / GLIMS_RD_UNROLL (4|8|12|24)   the same for the assembly sweep
+  //   GLIMS_MECH_MIXED  0|1        elasticity: fp32 copy of K_el in the inner PCG under fp64 iterative refinement (1)
   //   GLIMS_MHIST       0..8       depth of the elasticity solve history used for the initial guess (6)
   //   GLIMS_UPD_NT      0|1        non-temporal streams in the PCG vector update (everything but u)
   //   GLIMS_BLK_VARIANT 0|1|2      block SpMV: first version | pipelined, 2 | 4 block entries per batch
@@ -188,6 +189,7 @@ struct glims_ctx {
 
   // scalar operator planes (SELL-64 layout) and block planes
   dvec<double> vM, vS, vA, vKel, vG;
+  dvec<float> vKel32;                      // single-precision copy of K_el (inner solves of the elasticity solver)
   // vectors (internal numbering; length n_nodes unless noted)
   dvec<double> c, c_old, b, load_rd, dinv;
   dvec<double> cg_p, cg_s, cg_u, cg_w, cg_r, cg_r2, b2;     // scalar CG work vectors; r2/b2: speculative next step
@@ -198,6 +200,7 @@ struct glims_ctx {
   static constexpr int MHIST = 8;   // GLIMS_MHIST <= 8 limits the depth actually used
   dvec<double> mh_rhs[MHIST], mh_x[MHIST];
   int mh_count = 0, mh_next = 0, mh_depth = 6;
+  int mech_mixed = 1;                      // GLIMS_MECH_MIXED: fp32 K_el in the inner PCG under an fp64 refinement loop
   bool have_c_old = false;                                    // c_old holds the state at the start of the previous step
   bool pending = false;                                      // cg_r / b / vA already hold the first assembly of the next step
   double pending_r0 = 0.0;

@@ -534,11 +534,13 @@ __global__ __launch_bounds__(256) void k_spmv_block(int n_launch, int chunk,
 // Pipelined block SpMV: KB block entries per batch -- all column loads, then all KB*BS*BS value loads (non-temporal:
 // streamed once), then the gathers, then the FMAs; ragged tail as one clamped batch; blocks dealt to the XCDs in
 // chunks like the scalar kernel (the contiguous-eighths mapping of the first version costs 15 % on the scalar SpMV).
-template <int BS, int DOTS, int KB>
+// VT = double, or float for the single-precision copy of K_el that the inner solves of the mixed-precision elasticity
+// solver stream (products and sums stay fp64).
+template <int BS, int DOTS, int KB, class VT>
 __global__ __launch_bounds__(256) void k_spmv_block2(int n_launch, int chunk, const int32_t* __restrict__ slice_list,
                                                       int64_t n_own, const int64_t* __restrict__ slice_ptr,
                                                       const int32_t* __restrict__ cols,
-                                                      const double* __restrict__ vals, const double* __restrict__ x,
+                                                      const VT* __restrict__ vals, const double* __restrict__ x,
                                                       double* __restrict__ y, const uint8_t* __restrict__ fixed,
                                                       const double* __restrict__ r, double* __restrict__ partials,
                                                       int partial_off, const int* __restrict__ done, int remap) {
@@ -554,7 +556,7 @@ __global__ __launch_bounds__(256) void k_spmv_block2(int n_launch, int chunk, co
     const int64_t base = slice_ptr[s];
     const int len = (int)((slice_ptr[s + 1] - base) >> 6);
     const int32_t* cc = cols + base + lane;
-    const double* vb = vals + base * B2 + lane;
+    const VT* vb = vals + base * B2 + lane;
     double acc[BS];
 #pragma unroll
     for (int a = 0; a < BS; ++a) acc[a] = 0.0;
@@ -565,9 +567,9 @@ __global__ __launch_bounds__(256) void k_spmv_block2(int n_launch, int chunk, co
       for (int j = 0; j < KB; ++j) cj[j] = __builtin_nontemporal_load(cc + (int64_t)min(k + j, len - 1) * GL_WAVE);
 #pragma unroll
       for (int j = 0; j < KB; ++j) {
-        const double* vk = vb + (int64_t)min(k + j, len - 1) * (GL_WAVE * B2);
+        const VT* vk = vb + (int64_t)min(k + j, len - 1) * (GL_WAVE * B2);
 #pragma unroll
-        for (int e = 0; e < B2; ++e) v[j][e] = __builtin_nontemporal_load(vk + e * GL_WAVE);
+        for (int e = 0; e < B2; ++e) v[j][e] = (double)__builtin_nontemporal_load(vk + e * GL_WAVE);
       }
 #pragma unroll
       for (int j = 0; j < KB; ++j)
@@ -655,6 +657,11 @@ void gl_compute_egeo(glims_ctx* h, const double* d_xyz, const int32_t* d_cells) 
                                          "the first one is cell " + std::to_string(res[1]));
 }
 
+__global__ void k_to_float(int64_t n, const double* __restrict__ a, float* __restrict__ b) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) b[i] = (float)a[i];
+}
+
 template <int D>
 static void assemble_plane(glims_ctx* h, int mode, int ca, int cb, double* out, int ostride, int ooff) {
   const DevPattern& p = h->pat;
@@ -690,6 +697,12 @@ static void assemble_static_t(glims_ctx* h, int with_mechanics) {
     for (int a = 0; a < D; ++a)
       for (int b = 0; b < D; ++b) assemble_plane<D>(h, MODE_KEL, a, b, h->vKel.p, D * D, (a * D + b) * GL_WAVE);
     for (int a = 0; a < D; ++a) assemble_plane<D>(h, MODE_G, a, 0, h->vG.p, D, a * GL_WAVE);
+    // single-precision copy of K_el for the inner solves of the mixed-precision elasticity solver
+    h->vKel32.alloc(ne * D * D);
+    const size_t nk = ne * D * D;
+    hipLaunchKernelGGL(k_to_float, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, h->st, (int64_t)nk, h->vKel.p,
+                       h->vKel32.p);
+    GL_HIP(hipGetLastError());
   }
 }
 
@@ -790,7 +803,7 @@ void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* s
 
 void gl_launch_spmv_block(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* slice_list, const double* x,
                           double* y, const uint8_t* fixed, const double* r, double* partials, int partial_off,
-                          const int* done) {
+                          const int* done, bool single_precision_operator) {
   if (n_launch <= 0) return;
   const DevPattern& p = h->pat;
   const int grid = gl_spmv_grid(n_launch);
@@ -798,14 +811,18 @@ void gl_launch_spmv_block(glims_ctx* h, hipStream_t st, int n_launch, const int3
   const int remap = slice_list ? 0 : 1;
 #define GL_BLK(BS, DOTS)                                                                                         \
   do {                                                                                                           \
-    if (h->tune_blk_variant == 1)                                                                                \
-      hipLaunchKernelGGL((k_spmv_block2<BS, DOTS, 2>), dim3(grid), dim3(256), 0, st, n_launch, chunk, slice_list, \
-                         h->n_own, p.slice_ptr.p, p.cols.p, h->vKel.p, x, y, fixed, r, partials, partial_off,     \
-                         done, slice_list ? 0 : h->tune_xcd_remap);                                              \
+    if (single_precision_operator)                                                                               \
+      hipLaunchKernelGGL((k_spmv_block2<BS, DOTS, 2, float>), dim3(grid), dim3(256), 0, st, n_launch, chunk,      \
+                         slice_list, h->n_own, p.slice_ptr.p, p.cols.p, h->vKel32.p, x, y, fixed, r, partials,    \
+                         partial_off, done, slice_list ? 0 : h->tune_xcd_remap);                                 \
+    else if (h->tune_blk_variant == 1)                                                                           \
+      hipLaunchKernelGGL((k_spmv_block2<BS, DOTS, 2, double>), dim3(grid), dim3(256), 0, st, n_launch, chunk,     \
+                         slice_list, h->n_own, p.slice_ptr.p, p.cols.p, h->vKel.p, x, y, fixed, r, partials,      \
+                         partial_off, done, slice_list ? 0 : h->tune_xcd_remap);                                 \
     else if (h->tune_blk_variant == 2)                                                                           \
-      hipLaunchKernelGGL((k_spmv_block2<BS, DOTS, 4>), dim3(grid), dim3(256), 0, st, n_launch, chunk, slice_list, \
-                         h->n_own, p.slice_ptr.p, p.cols.p, h->vKel.p, x, y, fixed, r, partials, partial_off,     \
-                         done, slice_list ? 0 : h->tune_xcd_remap);                                              \
+      hipLaunchKernelGGL((k_spmv_block2<BS, DOTS, 4, double>), dim3(grid), dim3(256), 0, st, n_launch, chunk,     \
+                         slice_list, h->n_own, p.slice_ptr.p, p.cols.p, h->vKel.p, x, y, fixed, r, partials,      \
+                         partial_off, done, slice_list ? 0 : h->tune_xcd_remap);                                 \
     else                                                                                                         \
       hipLaunchKernelGGL((k_spmv_block<BS, DOTS>), dim3(grid), dim3(256), 0, st, n_launch, chunk, slice_list,     \
                          h->n_own, p.slice_ptr.p, p.cols.p, h->vKel.p, x, y, fixed, r, partials, partial_off,     \
@@ -827,7 +844,7 @@ void gl_spmv_scalar(glims_ctx* h, const double* vals, const double* x, double* y
 
 void gl_spmv_block(glims_ctx* h, const double* x, double* y, bool masked) {
   gl_launch_spmv_block(h, h->st, h->pat.n_slices, nullptr, x, y,
-                       masked && h->have_fixed_u ? h->fixed_u.p : nullptr, nullptr, nullptr, 0, nullptr);
+                       masked && h->have_fixed_u ? h->fixed_u.p : nullptr, nullptr, nullptr, 0, nullptr, false);
 }
 
 void gl_apply_G(glims_ctx* h, const double* c, double* y) {

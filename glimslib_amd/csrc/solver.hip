@@ -22,7 +22,7 @@ void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* s
                     double* partials, int partial_off, const int* done);
 void gl_launch_spmv_block(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* slice_list, const double* x,
                           double* y, const uint8_t* fixed, const double* r, double* partials, int partial_off,
-                          const int* done);
+                          const int* done, bool single_precision_operator = false);
 
 namespace {
 
@@ -632,6 +632,7 @@ struct CgVecs {
   const double* vals;       // scalar operator plane; nullptr -> K_el blocks
   const uint8_t* fixed;
   int bs;
+  bool k32 = false;         // block operator: stream the single-precision copy of K_el
 };
 
 static void apply_with_halo(glims_ctx* h, const CgVecs& v) {
@@ -645,7 +646,7 @@ static void apply_with_halo(glims_ctx* h, const CgVecs& v) {
                      h->done.p);
       if (timed) GL_HIP(hipEventRecord(h->tev[h->tev_used++], h->st));
     } else
-      gl_launch_spmv_block(h, h->st, p.n_slices, nullptr, v.u, v.w, v.fixed, v.r, h->partials.p, 0, h->done.p);
+      gl_launch_spmv_block(h, h->st, p.n_slices, nullptr, v.u, v.w, v.fixed, v.r, h->partials.p, 0, h->done.p, v.k32);
     return;
   }
   // interior slices overlap with the xGMI transfer; boundary slices run once the ghosts have landed
@@ -656,14 +657,14 @@ static void apply_with_halo(glims_ctx* h, const CgVecs& v) {
                    h->partials.p, 0, h->done.p);
   else
     gl_launch_spmv_block(h, h->st, p.n_interior, p.interior_slices.p, v.u, v.w, v.fixed, v.r, h->partials.p, 0,
-                         h->done.p);
+                         h->done.p, v.k32);
   halo_finish(h);
   if (v.vals)
     gl_launch_spmv(h, h->st, p.n_boundary, p.boundary_slices.p, v.vals, v.u, v.w, v.fixed, nullptr, v.r,
                    h->partials.p, nbi, h->done.p);
   else
     gl_launch_spmv_block(h, h->st, p.n_boundary, p.boundary_slices.p, v.u, v.w, v.fixed, v.r, h->partials.p, nbi,
-                         h->done.p);
+                         h->done.p, v.k32);
 }
 
 // `hint`: expected iteration count (0 = unknown).  The first batch is hint + 1 launches (the extra one only detects
@@ -1063,8 +1064,52 @@ int gl_solve_mechanics(glims_ctx* h, const double* c_dev) {
   CgVecs v{h->U.p, h->m_r.p, h->m_u.p, h->m_w.p, h->m_p.p, h->m_s.p, h->m_dinv.p, nullptr, fx, bs};
   int64_t its = 0;
   double res = 0.0;
-  int cs = cg_solve(h, v, tol, h->opt.mech_maxit, h->mech_hint, &its, &res);
-  h->mech_hint = (int)its;
+  int cs = GLIMS_OK;
+  if (!h->mech_mixed || h->vKel32.n == 0) {
+    cs = cg_solve(h, v, tol, h->opt.mech_maxit, h->mech_hint, &its, &res);
+    h->mech_hint = (int)its;
+  } else {
+    // Mixed precision: the inner PCG streams a single-precision copy of K_el (40 instead of 76 bytes per block entry;
+    // products and sums in fp64) and reduces the residual by 1e-3; the outer loop recomputes the true residual with
+    // the fp64 operator and repeats.  The answer converges to the fp64 tolerance like the plain solver's (iterative
+    // refinement); if a cycle gains less than a factor 2 the remaining ones use the fp64 operator.
+    auto true_residual = [&]() {
+      hipLaunchKernelGGL(k_dot_partials, dim3(gd), dim3(256), 0, h->st, nd, h->m_r.p, h->m_r.p, h->partials.p);
+      reduce_partials(h, (int)gd, 1, nullptr);
+      allreduce_sum(h, h->red.p, 1);
+      return std::sqrt(read_red0(h));
+    };
+    double nr = true_residual();
+    v.k32 = true;
+    for (int outer = 0; outer < 12; ++outer) {
+      res = nr;
+      if (!std::isfinite(nr)) {
+        cs = GLIMS_NAN;
+        break;
+      }
+      if (nr <= tol) break;
+      if (its >= h->opt.mech_maxit || outer == 11) {
+        cs = GLIMS_NOT_CONVERGED;
+        break;
+      }
+      int64_t in_its = 0;
+      double in_res = 0.0;
+      const int ics = cg_solve(h, v, std::max(tol, 1e-3 * nr), (int)std::max<int64_t>(1, h->opt.mech_maxit - its), 0,
+                               &in_its, &in_res);
+      its += in_its;
+      if (ics == GLIMS_NAN) {
+        cs = ics;
+        break;
+      }
+      gl_halo_exchange(h, h->U.p, bs);
+      gl_launch_spmv_block(h, h->st, p.n_slices, nullptr, h->U.p, h->m_w.p, fx, nullptr, nullptr, 0, nullptr);
+      hipLaunchKernelGGL(k_sub, dim3(grid_exact(nd)), dim3(256), 0, h->st, nd, h->m_r.p, h->m_rhs.p, h->m_w.p, fx);
+      GL_HIP(hipGetLastError());
+      const double nr_new = true_residual();
+      if (!(nr_new < 0.5 * nr)) v.k32 = false;   // single precision has given what it can
+      nr = nr_new;
+    }
+  }
   h->stats.mech_cg_its += its;
   h->stats.mech_solves++;
   h->stats.last_mech_res = res;
