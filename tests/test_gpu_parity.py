@@ -537,3 +537,61 @@ def test_elasticity_history_guess_changes_only_the_iteration_count(backend, monk
     assert rel_l2(out["6"][0][-1], o.mech_solve(c_last)) < 1e-8
     assert out["6"][1] < 0.9 * out["0"][1]
     print("elasticity PCG iterations over 8 solves: %d without history, %d with" % (out["0"][1], out["6"][1]))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_randomised_small_problems_match_the_oracle(backend, seed):
+    """Random mesh size / dimension / tissue layout / materials / Dirichlet sets / loads / dt, one seed per case:
+    operators, three coupled steps and the displacement against the scipy oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    dim = 2 + seed % 2
+    h0 = float(rng.uniform(0.2, 2.0))                               # mesh width; per-axis factors keep aspect ratios <= 4
+    if dim == 2:
+        nx, ny = rng.integers(1, 24, size=2)
+        nz = 1
+        mesh = RectangleMesh((0, 0), (nx * h0 * float(rng.uniform(0.5, 2)), ny * h0 * float(rng.uniform(0.5, 2))),
+                             int(nx), int(ny))
+    else:
+        nx, ny, nz = rng.integers(1, 9, size=3)
+        mesh = BoxMesh((0, 0, 0), tuple(float(k * h0 * f) for k, f in zip((nx, ny, nz), rng.uniform(0.5, 2, size=3))),
+                       int(nx), int(ny), int(nz))
+    pts = mesh.points + rng.uniform(-0.2, 0.2, size=mesh.points.shape) * (np.ptp(mesh.points, axis=0) / np.array(
+        [nx, ny, nz][:dim])) * (0.0 if seed < 2 else 1.0)          # jittered vertices from the third case on
+    from glimslib_amd.mesh import Mesh
+    mesh = Mesh(pts, mesh.cells)
+    n, m = mesh.num_vertices(), mesh.num_cells()
+    n_lab = int(rng.integers(1, 5))
+    lab = rng.integers(1, n_lab + 1, size=m).astype(np.int32)
+    tabs = dict(D=[0.0] + list(rng.uniform(0.0, 0.5, n_lab)), rho=[0.0] + list(rng.uniform(0.0, 0.3, n_lab)),
+                gamma=[0.0] + list(rng.uniform(0.0, 0.5, n_lab)), E=[1.0] + list(10.0 ** rng.uniform(-3, 1, n_lab)),
+                nu=[0.3] + list(rng.uniform(0.05, 0.47, n_lab)))
+    dt = float(rng.uniform(0.2, 2.0))
+    bf, _ = boundary_facets(mesh.cells)
+    bn = np.unique(bf)
+    bn = bn[rng.random(len(bn)) < 0.7] if len(bn) > dim + 2 else bn
+    bn = np.union1d(bn, np.unique(bf)[:dim + 1])                   # enough clamped nodes to remove rigid motion
+    dofs = (bn[:, None] * dim + np.arange(dim)).ravel()
+    vals = 1e-2 * rng.standard_normal(len(dofs))
+    kw = dict(dirichlet_u=(dofs, vals))
+    load = mload = None
+    if seed % 3 == 0:
+        load = dt * 0.01 * rng.random(n)
+        mload = 1e-4 * rng.standard_normal(n * dim)
+        kw.update(rd_load=load, mech_load=mload)
+    o = _oracle(mesh, lab, dt, tabs, **kw)
+    h = _handle(backend, mesh, lab, dt, tabs)
+    h.set_dirichlet_u(dofs, vals)
+    if load is not None:
+        h.set_rd_load(load)
+        h.set_mech_load(mload)
+    x = rng.standard_normal(n)
+    assert rel_l2(h.apply(1, x)[0], o.S @ x) < 1e-13 and rel_l2(h.apply(2, x)[0], o.M @ x) < 1e-13
+    c0 = rng.random(n) * 0.8
+    uo, co = o.run(c0, 3 * dt)
+    h.set_state(c0)
+    assert h.step(3) == 0 and h.solve_mechanics() == 0
+    c, u = h.get_state()
+    h.close()
+    # solution errors = condition number x the residual tolerances (1e-10): material contrasts of 1e4 are allowed here
+    assert rel_l2(c, co) < 2e-9, (seed, dim, n)
+    assert rel_l2(u, uo) < 1e-6, (seed, dim, n)
