@@ -135,7 +135,7 @@ def _worker(rank, world, port, out_dir, dim=3, mailbox=False):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("dim,world,mailbox", [(3, 2, False), (2, 3, False), (3, 2, True), (2, 4, True)])
+@pytest.mark.parametrize("dim,world,mailbox", [(3, 2, False), (2, 3, False), (3, 2, True), (2, 4, True), (3, 3, True)])
 def test_ranks_on_one_gpu_match_serial(tmp_path, backend, dim, world, mailbox):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), dim, mailbox), nprocs=world, join=True)
     mesh, label, bn, c0 = _problem(dim)
