@@ -171,7 +171,8 @@ struct glims_ctx {
   //   GLIMS_SPMV_NT     0|1|2      non-temporal loads: none | values + columns | values only
   //   GLIMS_IDX16       0|1        columns as int32 | as 16-bit (window, offset) codes where a slice allows it
   //   GLIMS_RD_NT / GLIMS_RD_REMAP / GLIMS_RD_UNROLL (4|8|12|24)   the same for the assembly sweep
-  //   GLIMS_MECH_MIXED  0|1        elasticity: fp32 copy of K_el in the inner PCG under fp64 iterative refinement (1)
+  //   GLIMS_MECH_MIXED  0|1|2      elasticity: fp32 copy of K_el in the inner PCG under fp64 iterative refinement:
+  //                                off | when K_el exceeds the Infinity Cache (default) | always
   //   GLIMS_MHIST       0..8       depth of the elasticity solve history used for the initial guess (6)
   //   GLIMS_UPD_NT      0|1        non-temporal streams in the PCG vector update (everything but u)
   //   GLIMS_BLK_VARIANT 0|1|2      block SpMV: first version | pipelined, 2 | 4 block entries per batch

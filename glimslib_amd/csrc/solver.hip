@@ -1065,7 +1065,11 @@ int gl_solve_mechanics(glims_ctx* h, const double* c_dev) {
   int64_t its = 0;
   double res = 0.0;
   int cs = GLIMS_OK;
-  if (!h->mech_mixed || h->vKel32.n == 0) {
+  // worth it only where the operator is streamed from HBM: below ~256 MB (Infinity Cache) an iteration is latency
+  // bound and the restarts of the refinement loop only add iterations (GLIMS_MECH_MIXED: 0 off, 1 auto, 2 always)
+  const bool big = (size_t)p.total_entries * bs * bs * sizeof(double) > ((size_t)256 << 20);
+  const bool mixed = h->vKel32.n != 0 && (h->mech_mixed == 2 || (h->mech_mixed == 1 && big));
+  if (!mixed) {
     cs = cg_solve(h, v, tol, h->opt.mech_maxit, h->mech_hint, &its, &res);
     h->mech_hint = (int)its;
   } else {

@@ -520,6 +520,7 @@ def test_elasticity_history_guess_changes_only_the_iteration_count(backend, monk
     c0 = np.exp(-0.2 * ((mesh.points - np.array([5.0, 4.5, 4.0])) ** 2).sum(1))
     o = _oracle(mesh, lab, 1.0, dirichlet_u=(dofs, vals))
     out = {}
+    monkeypatch.setenv("GLIMS_MECH_MIXED", "2")                    # fp32 inner operator + fp64 refinement, also on this small mesh
     for depth in ("0", "6"):
         monkeypatch.setenv("GLIMS_MHIST", depth)
         h = _handle(backend, mesh, lab, 1.0)
