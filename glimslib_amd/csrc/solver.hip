@@ -7,10 +7,16 @@
 // (simulation_tumor_growth.py:115-120), so the monolithic Newton iteration and "Newton on c, then one linear
 // solve for u" have the same fixed point; tests/ checks that claim against the monolithic oracle.
 //
-// Host/device protocol: the host never reads a scalar inside a Krylov iteration.  alpha/beta live in `scal`,
-// a device-side `done` word turns the remaining enqueued kernels of a batch into no-ops, and the host polls it
-// once per `check_every` iterations.  In a partitioned run every rank enqueues the same kernel/collective
-// sequence; the decision words are computed from all-reduced values and are therefore identical on all ranks.
+// Host/device protocol: the host never reads a scalar inside a Krylov iteration.  alpha/beta live in `scal`, a
+// device-side `done` word turns the remaining enqueued kernels of a solve into no-ops.  Inside the Newton iteration the
+// host does not even ask how a linear solve went: it enqueues the previous solve's iteration count + 2, goes on to the
+// assembly sweep and receives {||R||, Krylov iterations, final rr, done} in one store sequence into pinned host memory
+// (k_publish), on whose sequence number it spins -- one decision point per Newton iteration, no stream
+// synchronisation, no copies.  Solves whose length cannot be predicted (first step, elasticity, projections) are
+// polled once per `check_every` iterations through the same mailbox.
+// In a partitioned run every rank enqueues the same kernel / collective sequence; the decision words are computed from
+// all-reduced values (summed in rank order inside the final reduction block, see NodeMail) and are therefore
+// identical on all ranks.
 #include "glims_internal.h"
 
 #include <atomic>
