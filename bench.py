@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--cg-rtol", type=float, default=None, help="override glims_options.cg_rtol (tuning runs only)")
     ap.add_argument("--check-every", type=int, default=None)
     ap.add_argument("--newton-rtol", type=float, default=None)
+    ap.add_argument("--fp32-jacobian", type=int, default=0,
+                    help="1: GLIMS_FLAG_FP32_JACOBIAN (study runs only; the line then says dtype f64/f32-jacobian)")
     ap.add_argument("--warm-start", type=int, default=None, help="override GLIMS_FLAG_WARM_START (tuning runs only)")
     args = ap.parse_args()
 
@@ -153,6 +155,8 @@ def main():
     flags = FLAG_EXTRAPOLATE_GUESS if args.extrapolate else h.options.flags
     if args.warm_start is not None:
         flags = (flags | 2) if args.warm_start else (flags & ~2)
+    if args.fp32_jacobian:
+        flags |= 4
     h.set_options(dt=w.dt, flags=flags, **extra)
     # coupled configs (C5): the displacement is solved after EVERY step, as the reference's monolithic solve does; the
     # unknown count is then (d + 1) per node.  (The simulation classes solve it lazily)
@@ -280,7 +284,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f64" if not args.fp32_jacobian else "f64 (Jacobian stored f32 inside the Krylov solves)",
             "data": "synthetic",
             "config": {"workload": w.name, "dofs": n_global * (dim + 1 if coupled else 1), "dt": w.dt,
                        "mech_cg_its_per_step": st['mech_cg_its'] / max(1, steps_done) if coupled else None,

@@ -19,6 +19,7 @@ GLIMS_E_USAGE, GLIMS_E_HIP, GLIMS_E_RCCL, GLIMS_E_NO_DEVICE = -1, -2, -3, -4
 GLIMS_UNIQUE_ID_BYTES = 256
 FLAG_EXTRAPOLATE_GUESS = 1
 FLAG_WARM_START = 2
+FLAG_FP32_JACOBIAN = 4
 
 
 class BackendError(RuntimeError):

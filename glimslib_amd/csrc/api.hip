@@ -17,7 +17,7 @@ static void mailbox_close(glims_ctx* h);
 
 void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* slice_list, const double* vals,
                     const double* x, double* y, const uint8_t* fixed, const double* addv, const double* r,
-                    double* partials, int partial_off, const int* done);
+                    double* partials, int partial_off, const int* done, const float* vals32 = nullptr);
 
 namespace {
 
@@ -333,6 +333,7 @@ int glims_set_options(glims_ctx* h, const glims_options* opt) {
     GL_REQUIRE(opt->dt > 0.0 && std::isfinite(opt->dt), "dt must be positive");
     GL_REQUIRE(opt->newton_maxit >= 0 && opt->cg_maxit > 0 && opt->mech_maxit > 0, "bad iteration caps");
     if (opt->dt != h->opt.dt) h->is_setup = false;
+    if ((opt->flags ^ h->opt.flags) & GLIMS_FLAG_FP32_JACOBIAN) h->is_setup = false;
     h->opt = *opt;
     h->pending = false;
     return GLIMS_OK;
@@ -434,6 +435,7 @@ int glims_setup(glims_ctx* h, int with_mechanics) {
       if (!h->m_uD.p) h->m_uD.alloc_zero(nd, h->st);
     }
     h->pending = false;
+    h->jac32 = (h->opt.flags & GLIMS_FLAG_FP32_JACOBIAN) != 0;
     gl_assemble_static(h, with_mechanics);
     GL_HIP(hipStreamSynchronize(h->st));
     h->is_setup = true;
@@ -520,7 +522,7 @@ int glims_apply(glims_ctx* h, int which, const double* x, double* y, int reps, d
     for (int r = 0; r < reps; ++r) {
       if (which == 5)   // A x with the fused dot product of the Krylov iteration (timing studies)
         gl_launch_spmv(h, h->st, h->pat.n_slices, nullptr, h->vA.p, xin.p, yout.p, nullptr, nullptr, xin.p,
-                       h->partials.p, 0, nullptr);
+                       h->partials.p, 0, nullptr, h->jac32 ? h->vA32.p : nullptr);
       else if (which <= 2)
         gl_spmv_scalar(h, which == 0 ? h->vA.p : which == 1 ? h->vS.p : h->vM.p, xin.p, yout.p, false);
       else if (which == 3)

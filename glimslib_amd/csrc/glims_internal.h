@@ -190,6 +190,8 @@ struct glims_ctx {
 
   // scalar operator planes (SELL-64 layout) and block planes
   dvec<double> vM, vS, vA, vKel, vG;
+  dvec<float> vA32;                        // Newton Jacobian in single precision (GLIMS_FLAG_FP32_JACOBIAN only)
+  bool jac32 = false;
   dvec<float> vKel32;                      // single-precision copy of K_el (inner solves of the elasticity solver)
   // vectors (internal numbering; length n_nodes unless noted)
   dvec<double> c, c_old, b, load_rd, dinv;

@@ -198,13 +198,13 @@ __device__ __forceinline__ void corner_batch(const double* __restrict__ wp, cons
   for (int j = 0; j < B; ++j) corner(wb[j], sb[j]);
 }
 
-template <int NV, int NT, int CU, int CIDX>
+template <int NV, int NT, int CU, int CIDX, class AT = double>
 __global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
     const int32_t* __restrict__ slice_list, int64_t n_own, const int64_t* __restrict__ slice_ptr,
     const int32_t* __restrict__ cols, const uint16_t* __restrict__ cols16, const int32_t* __restrict__ win_base,
     const uint8_t* __restrict__ win_ok,
     const int64_t* __restrict__ cslice_ptr, const uint32_t* __restrict__ cslots, const double* __restrict__ cw,
-    const uint8_t* __restrict__ diag_k, const double* __restrict__ vS, double* __restrict__ vA,
+    const uint8_t* __restrict__ diag_k, const double* __restrict__ vS, AT* __restrict__ vA,
     const double* __restrict__ c, const double* __restrict__ b, const double* __restrict__ b2,
     double* __restrict__ r_out, double* __restrict__ r2_out, double* __restrict__ dinv,
     const uint8_t* __restrict__ fixed, double two_dt, double* __restrict__ partials, int max_len, int remap) {
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
     }
     // phase 3: A = S + 2 dt N(c), residual 1/2 (A + S) c, diagonal
     const double* sv = vS + base + lane;
-    double* av = vA + base + lane;
+    AT* av = vA + base + lane;
     double r = 0.0, d = 1.0;
     {
       int k = 0;
@@ -305,8 +305,8 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const double Av = S8[j] + two_dt * acc[(k + j) * GL_WAVE + lane];
-          if (NT) __builtin_nontemporal_store(Av, av + (int64_t)(k + j) * GL_WAVE);
-          else av[(int64_t)(k + j) * GL_WAVE] = Av;
+          if (NT) __builtin_nontemporal_store((AT)Av, av + (int64_t)(k + j) * GL_WAVE);
+          else av[(int64_t)(k + j) * GL_WAVE] = (AT)Av;
           r += 0.5 * (Av + S8[j]) * cn[(k + j) * GL_WAVE + lane];
           if (k + j == dk) d = Av;
         }
@@ -322,8 +322,8 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
         for (int j = 0; j < 8; ++j)
           if (k + j < len) {
             const double Av = S8[j] + two_dt * acc[(k + j) * GL_WAVE + lane];
-            if (NT) __builtin_nontemporal_store(Av, av + (int64_t)(k + j) * GL_WAVE);
-            else av[(int64_t)(k + j) * GL_WAVE] = Av;
+            if (NT) __builtin_nontemporal_store((AT)Av, av + (int64_t)(k + j) * GL_WAVE);
+            else av[(int64_t)(k + j) * GL_WAVE] = (AT)Av;
             r += 0.5 * (Av + S8[j]) * cn[(k + j) * GL_WAVE + lane];
             if (k + j == dk) d = Av;
           }
@@ -360,9 +360,9 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
 // gathered x entries from L2 / Infinity Cache
 // DK >= 0 (fused dot product): also returns x at the row's own column through xdiag (slot dk of the row), so that
 // the dot y.x does not read x[row] a second time
-template <int COMP, int UNR, int NT, int WANT_DIAG>
+template <int COMP, int UNR, int NT, int WANT_DIAG, class VT>
 __device__ __forceinline__ double spmv_row(const int32_t* __restrict__ cc, const uint16_t* __restrict__ c16,
-                                            int32_t wb, const double* __restrict__ v, const double* __restrict__ x,
+                                            int32_t wb, const VT* __restrict__ v, const double* __restrict__ x,
                                             int len, int dk, double& xdiag) {
   constexpr bool NTC = NT == 1, NTV = NT != 0;   // NT = 2: only the 8-byte value stream is non-temporal
   double acc = 0.0;
@@ -377,7 +377,7 @@ __device__ __forceinline__ double spmv_row(const int32_t* __restrict__ cc, const
         qu[j] = NTC ? __builtin_nontemporal_load(c16 + (int64_t)(k + j) * GL_WAVE) : c16[(int64_t)(k + j) * GL_WAVE];
 #pragma unroll
       for (int j = 0; j < UNR; ++j)
-        vu[j] = NTV ? __builtin_nontemporal_load(v + (int64_t)(k + j) * GL_WAVE) : v[(int64_t)(k + j) * GL_WAVE];
+        vu[j] = (double)(NTV ? __builtin_nontemporal_load(v + (int64_t)(k + j) * GL_WAVE) : v[(int64_t)(k + j) * GL_WAVE]);
 #pragma unroll
       for (int j = 0; j < UNR; ++j) cu[j] = decode_col(qu[j], wb);
     } else {
@@ -386,7 +386,7 @@ __device__ __forceinline__ double spmv_row(const int32_t* __restrict__ cc, const
         cu[j] = NTC ? __builtin_nontemporal_load(cc + (int64_t)(k + j) * GL_WAVE) : cc[(int64_t)(k + j) * GL_WAVE];
 #pragma unroll
       for (int j = 0; j < UNR; ++j)
-        vu[j] = NTV ? __builtin_nontemporal_load(v + (int64_t)(k + j) * GL_WAVE) : v[(int64_t)(k + j) * GL_WAVE];
+        vu[j] = (double)(NTV ? __builtin_nontemporal_load(v + (int64_t)(k + j) * GL_WAVE) : v[(int64_t)(k + j) * GL_WAVE]);
     }
 #pragma unroll
     for (int j = 0; j < UNR; ++j) xu[j] = x[cu[j]];
@@ -413,7 +413,7 @@ __device__ __forceinline__ double spmv_row(const int32_t* __restrict__ cc, const
 #pragma unroll
     for (int j = 0; j < UNR; ++j) {
       const int kk = min(k + j, len - 1);
-      const double vj = NTV ? __builtin_nontemporal_load(v + (int64_t)kk * GL_WAVE) : v[(int64_t)kk * GL_WAVE];
+      const double vj = (double)(NTV ? __builtin_nontemporal_load(v + (int64_t)kk * GL_WAVE) : v[(int64_t)kk * GL_WAVE]);
       vu[j] = (k + j < len) ? vj : 0.0;
     }
     if (COMP) {
@@ -432,13 +432,14 @@ __device__ __forceinline__ double spmv_row(const int32_t* __restrict__ cc, const
   return acc;
 }
 
-template <int DOTS, int UNR, int NT, int CIDX>
+// VT = double; float only for the optional single-precision copy of the Newton Jacobian (GLIMS_FLAG_FP32_JACOBIAN).
+template <int DOTS, int UNR, int NT, int CIDX, class VT = double>
 __global__ __launch_bounds__(256) void k_spmv(int n_launch, int chunk, const int32_t* __restrict__ slice_list,
                                                int64_t n_own, const int64_t* __restrict__ slice_ptr,
                                                const int32_t* __restrict__ cols, const uint16_t* __restrict__ cols16,
                                                const int32_t* __restrict__ win_base,
                                                const uint8_t* __restrict__ win_ok,
-                                               const uint8_t* __restrict__ diag_k, const double* __restrict__ vals,
+                                               const uint8_t* __restrict__ diag_k, const VT* __restrict__ vals,
                                                const double* __restrict__ x, double* __restrict__ y,
                                                const uint8_t* __restrict__ fixed, const double* __restrict__ addv,
                                                const double* __restrict__ r, double* __restrict__ partials,
@@ -455,14 +456,14 @@ __global__ __launch_bounds__(256) void k_spmv(int n_launch, int chunk, const int
     const int64_t row = (int64_t)s * GL_WAVE + lane;
     const int64_t base = slice_ptr[s];
     const int len = (int)((slice_ptr[s + 1] - base) >> 6);
-    const double* v = vals + base + lane;
+    const VT* v = vals + base + lane;
     double acc, xd = 0.0;
     const int dk = DOTS ? (int)diag_k[row] : -1;   // diag_k covers the padded rows of the last slice as well
     if (CIDX && win_ok[s]) {   // wave-uniform
       const int32_t wb = win_base[(int64_t)s * GL_N_WIN + (lane & (GL_N_WIN - 1))];
-      acc = spmv_row<1, UNR, NT, DOTS>(nullptr, cols16 + base + lane, wb, v, x, len, dk, xd);
+      acc = spmv_row<1, UNR, NT, DOTS, VT>(nullptr, cols16 + base + lane, wb, v, x, len, dk, xd);
     } else {
-      acc = spmv_row<0, UNR, NT, DOTS>(cols + base + lane, nullptr, 0, v, x, len, dk, xd);
+      acc = spmv_row<0, UNR, NT, DOTS, VT>(cols + base + lane, nullptr, 0, v, x, len, dk, xd);
     }
     if (row < n_own) {
       if (fixed && fixed[row]) acc = 0.0;
@@ -683,6 +684,12 @@ static void assemble_static_t(glims_ctx* h, int with_mechanics) {
   assemble_plane<D>(h, MODE_M, 0, 0, h->vM.p, 1, 0);
   assemble_plane<D>(h, MODE_S, 0, 0, h->vS.p, 1, 0);
   GL_HIP(hipMemcpyAsync(h->vA.p, h->vS.p, ne * sizeof(double), hipMemcpyDeviceToDevice, h->st));
+  if (h->jac32) {
+    h->vA32.alloc(ne);
+    hipLaunchKernelGGL(k_to_float, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, h->st, (int64_t)ne, h->vS.p,
+                       h->vA32.p);
+    GL_HIP(hipGetLastError());
+  }
   p.cw.alloc((size_t)p.total_corners);
   {
     const int bs = 256;
@@ -748,6 +755,20 @@ void gl_rd_assemble(glims_ctx* h, const double* c, const double* b, const double
                      : part == GL_PART_INTERIOR ? n_int : p.bucket_count[bk] - n_int;
     if (grid <= 0) continue;
     const int32_t* list = p.bucket_slices[bk]->p + (part == GL_PART_BOUNDARY ? n_int : 0);
+    if (h->jac32) {   // Jacobian stored in single precision (option): default kernel configuration only
+      const size_t lds32 = (size_t)2 * cap * GL_WAVE * sizeof(double);
+#define GL_RD32(NV)                                                                                                 \
+  do {                                                                                                             \
+    set_lds(k_rd_assemble<NV, 0, 24, 1, float>, lds32);                                                            \
+    hipLaunchKernelGGL((k_rd_assemble<NV, 0, 24, 1, float>), dim3(grid), dim3(GL_WAVE), lds32, h->st, list,         \
+                       h->n_own, p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, p.win_ok.p, p.cslice_ptr.p,     \
+                       p.cslots.p, p.cw.p, p.diag_k.p, h->vS.p, h->vA32.p, c, b, b2, r_out, r2_out, h->dinv.p, fx,   \
+                       2.0 * h->opt.dt, partials, cap, h->tune_rd_remap);                                          \
+  } while (0)
+      if (h->nv == 3) GL_RD32(3); else GL_RD32(4);
+#undef GL_RD32
+      continue;
+    }
     const size_t lds = (size_t)2 * cap * GL_WAVE * sizeof(double);
     if (h->nv == 3) {
       if (h->tune_rd_nt) GL_RD(3, 1); else GL_RD(3, 0);
@@ -770,12 +791,24 @@ int gl_spmv_grid(int n_launch) { return std::max(1, (n_launch + 3) / 4); }
 // Generic entry used by the solver: slice subset + fused dots.
 void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* slice_list, const double* vals,
                     const double* x, double* y, const uint8_t* fixed, const double* addv, const double* r,
-                    double* partials, int partial_off, const int* done) {
+                    double* partials, int partial_off, const int* done, const float* vals32) {
   if (n_launch <= 0) return;
   const DevPattern& p = h->pat;
   const int grid = gl_spmv_grid(n_launch);
   const int chunk = (n_launch + grid - 1) / grid;
   const int remap = slice_list ? 0 : h->tune_xcd_remap;   // 0 plain, 1 contiguous eighths, G > 1 chunks of G blocks
+  if (vals32) {   // single-precision operator copy: only the default kernel configuration is built for it
+    if (r)
+      hipLaunchKernelGGL((k_spmv<1, 4, 1, 1, float>), dim3(grid), dim3(256), 0, st, n_launch, chunk, slice_list,
+                         h->n_own, p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, p.win_ok.p, p.diag_k.p, vals32,
+                         x, y, fixed, addv, r, partials, partial_off, done, remap);
+    else
+      hipLaunchKernelGGL((k_spmv<0, 4, 1, 1, float>), dim3(grid), dim3(256), 0, st, n_launch, chunk, slice_list,
+                         h->n_own, p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, p.win_ok.p, p.diag_k.p, vals32,
+                         x, y, fixed, addv, r, partials, partial_off, done, remap);
+    GL_HIP(hipGetLastError());
+    return;
+  }
 #define GL_SPMV3(DOTS, UNR, NT, CIDX)                                                                              \
   hipLaunchKernelGGL((k_spmv<DOTS, UNR, NT, CIDX>), dim3(grid), dim3(256), 0, st, n_launch, chunk, slice_list,      \
                      h->n_own, p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, p.win_ok.p, p.diag_k.p, vals, x, y, \
@@ -839,7 +872,8 @@ void gl_launch_spmv_block(glims_ctx* h, hipStream_t st, int n_launch, const int3
 
 void gl_spmv_scalar(glims_ctx* h, const double* vals, const double* x, double* y, bool masked) {
   gl_launch_spmv(h, h->st, h->pat.n_slices, nullptr, vals, x, y,
-                 masked && h->have_fixed_c ? h->fixed_c.p : nullptr, nullptr, nullptr, nullptr, 0, nullptr);
+                 masked && h->have_fixed_c ? h->fixed_c.p : nullptr, nullptr, nullptr, nullptr, 0, nullptr,
+                 vals == h->vA.p && h->jac32 ? h->vA32.p : nullptr);
 }
 
 void gl_spmv_block(glims_ctx* h, const double* x, double* y, bool masked) {

@@ -25,7 +25,7 @@
 
 void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* slice_list, const double* vals,
                     const double* x, double* y, const uint8_t* fixed, const double* addv, const double* r,
-                    double* partials, int partial_off, const int* done);
+                    double* partials, int partial_off, const int* done, const float* vals32 = nullptr);
 void gl_launch_spmv_block(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* slice_list, const double* x,
                           double* y, const uint8_t* fixed, const double* r, double* partials, int partial_off,
                           const int* done, bool single_precision_operator = false);
@@ -639,6 +639,7 @@ struct CgVecs {
   const uint8_t* fixed;
   int bs;
   bool k32 = false;         // block operator: stream the single-precision copy of K_el
+  const float* vals32 = nullptr;   // scalar operator in single precision (optional; streamed instead of vals)
 };
 
 static void apply_with_halo(glims_ctx* h, const CgVecs& v) {
@@ -649,7 +650,7 @@ static void apply_with_halo(glims_ctx* h, const CgVecs& v) {
       const bool timed = h->time_spmv && h->tev_used + 2 <= h->tev.size();
       if (timed) GL_HIP(hipEventRecord(h->tev[h->tev_used++], h->st));
       gl_launch_spmv(h, h->st, p.n_slices, nullptr, v.vals, v.u, v.w, v.fixed, nullptr, v.r, h->partials.p, 0,
-                     h->done.p);
+                     h->done.p, v.vals32);
       if (timed) GL_HIP(hipEventRecord(h->tev[h->tev_used++], h->st));
     } else
       gl_launch_spmv_block(h, h->st, p.n_slices, nullptr, v.u, v.w, v.fixed, v.r, h->partials.p, 0, h->done.p, v.k32);
@@ -660,14 +661,14 @@ static void apply_with_halo(glims_ctx* h, const CgVecs& v) {
   const int nbi = p.n_interior > 0 ? gl_spmv_grid(p.n_interior) : 0;   // partial-sum slots of the interior launch
   if (v.vals)
     gl_launch_spmv(h, h->st, p.n_interior, p.interior_slices.p, v.vals, v.u, v.w, v.fixed, nullptr, v.r,
-                   h->partials.p, 0, h->done.p);
+                   h->partials.p, 0, h->done.p, v.vals32);
   else
     gl_launch_spmv_block(h, h->st, p.n_interior, p.interior_slices.p, v.u, v.w, v.fixed, v.r, h->partials.p, 0,
                          h->done.p, v.k32);
   halo_finish(h);
   if (v.vals)
     gl_launch_spmv(h, h->st, p.n_boundary, p.boundary_slices.p, v.vals, v.u, v.w, v.fixed, nullptr, v.r,
-                   h->partials.p, nbi, h->done.p);
+                   h->partials.p, nbi, h->done.p, v.vals32);
   else
     gl_launch_spmv_block(h, h->st, p.n_boundary, p.boundary_slices.p, v.u, v.w, v.fixed, v.r, h->partials.p, nbi,
                          h->done.p, v.k32);
@@ -842,7 +843,8 @@ int gl_step(glims_ctx* h, int n_steps) {
                            h->c_old.p, h->cg_u.p);
         if (h->have_c_old) {
           gl_launch_spmv(h, h->st, p.n_slices, nullptr, h->vA.p, h->cg_u.p, h->cg_w.p,
-                         h->have_fixed_c ? h->fixed_c.p : nullptr, nullptr, nullptr, nullptr, 0, nullptr);
+                         h->have_fixed_c ? h->fixed_c.p : nullptr, nullptr, nullptr, nullptr, 0, nullptr,
+                         h->jac32 ? h->vA32.p : nullptr);
           hipLaunchKernelGGL(k_ws_apply, dim3(grid_exact(n)), dim3(256), 0, h->st, n, h->cg_r.p, h->cg_w.p, h->c.p,
                              h->cg_u.p);
         }
@@ -850,6 +852,7 @@ int gl_step(glims_ctx* h, int n_steps) {
       }
       CgVecs v{h->c.p, h->cg_r.p, h->cg_u.p, h->cg_w.p, h->cg_p.p, h->cg_s.p,
                h->dinv.p, h->vA.p, h->have_fixed_c ? h->fixed_c.p : nullptr, 1};
+      if (h->jac32) v.vals32 = h->vA32.p;
       int64_t its = 0;
       double res = 0.0;
       const int slot = std::min(it, 7);

@@ -65,6 +65,10 @@ typedef struct glims_options {
 } glims_options;
 
 #define GLIMS_FLAG_EXTRAPOLATE_GUESS 1  /* Newton guess c^n + (c^n - c^{n-1}) instead of c^n (reference: c^n) */
+#define GLIMS_FLAG_FP32_JACOBIAN 4       /* OFF by default.  The Newton Jacobian A(c) is stored and streamed in single
+                                           precision inside the Krylov solves (products, sums, all vectors and the Newton
+                                           residual stay fp64, so the iteration still converges to the fp64 tolerance of
+                                           the same fixed point); takes effect at glims_setup */
 #define GLIMS_FLAG_WARM_START 2         /* first linear solve of a step starts from the previous step's increment
                                            (ignored when GLIMS_FLAG_EXTRAPOLATE_GUESS is set) */
 

@@ -596,3 +596,28 @@ def test_randomised_small_problems_match_the_oracle(backend, seed):
     # solution errors = condition number x the residual tolerances (1e-10): material contrasts of 1e4 are allowed here
     assert rel_l2(c, co) < 2e-9, (seed, dim, n)
     assert rel_l2(u, uo) < 1e-6, (seed, dim, n)
+
+
+def test_optional_fp32_jacobian_converges_to_the_same_fixed_point(backend):
+    """GLIMS_FLAG_FP32_JACOBIAN (off by default): the Jacobian is stored in single precision inside the Krylov solves,
+    the Newton residual stays fp64 -- the time steps converge to the same fp64 tolerance, the answers agree with the
+    oracle like the default path's, and A(c) x through the operator hook is the fp32-rounded operator."""
+    mesh = BoxMesh((0, 0, 0), (10.0, 9.0, 8.0), 20, 18, 16)
+    lab = (1 + (mesh.cell_midpoints()[:, 0] > 5.0)).astype(np.int32)
+    c0 = np.exp(-0.2 * ((mesh.points - np.array([5.0, 4.5, 4.0])) ** 2).sum(1))
+    o = _oracle(mesh, lab, 1.0)
+    _, co = o.run(c0, 5.0, mechanics=False)
+    outs = {}
+    for flags in (backend.FLAG_WARM_START, backend.FLAG_WARM_START | backend.FLAG_FP32_JACOBIAN):
+        h = _handle(backend, mesh, lab, 1.0, mechanics=False, flags=flags)
+        h.set_state(c0)
+        assert h.step(5) == 0
+        x = np.random.default_rng(1).standard_normal(mesh.num_vertices())
+        outs[flags] = (h.get_state(want_u=False)[0], h.apply(0, x)[0], h.stats())
+        h.close()
+    c64, A64, st64 = outs[backend.FLAG_WARM_START]
+    c32, A32, st32 = outs[backend.FLAG_WARM_START | backend.FLAG_FP32_JACOBIAN]
+    assert rel_l2(c64, co) < 1e-9 and rel_l2(c32, co) < 1e-9
+    assert st32['last_newton_res'] < 1e-9 * max(1.0, st64['last_newton_res'] / 1e-10)
+    assert 1e-9 < rel_l2(A32, A64) < 1e-6                          # the hook shows the single-precision operator
+    assert st32['newton_its'] <= st64['newton_its'] + 2
