@@ -274,7 +274,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "DoF-updates/s (implicit RD timestep) on 3D brain mesh",
+            "metric": "DoF-updates/s (implicit RD timestep) on 3D brain mesh; 1/2/4/8 GPU + %HBM roofline",
             "value": n_global * (dim + 1 if coupled else 1) * steps_done / elapsed,
             "unit": "DoF-updates/s",
             "n_gpus": world,
