@@ -48,7 +48,7 @@ __device__ __forceinline__ void block_sum2(double a, double b, double* __restric
   if (threadIdx.x < 2) pv[(size_t)blockIdx.x * 2 + threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
 }
 
-// u = Dinv r, p = s = 0, and the first (r.u, r.r) partials; also clears the recurrence scalars and the decision word
+// u = Dinv r and the first (r.u, r.r) partials (p, s start undefined: the first update has beta = 0 and skips them); also clears the recurrence scalars and the decision word
 // of the previous solve (two memset nodes on the stream cost ~20 us of idle device per solve)
 template <int BS>
 __global__ __launch_bounds__(256) void k_cg_init(int64_t n_own, const double* __restrict__ r,
@@ -63,9 +63,7 @@ __global__ __launch_bounds__(256) void k_cg_init(int64_t n_own, const double* __
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_own; i += stride) {
     if constexpr (BS == 1) {
       const double ri = r[i], ui = dinv[i] * ri;
-      u[i] = ui;
-      p[i] = 0.0;
-      s[i] = 0.0;
+      u[i] = ui;           // p and s are not initialised: the first update (beta = 0) does not read them
       pg += ri * ui;
       pr += ri * ri;
     } else {
@@ -78,8 +76,6 @@ __global__ __launch_bounds__(256) void k_cg_init(int64_t n_own, const double* __
 #pragma unroll
         for (int b = 0; b < BS; ++b) v += dinv[i * BS * BS + a * BS + b] * rv[b];
         u[i * BS + a] = v;
-        p[i * BS + a] = 0.0;
-        s[i * BS + a] = 0.0;
         pg += rv[a] * v;
         pr += rv[a] * rv[a];
       }
@@ -126,6 +122,7 @@ __global__ __launch_bounds__(256) void k_cg_update(int64_t n_own, const double* 
     return;
   }
   const double it = prev[SC_IT];
+  const bool first = !(it > 0.0);
   double beta = 0.0, denom = delta;
   if (it > 0.0) {
     beta = gamma / prev[SC_GAMMA];
@@ -160,10 +157,17 @@ __global__ __launch_bounds__(256) void k_cg_update(int64_t n_own, const double* 
       // following SpMV gathers from -- is what stays in L2 / Infinity Cache
       double2 uu, pp, ww, ss, rr2, dd, xx, pn, sn, rn, un;
       if (nt) {
-        uu = ntload2(u2 + i); pp = ntload2(p2 + i); ww = ntload2(w2 + i);
-        ss = ntload2(s2 + i); rr2 = ntload2(r2 + i); dd = ntload2(d2 + i); xx = ntload2(x2 + i);
+        uu = ntload2(u2 + i); ww = ntload2(w2 + i);
+        rr2 = ntload2(r2 + i); dd = ntload2(d2 + i); xx = ntload2(x2 + i);
       } else {
-        uu = u2[i]; pp = p2[i]; ww = w2[i]; ss = s2[i]; rr2 = r2[i]; dd = d2[i]; xx = x2[i];
+        uu = u2[i]; ww = w2[i]; rr2 = r2[i]; dd = d2[i]; xx = x2[i];
+      }
+      if (first) {          // beta = 0: p = u, s = w; the old p, s (uninitialised) are not read
+        pp.x = pp.y = ss.x = ss.y = 0.0;
+      } else if (nt) {
+        pp = ntload2(p2 + i); ss = ntload2(s2 + i);
+      } else {
+        pp = p2[i]; ss = s2[i];
       }
       pn.x = uu.x + beta * pp.x;
       pn.y = uu.y + beta * pp.y;
@@ -186,8 +190,8 @@ __global__ __launch_bounds__(256) void k_cg_update(int64_t n_own, const double* 
     }
     if ((n_own & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
       const int64_t i = n_own - 1;
-      const double pi = u[i] + beta * p[i];
-      const double si = w[i] + beta * s[i];
+      const double pi = u[i] + (first ? 0.0 : beta * p[i]);
+      const double si = w[i] + (first ? 0.0 : beta * s[i]);
       p[i] = pi;
       s[i] = si;
       x[i] += alpha * pi;
@@ -208,8 +212,8 @@ __global__ __launch_bounds__(256) void k_cg_update(int64_t n_own, const double* 
 #pragma unroll
       for (int a = 0; a < BS; ++a) {
         const int64_t j = i * BS + a;
-        const double pi = u[j] + beta * p[j];
-        const double si = w[j] + beta * s[j];
+        const double pi = u[j] + (first ? 0.0 : beta * p[j]);
+        const double si = w[j] + (first ? 0.0 : beta * s[j]);
         p[j] = pi;
         s[j] = si;
         x[j] += alpha * pi;
