@@ -30,6 +30,7 @@ void read_tuning(glims_ctx* h) {
   if (const char* e = getenv("GLIMS_RD_UNROLL")) h->tune_rd_unroll = atoi(e);
   if (const char* e = getenv("GLIMS_IDX16")) h->tune_idx16 = atoi(e);
   if (const char* e = getenv("GLIMS_TIME_SPMV")) h->time_spmv = atoi(e) != 0;
+  if (const char* e = getenv("GLIMS_FUSED_PACK")) h->tune_fused_pack = atoi(e);
   if (const char* e = getenv("GLIMS_MECH_MIXED")) h->mech_mixed = atoi(e);
   if (const char* e = getenv("GLIMS_MHIST")) h->mh_depth = std::max(0, std::min((int)glims_ctx::MHIST, atoi(e)));
   if (const char* e = getenv("GLIMS_UPD_NT")) h->tune_upd_nt = atoi(e);
@@ -754,6 +755,21 @@ int glims_set_halo(glims_ctx* h, int n_peers, const int32_t* peer_rank, const in
       idx[k] = h->old2new[send_idx[k]];
     }
     h->send_idx.upload(idx, h->st);
+    {   // inverse map: which send slots does an owned row feed (a corner node goes to several peers)
+      std::vector<int32_t> cnt(h->n_own, 0);
+      for (int64_t k = 0; k < h->n_send; ++k) cnt[idx[k]]++;
+      std::vector<int32_t> ref(h->n_own, -1), ptr(1, 0);
+      for (int64_t r = 0; r < h->n_own; ++r)
+        if (cnt[r]) {
+          ref[r] = (int32_t)ptr.size() - 1;
+          ptr.push_back(ptr.back() + cnt[r]);
+        }
+      std::vector<int32_t> slot(std::max<int64_t>(h->n_send, 1), 0), fill(ptr.begin(), ptr.end());
+      for (int64_t k = 0; k < h->n_send; ++k) slot[fill[ref[idx[k]]]++] = (int32_t)k;
+      h->send_ref.upload(ref, h->st);
+      h->send_slot_ptr.upload(ptr, h->st);
+      h->send_slot.upload(slot, h->st);
+    }
     h->sendbuf.alloc_zero((size_t)std::max<int64_t>(h->n_send, 1) * h->dim, h->st);
     GL_HIP(hipStreamSynchronize(h->st));
     return GLIMS_OK;

@@ -171,6 +171,7 @@ struct glims_ctx {
   //   GLIMS_SPMV_NT     0|1|2      non-temporal loads: none | values + columns | values only
   //   GLIMS_IDX16       0|1        columns as int32 | as 16-bit (window, offset) codes where a slice allows it
   //   GLIMS_RD_NT / GLIMS_RD_REMAP / GLIMS_RD_UNROLL (4|8|12|24)   the same for the assembly sweep
+  //   GLIMS_FUSED_PACK  0|1        partitioned run: halo payload packed by the vector-update kernel (1) or by k_pack
   //   GLIMS_MECH_MIXED  0|1|2      elasticity: fp32 copy of K_el in the inner PCG under fp64 iterative refinement:
   //                                off | when K_el exceeds the Infinity Cache (default) | always
   //   GLIMS_MHIST       0..8       depth of the elasticity solve history used for the initial guess (6)
@@ -229,6 +230,10 @@ struct glims_ctx {
   std::vector<int32_t> peer_rank;
   std::vector<int64_t> send_ptr, recv_ptr;
   dvec<int32_t> send_idx;
+  // row -> send slots (the vector-update kernel packs the halo payload itself): send_ref[row] = -1 or r with the
+  // slots send_slot[send_slot_ptr[r] .. send_slot_ptr[r+1])
+  dvec<int32_t> send_ref, send_slot_ptr, send_slot;
+  int tune_fused_pack = 1;                  // GLIMS_FUSED_PACK
   dvec<double> sendbuf;
   int64_t n_send = 0;
   NodeMail nm;                              // active when nm.slots != nullptr

@@ -48,6 +48,24 @@ __device__ __forceinline__ void block_sum2(double a, double b, double* __restric
   if (threadIdx.x < 2) pv[(size_t)blockIdx.x * 2 + threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
 }
 
+// halo payload of one owned row, written by the kernel that has just produced the row's value(s)
+struct PackMap {
+  const int32_t* ref = nullptr;    // [n_own]: -1 or index into ptr; nullptr = no fused packing
+  const int32_t* ptr = nullptr;
+  const int32_t* slot = nullptr;
+  double* sendbuf = nullptr;
+};
+template <int BS>
+__device__ __forceinline__ void pack_row(const PackMap& pm, int64_t row, const double* vals /*[BS]*/) {
+  const int32_t r = pm.ref[row];
+  if (r < 0) return;
+  for (int32_t q = pm.ptr[r]; q < pm.ptr[r + 1]; ++q) {
+    const int64_t k = pm.slot[q];
+#pragma unroll
+    for (int a = 0; a < BS; ++a) pm.sendbuf[k * BS + a] = vals[a];
+  }
+}
+
 // u = Dinv r and the first (r.u, r.r) partials (p, s start undefined: the first update has beta = 0 and skips them); also clears the recurrence scalars and the decision word
 // of the previous solve (two memset nodes on the stream cost ~20 us of idle device per solve)
 template <int BS>
@@ -55,7 +73,7 @@ __global__ __launch_bounds__(256) void k_cg_init(int64_t n_own, const double* __
                                                   const double* __restrict__ dinv, double* __restrict__ u,
                                                   double* __restrict__ p, double* __restrict__ s,
                                                   double* __restrict__ pv, double* __restrict__ scal,
-                                                  int* __restrict__ done) {
+                                                  int* __restrict__ done, const PackMap pm) {
   if (blockIdx.x == 0 && threadIdx.x < 2 * SC_COUNT + 2) scal[threadIdx.x] = 0.0;
   if (blockIdx.x == 0 && threadIdx.x == 0) *done = 0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -64,10 +82,11 @@ __global__ __launch_bounds__(256) void k_cg_init(int64_t n_own, const double* __
     if constexpr (BS == 1) {
       const double ri = r[i], ui = dinv[i] * ri;
       u[i] = ui;           // p and s are not initialised: the first update (beta = 0) does not read them
+      if (pm.ref) pack_row<1>(pm, i, &ui);
       pg += ri * ui;
       pr += ri * ri;
     } else {
-      double rv[BS];
+      double rv[BS], uv[BS];
 #pragma unroll
       for (int a = 0; a < BS; ++a) rv[a] = r[i * BS + a];
 #pragma unroll
@@ -76,9 +95,11 @@ __global__ __launch_bounds__(256) void k_cg_init(int64_t n_own, const double* __
 #pragma unroll
         for (int b = 0; b < BS; ++b) v += dinv[i * BS * BS + a * BS + b] * rv[b];
         u[i * BS + a] = v;
+        uv[a] = v;
         pg += rv[a] * v;
         pr += rv[a] * rv[a];
       }
+      if (pm.ref) pack_row<BS>(pm, i, uv);
     }
   }
   block_sum2(pg, pr, pv);
@@ -108,7 +129,8 @@ __global__ __launch_bounds__(256) void k_cg_update(int64_t n_own, const double* 
                                                     double* __restrict__ p, double* __restrict__ s,
                                                     double* __restrict__ x, double* __restrict__ r,
                                                     double* __restrict__ u, const double* __restrict__ w,
-                                                    const double* __restrict__ dinv, double* __restrict__ pv, int nt) {
+                                                    const double* __restrict__ dinv, double* __restrict__ pv, int nt,
+                                                    const PackMap pm) {
   if (*done) return;
   const double gamma = red[0], delta = red[1], rr = red[2];
   const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
@@ -187,6 +209,10 @@ __global__ __launch_bounds__(256) void k_cg_update(int64_t n_own, const double* 
         p2[i] = pn; s2[i] = sn; x2[i] = xx; r2[i] = rn;
       }
       u2[i] = un;
+      if (pm.ref) {
+        pack_row<1>(pm, 2 * i, &un.x);
+        pack_row<1>(pm, 2 * i + 1, &un.y);
+      }
     }
     if ((n_own & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
       const int64_t i = n_own - 1;
@@ -197,8 +223,10 @@ __global__ __launch_bounds__(256) void k_cg_update(int64_t n_own, const double* 
       x[i] += alpha * pi;
       const double ri = r[i] - alpha * si;
       r[i] = ri;
-      u[i] = dinv[i] * ri;
-      pg += ri * (dinv[i] * ri);
+      const double ui = dinv[i] * ri;
+      u[i] = ui;
+      if (pm.ref) pack_row<1>(pm, i, &ui);
+      pg += ri * ui;
       pr += ri * ri;
     }
     block_sum2(pg, pr, pv);
@@ -220,15 +248,18 @@ __global__ __launch_bounds__(256) void k_cg_update(int64_t n_own, const double* 
         rv[a] = r[j] - alpha * si;
         r[j] = rv[a];
       }
+      double uv[BS];
 #pragma unroll
       for (int a = 0; a < BS; ++a) {
         double v = 0.0;
 #pragma unroll
         for (int b = 0; b < BS; ++b) v += dinv[i * BS * BS + a * BS + b] * rv[b];
         u[i * BS + a] = v;
+        uv[a] = v;
         pg += rv[a] * v;
         pr += rv[a] * rv[a];
       }
+      if (pm.ref) pack_row<BS>(pm, i, uv);
     }
   }
   block_sum2(pg, pr, pv);
@@ -517,9 +548,10 @@ inline unsigned grid_exact(int64_t n, int bs = 256) { return (unsigned)((n + bs 
 // ===================================================================================================
 // halo exchange (RCCL grouped send/recv on the communication stream)
 // ===================================================================================================
-static void halo_start(glims_ctx* h, double* vec, int bs) {
+// `prepacked`: the kernel that produced `vec` has written the send buffer already (PackMap)
+static void halo_start(glims_ctx* h, double* vec, int bs, bool prepacked = false) {
   if (h->world <= 1 || h->n_peers == 0) return;
-  if (h->n_send > 0) {
+  if (h->n_send > 0 && !prepacked) {
     hipLaunchKernelGGL(k_pack, dim3(grid_exact(h->n_send * bs)), dim3(256), 0, h->st, h->n_send, bs,
                        h->send_idx.p, vec, h->sendbuf.p);
     GL_HIP(hipGetLastError());
@@ -661,7 +693,7 @@ static void apply_with_halo(glims_ctx* h, const CgVecs& v) {
     return;
   }
   // interior slices overlap with the xGMI transfer; boundary slices run once the ghosts have landed
-  halo_start(h, v.u, v.bs);
+  halo_start(h, v.u, v.bs, /*prepacked=*/h->tune_fused_pack != 0);
   const int nbi = p.n_interior > 0 ? gl_spmv_grid(p.n_interior) : 0;   // partial-sum slots of the interior launch
   if (v.vals)
     gl_launch_spmv(h, h->st, p.n_interior, p.interior_slices.p, v.vals, v.u, v.w, v.fixed, nullptr, v.r,
@@ -703,7 +735,14 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
     else hipLaunchKernelGGL(K<3>, dim3(g), dim3(256), 0, h->st, __VA_ARGS__);           \
     GL_HIP(hipGetLastError());                                                          \
   } while (0)
-  GL_VEC(k_cg_init, n, v.r, v.dinv, v.u, v.p, v.s, h->partials_v.p, h->scal.p, h->done.p);
+  PackMap pm;
+  if (split && h->tune_fused_pack && h->n_send > 0) {
+    pm.ref = h->send_ref.p;
+    pm.ptr = h->send_slot_ptr.p;
+    pm.slot = h->send_slot.p;
+    pm.sendbuf = h->sendbuf.p;
+  }
+  GL_VEC(k_cg_init, n, v.r, v.dinv, v.u, v.p, v.s, h->partials_v.p, h->scal.p, h->done.p, pm);
   int done = 0;
   double info[2] = {0.0, 0.0};
   const int batch = h->opt.check_every > 0 ? h->opt.check_every : 8;
@@ -732,7 +771,7 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
                          h->done.p, h->nm);
       allreduce_sum(h, h->red.p, 3);
       GL_VEC(k_cg_update, n, h->red.p, prev, cur, info_dev, h->done.p, tol2, v.p, v.s, v.x, v.r, v.u, v.w, v.dinv,
-             h->partials_v.p, h->tune_upd_nt);
+             h->partials_v.p, h->tune_upd_nt, pm);
     }
     enq += nb;
     if (defer && hint > 0) {
