@@ -38,3 +38,18 @@ def test_c_port_uniform_field_recurrence():
     for _ in range(3):
         cn = (-(1 - .1) + np.sqrt((1 - .1) ** 2 + 4 * .1 * cn)) / (2 * .1)
     assert np.abs(c - cn).max() < 1e-12
+
+
+def test_c_oracle_is_clean_under_address_and_ub_sanitizers():
+    """`make -C oracle sanitize`: the C restatement on a small 3-D problem with
+    -fsanitize=address,undefined; any report makes the run fail."""
+    import os
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        import pytest
+        pytest.skip("no gcc")
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    r = subprocess.run(["make", "-C", here, "sanitize"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "sanitize_main: status 0" in r.stdout and "ERROR" not in r.stderr and "runtime error" not in r.stderr
