@@ -19,8 +19,10 @@ from _brain_like import brain_like_mesh
 
 world = int(os.environ.get("WORLD_SIZE", "1"))
 if world > 1:
-    torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
-    dist.init_process_group(backend="cpu:gloo,cuda:nccl")
+    # GLIMS_FORCE_DEVICE=<ordinal> + GLIMS_TRANSPORT=gloo: rehearsal with all ranks on one GPU (RCCL needs one GPU per rank)
+    forced = os.environ.get("GLIMS_FORCE_DEVICE")
+    torch.cuda.set_device(int(forced if forced is not None else os.environ["LOCAL_RANK"]))
+    dist.init_process_group(backend="gloo" if forced is not None else "cpu:gloo,cuda:nccl")
 rank = dist.get_rank() if world > 1 else 0
 
 
