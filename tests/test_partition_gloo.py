@@ -148,3 +148,55 @@ def test_rccl_unique_id_reaches_every_rank(tmp_path):
     a = open(os.path.join(str(tmp_path), "uid0.bin"), "rb").read()
     b = open(os.path.join(str(tmp_path), "uid1.bin"), "rb").read()
     assert len(a) == 256 and a == b and any(a)
+
+
+class _FakeHandle:
+    """Stands in for _backend.Handle in the collective agreement logic of parallel.setup_node_mailbox."""
+
+    def __init__(self, fail_map, fail_selftest):
+        self.fail_map, self.fail_selftest, self.calls = fail_map, fail_selftest, []
+
+    def comm_mailbox(self, name):
+        self.calls.append(("map", name))
+        if name is not None and self.fail_map:
+            raise RuntimeError("hipHostRegister failed (simulated)")
+
+    def comm_mailbox_selftest(self):
+        self.calls.append(("selftest",))
+        if self.fail_selftest:
+            raise RuntimeError("timed out (simulated)")
+
+
+def _mailbox_worker(rank, world, port, out_dir, scenario):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.pop("GLIMS_ALLREDUCE", None)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from glimslib_amd.parallel import setup_node_mailbox
+        h = _FakeHandle(fail_map=(scenario == "map" and rank == 1), fail_selftest=(scenario == "selftest" and rank == 0))
+        used = setup_node_mailbox(h, dist, rank)
+        names = [c[1] for c in h.calls if c[0] == "map"]
+        np.savez(os.path.join(out_dir, "mb_%s_%d.npz" % (scenario, rank)), used=used, n_map=len(names),
+                 first=str(names[0]), last=str(names[-1]), selftests=sum(c[0] == "selftest" for c in h.calls))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scenario", ["ok", "map", "selftest"])
+def test_node_mailbox_is_used_by_all_ranks_or_by_none(tmp_path, scenario):
+    """parallel.setup_node_mailbox: every rank maps the same shared-memory name; if mapping or the self-test fails on
+    ANY rank, ALL ranks switch the mailbox off again (and fall back to RCCL / the transport's all-reduce)."""
+    world = 2
+    mp.spawn(_mailbox_worker, args=(world, _free_port(), str(tmp_path), scenario), nprocs=world, join=True)
+    z = [np.load(os.path.join(str(tmp_path), "mb_%s_%d.npz" % (scenario, r))) for r in range(world)]
+    assert str(z[0]['first']) == str(z[1]['first']) and str(z[0]['first']).startswith("/glims_")
+    assert not os.path.exists("/dev/shm" + str(z[0]['first']))                 # rank 0 unlinked the object
+    if scenario == "ok":
+        assert all(bool(q['used']) for q in z) and all(int(q['selftests']) == 1 for q in z)
+        assert all(str(q['last']) == str(q['first']) for q in z)
+    else:
+        assert not any(bool(q['used']) for q in z)
+        assert all(str(q['last']) == "None" for q in z)                        # comm_mailbox(None) on every rank
+        if scenario == "map":
+            assert all(int(q['selftests']) == 0 for q in z)                    # nobody runs the collective self-test
