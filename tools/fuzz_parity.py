@@ -3,7 +3,7 @@ import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.
 import glimslib_amd._backend as backend
 import test_gpu_parity as T
 bad = 0
-for seed in range(8, 136):
+for seed in range(8, int(sys.argv[1]) if len(sys.argv) > 1 else 136):
     try:
         T.test_randomised_small_problems_match_the_oracle(backend, seed)
     except Exception as e:
