@@ -508,7 +508,9 @@ int glims_apply(glims_ctx* h, int which, const double* x, double* y, int reps, d
   return guarded(h, [&]() {
     GL_REQUIRE(h->is_setup, "glims_apply before glims_setup");
     GL_REQUIRE(x && y && reps >= 1, "bad arguments");
-    GL_REQUIRE(which >= 0 && which <= 5, "unknown operator");
+    GL_REQUIRE(which >= 0 && which <= 6, "unknown operator");
+    if (which == 6) GL_REQUIRE(h->tune_idx16 && h->stats.nnz_idx16 == h->stats.nnz_padded,
+                               "the slot-pair study needs 16-bit codes on every slice");
     read_tuning(h);
     const int d = h->dim;
     const bool blk_in = which == 3, blk_out = which == 3 || which == 4;
@@ -519,9 +521,12 @@ int glims_apply(glims_ctx* h, int which, const double* x, double* y, int reps, d
     to_device_perm(h, x, xin.p, blk_in ? d : 1);
     const bool saved_mload = h->have_mload;
     h->have_mload = false;
+    if (which == 6) gl_spmv_pairs_study(h, h->vA.p, xin.p, yout.p);   // converts the layout (not timed)
     GL_HIP(hipEventRecord(h->ev_a, h->st));
     for (int r = 0; r < reps; ++r) {
-      if (which == 5)   // A x with the fused dot product of the Krylov iteration (timing studies)
+      if (which == 6)
+        gl_spmv_pairs_study_run(h, xin.p, yout.p);
+      else if (which == 5)   // A x with the fused dot product of the Krylov iteration (timing studies)
         gl_launch_spmv(h, h->st, h->pat.n_slices, nullptr, h->vA.p, xin.p, yout.p, nullptr, nullptr, xin.p,
                        h->partials.p, 0, nullptr, h->jac32 ? h->vA32.p : nullptr);
       else if (which <= 2)

@@ -191,6 +191,8 @@ struct glims_ctx {
 
   // scalar operator planes (SELL-64 layout) and block planes
   dvec<double> vM, vS, vA, vKel, vG;
+  dvec<double> study_pvals;                // slot-pair layout study (glims_apply which = 6)
+  dvec<uint16_t> study_pc16;
   dvec<float> vA32;                        // Newton Jacobian in single precision (GLIMS_FLAG_FP32_JACOBIAN only)
   bool jac32 = false;
   dvec<float> vKel32;                      // single-precision copy of K_el (inner solves of the elasticity solver)
@@ -259,6 +261,8 @@ void gl_rd_assemble(glims_ctx* h, const double* c, const double* b, const double
 void gl_spmv_scalar(glims_ctx* h, const double* vals, const double* x, double* y, bool masked);
 void gl_apply_G(glims_ctx* h, const double* c, double* y);
 void gl_spmv_block(glims_ctx* h, const double* x, double* y, bool masked);
+void gl_spmv_pairs_study(glims_ctx* h, const double* vals, const double* x, double* y);
+void gl_spmv_pairs_study_run(glims_ctx* h, const double* x, double* y);
 
 // solver.hip ----------------------------------------------------------------------------------------
 int gl_step(glims_ctx* h, int n_steps);

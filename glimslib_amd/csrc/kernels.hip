@@ -479,6 +479,79 @@ __global__ __launch_bounds__(256) void k_spmv(int n_launch, int chunk, const int
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// STUDY (glims_apply which = 6, not used by the solver): "slot-pair" SELL -- two consecutive slots of a row are adjacent
+// in memory, so a lane reads its values 16 B and its column codes 4 B at a time (1024-B / 256-B wave loads, half the
+// load instructions); an odd last slot stays a single 8-B / 2-B load.  Layout per slice with len slots:
+//   pairs q = 0 .. len/2 - 1 at pbase + (q*64 + lane)*2 + {0,1},  odd tail at pbase + (len/2)*128 + lane.
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_to_pairs(int n_slices, const int64_t* __restrict__ slice_ptr, const double* __restrict__ vals,
+                           const uint16_t* __restrict__ c16, double* __restrict__ pvals, uint16_t* __restrict__ pc16) {
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const int64_t base = slice_ptr[s];
+  const int len = (int)((slice_ptr[s + 1] - base) >> 6);
+  for (int k = 0; k < len; ++k) {
+    const int64_t src = base + (int64_t)k * GL_WAVE + lane;
+    int64_t d;
+    if ((len & 1) && k == len - 1) d = base + (int64_t)(len / 2) * 2 * GL_WAVE + lane;
+    else d = base + ((int64_t)(k >> 1) * GL_WAVE + lane) * 2 + (k & 1);
+    pvals[d] = vals[src];
+    pc16[d] = c16[src];
+  }
+}
+
+template <int DOTS>
+__global__ __launch_bounds__(256) void k_spmv_pairs(int n_launch, int chunk, int64_t n_own,
+                                                     const int64_t* __restrict__ slice_ptr,
+                                                     const uint16_t* __restrict__ pc16,
+                                                     const int32_t* __restrict__ win_base,
+                                                     const double* __restrict__ pvals, const double* __restrict__ x,
+                                                     double* __restrict__ y, int remap) {
+  const int b = remap > 1 ? xcd_chunk_remap(blockIdx.x, gridDim.x, remap) : blockIdx.x;
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int s_end = min(n_launch, (b + 1) * chunk);
+  for (int s = b * chunk + wid; s < s_end; s += 4) {
+    const int64_t row = (int64_t)s * GL_WAVE + lane;
+    const int64_t base = slice_ptr[s];
+    const int len = (int)((slice_ptr[s + 1] - base) >> 6);
+    const int32_t wb = win_base[(int64_t)s * GL_N_WIN + (lane & (GL_N_WIN - 1))];
+    const double2* v2 = reinterpret_cast<const double2*>(pvals + base) + lane;
+    const uint32_t* c2 = reinterpret_cast<const uint32_t*>(pc16 + base) + lane;
+    const int np = len >> 1;
+    double acc = 0.0;
+    int q = 0;
+    for (; q + 2 <= np; q += 2) {   // 2 pairs = 4 entries per batch
+      uint32_t cc[2];
+      double2 vv[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) cc[j] = __builtin_nontemporal_load(c2 + (int64_t)(q + j) * GL_WAVE);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        vv[j].x = __builtin_nontemporal_load(&v2[(int64_t)(q + j) * GL_WAVE].x);
+        vv[j].y = __builtin_nontemporal_load(&v2[(int64_t)(q + j) * GL_WAVE].y);
+      }
+      double xg[4];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        xg[2 * j] = x[decode_col(cc[j] & 0xffffu, wb)];
+        xg[2 * j + 1] = x[decode_col(cc[j] >> 16, wb)];
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc += vv[j].x * xg[2 * j] + vv[j].y * xg[2 * j + 1];
+    }
+    for (; q < np; ++q) {
+      const uint32_t c = __builtin_nontemporal_load(c2 + (int64_t)q * GL_WAVE);
+      const double2 v = v2[(int64_t)q * GL_WAVE];
+      acc += v.x * x[decode_col(c & 0xffffu, wb)] + v.y * x[decode_col(c >> 16, wb)];
+    }
+    if (len & 1) {
+      const int64_t t = base + (int64_t)np * 2 * GL_WAVE + lane;
+      acc += pvals[t] * x[decode_col(pc16[t], wb)];
+    }
+    if (row < n_own) y[row] = acc;
+  }
+}
+
 // block version (mechanics): BS x BS blocks stored as BS*BS slot-major planes per slice entry
 template <int BS, int DOTS>
 __global__ __launch_bounds__(256) void k_spmv_block(int n_launch, int chunk,
@@ -874,6 +947,30 @@ void gl_spmv_scalar(glims_ctx* h, const double* vals, const double* x, double* y
   gl_launch_spmv(h, h->st, h->pat.n_slices, nullptr, vals, x, y,
                  masked && h->have_fixed_c ? h->fixed_c.p : nullptr, nullptr, nullptr, nullptr, 0, nullptr,
                  vals == h->vA.p && h->jac32 ? h->vA32.p : nullptr);
+}
+
+void gl_spmv_pairs_study(glims_ctx* h, const double* vals, const double* x, double* y) {
+  const DevPattern& p = h->pat;
+  if (h->study_pvals.n != (size_t)p.total_entries) {
+    h->study_pvals.alloc((size_t)p.total_entries);
+    h->study_pc16.alloc((size_t)p.total_entries);
+  }
+  hipLaunchKernelGGL(k_to_pairs, dim3(p.n_slices), dim3(GL_WAVE), 0, h->st, p.n_slices, p.slice_ptr.p, vals, p.cols16.p,
+                     h->study_pvals.p, h->study_pc16.p);
+  const int grid = gl_spmv_grid(p.n_slices);
+  const int chunk = (p.n_slices + grid - 1) / grid;
+  hipLaunchKernelGGL(k_spmv_pairs<0>, dim3(grid), dim3(256), 0, h->st, p.n_slices, chunk, h->n_own, p.slice_ptr.p,
+                     h->study_pc16.p, p.win_base.p, h->study_pvals.p, x, y, h->tune_xcd_remap);
+  GL_HIP(hipGetLastError());
+}
+
+void gl_spmv_pairs_study_run(glims_ctx* h, const double* x, double* y) {   // layout already converted
+  const DevPattern& p = h->pat;
+  const int grid = gl_spmv_grid(p.n_slices);
+  const int chunk = (p.n_slices + grid - 1) / grid;
+  hipLaunchKernelGGL(k_spmv_pairs<0>, dim3(grid), dim3(256), 0, h->st, p.n_slices, chunk, h->n_own, p.slice_ptr.p,
+                     h->study_pc16.p, p.win_base.p, h->study_pvals.p, x, y, h->tune_xcd_remap);
+  GL_HIP(hipGetLastError());
 }
 
 void gl_spmv_block(glims_ctx* h, const double* x, double* y, bool masked) {

@@ -160,7 +160,8 @@ int glims_reset_stats(glims_ctx* h);
 /* y = Op x, repeated `reps` times on the handle's stream and timed with HIP events (ms_total out, may be NULL).
  * which: 0 = current RD Jacobian A(c), 1 = S, 2 = M (scalar, [n_nodes]);  3 = K_el, ([n_nodes*dim], unconstrained);
  *        4 = G (x [n_nodes] -> y [n_nodes*dim]);  5 = A(c) through the kernel variant with the Krylov iteration's
- *        fused dot product (timing studies).  Ghost rows of y are returned as 0. */
+ *        fused dot product, 6 = A(c) through a study kernel on a slot-pair copy of the layout (timing studies).
+ *        Ghost rows of y are returned as 0. */
 int glims_apply(glims_ctx* h, int which, const double* x, double* y, int reps, double* ms_total);
 
 /* Assembles A(c) and the Newton residual R(c; c_prev) for host vectors (ghost rows 0):

@@ -36,6 +36,11 @@ which = {}
 if study == 'dots':
     variants = [("plain (k_spmv<0,..>)", {}), ("fused dot (k_spmv<1,..>)", {})]
     which = {"fused dot (k_spmv<1,..>)": 5}
+if study == 'pairs':
+    variants = [("8-B value loads (product kernel)", {}), ("slot pairs, 16-B value loads (study)", {})]
+    which = {"slot pairs, 16-B value loads (study)": 6}
+    ya, yb = h.apply(0, x)[0], h.apply(6, x)[0]
+    print("max |difference| of the two products: %.2e (summation order differs)" % np.abs(ya - yb).max())
 res = {n: [] for n, _ in variants}
 for rnd in range(9):
     for name, env in variants:
