@@ -30,6 +30,7 @@ void read_tuning(glims_ctx* h) {
   if (const char* e = getenv("GLIMS_RD_UNROLL")) h->tune_rd_unroll = atoi(e);
   if (const char* e = getenv("GLIMS_IDX16")) h->tune_idx16 = atoi(e);
   if (const char* e = getenv("GLIMS_TIME_SPMV")) h->time_spmv = atoi(e) != 0;
+  if (const char* e = getenv("GLIMS_PAIR_A")) h->tune_pair_A = atoi(e);
   if (const char* e = getenv("GLIMS_FUSED_PACK")) h->tune_fused_pack = atoi(e);
   if (const char* e = getenv("GLIMS_MECH_MIXED")) h->mech_mixed = atoi(e);
   if (const char* e = getenv("GLIMS_MHIST")) h->mh_depth = std::max(0, std::min((int)glims_ctx::MHIST, atoi(e)));
@@ -437,6 +438,7 @@ int glims_setup(glims_ctx* h, int with_mechanics) {
     }
     h->pending = false;
     h->jac32 = (h->opt.flags & GLIMS_FLAG_FP32_JACOBIAN) != 0;
+    h->pair_A = h->tune_pair_A != 0 && h->tune_idx16 != 0 && h->stats.nnz_idx16 == h->stats.nnz_padded;
     gl_assemble_static(h, with_mechanics);
     GL_HIP(hipStreamSynchronize(h->st));
     h->is_setup = true;
@@ -509,8 +511,8 @@ int glims_apply(glims_ctx* h, int which, const double* x, double* y, int reps, d
     GL_REQUIRE(h->is_setup, "glims_apply before glims_setup");
     GL_REQUIRE(x && y && reps >= 1, "bad arguments");
     GL_REQUIRE(which >= 0 && which <= 6, "unknown operator");
-    if (which == 6) GL_REQUIRE(h->tune_idx16 && h->stats.nnz_idx16 == h->stats.nnz_padded,
-                               "the slot-pair study needs 16-bit codes on every slice");
+    if (which == 6) GL_REQUIRE(h->tune_idx16 && h->stats.nnz_idx16 == h->stats.nnz_padded && !h->pair_A,
+                               "the slot-pair study needs 16-bit codes on every slice and GLIMS_PAIR_A=0");
     read_tuning(h);
     const int d = h->dim;
     const bool blk_in = which == 3, blk_out = which == 3 || which == 4;

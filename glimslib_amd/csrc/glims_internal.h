@@ -114,6 +114,7 @@ struct DevPattern {
   dvec<int64_t> slice_ptr;
   dvec<int32_t> cols;
   dvec<uint16_t> cols16;
+  dvec<uint16_t> cols16p;                  // the same codes in the slot-pair layout (Newton Jacobian only)
   dvec<int32_t> win_base;
   dvec<uint8_t> win_ok;
   dvec<uint8_t> diag_k;
@@ -171,6 +172,7 @@ struct glims_ctx {
   //   GLIMS_SPMV_NT     0|1|2      non-temporal loads: none | values + columns | values only
   //   GLIMS_IDX16       0|1        columns as int32 | as 16-bit (window, offset) codes where a slice allows it
   //   GLIMS_RD_NT / GLIMS_RD_REMAP / GLIMS_RD_UNROLL (4|8|12|24)   the same for the assembly sweep
+  //   GLIMS_PAIR_A      0|1        Newton Jacobian + its column codes in the slot-pair layout (16-B value loads)
   //   GLIMS_FUSED_PACK  0|1        partitioned run: halo payload packed by the vector-update kernel (1) or by k_pack
   //   GLIMS_MECH_MIXED  0|1|2      elasticity: fp32 copy of K_el in the inner PCG under fp64 iterative refinement:
   //                                off | when K_el exceeds the Infinity Cache (default) | always
@@ -195,6 +197,8 @@ struct glims_ctx {
   dvec<uint16_t> study_pc16;
   dvec<float> vA32;                        // Newton Jacobian in single precision (GLIMS_FLAG_FP32_JACOBIAN only)
   bool jac32 = false;
+  bool pair_A = false;                     // vA / vA32 and cols16p use the slot-pair layout (GLIMS_PAIR_A, needs 16-bit codes everywhere)
+  int tune_pair_A = 1;
   dvec<float> vKel32;                      // single-precision copy of K_el (inner solves of the elasticity solver)
   // vectors (internal numbering; length n_nodes unless noted)
   dvec<double> c, c_old, b, load_rd, dinv;

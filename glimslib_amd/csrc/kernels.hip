@@ -178,6 +178,17 @@ __global__ __launch_bounds__(GL_WAVE) void k_assemble_static(
 //   s_T = sum of c over the cell's vertices, w_T = rho_T |T| d!/(d+3)!   [exact integral of rho c_h phi_i phi_j]
 //   -R = b - 1/2 (A + S) c,   b = M c_prev + load
 // ---------------------------------------------------------------------------------------------------
+template <class VT> struct Pair2;
+template <> struct Pair2<double> { using type = double2; };
+template <> struct Pair2<float> { using type = float2; };
+// Slot-pair layout of the Newton Jacobian A(c) and of its column codes: two consecutive slots of a row are adjacent in
+// memory, so that a lane reads 16 B of values (8 B in single precision) and 4 B of codes per load -- 1024-B / 256-B wave
+// loads, half the load instructions.  Element offset of slot k of lane l inside a slice with `len` slots (the odd last
+// slot stays a single element after the pairs):
+__device__ __forceinline__ int64_t pair_off(int k, int len, int lane) {
+  return ((len & 1) && k == len - 1) ? (int64_t)(len >> 1) * (2 * GL_WAVE) + lane
+                                     : ((int64_t)(k >> 1) * GL_WAVE + lane) * 2 + (k & 1);
+}
 // column of one entry from its 16-bit code: window base by cross-lane read (lane w of `wb` holds base w), + offset
 __device__ __forceinline__ int32_t decode_col(uint32_t code, int32_t wb) {
   return __builtin_amdgcn_ds_bpermute((int)((code >> GL_WIN_BITS) << 2), wb) + (int32_t)(code & ((1u << GL_WIN_BITS) - 1u));
@@ -198,7 +209,7 @@ __device__ __forceinline__ void corner_batch(const double* __restrict__ wp, cons
   for (int j = 0; j < B; ++j) corner(wb[j], sb[j]);
 }
 
-template <int NV, int NT, int CU, int CIDX, class AT = double>
+template <int NV, int NT, int CU, int CIDX, class AT = double, int PAIR = 0>
 __global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
     const int32_t* __restrict__ slice_list, int64_t n_own, const int64_t* __restrict__ slice_ptr,
     const int32_t* __restrict__ cols, const uint16_t* __restrict__ cols16, const int32_t* __restrict__ win_base,
@@ -302,13 +313,28 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
 #pragma unroll
         for (int j = 0; j < 8; ++j)
           S8[j] = NT ? __builtin_nontemporal_load(sv + (int64_t)(k + j) * GL_WAVE) : sv[(int64_t)(k + j) * GL_WAVE];
+        double A8[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const double Av = S8[j] + two_dt * acc[(k + j) * GL_WAVE + lane];
-          if (NT) __builtin_nontemporal_store((AT)Av, av + (int64_t)(k + j) * GL_WAVE);
-          else av[(int64_t)(k + j) * GL_WAVE] = (AT)Av;
+          A8[j] = Av;
+          if (!PAIR) {
+            if (NT) __builtin_nontemporal_store((AT)Av, av + (int64_t)(k + j) * GL_WAVE);
+            else av[(int64_t)(k + j) * GL_WAVE] = (AT)Av;
+          }
           r += 0.5 * (Av + S8[j]) * cn[(k + j) * GL_WAVE + lane];
           if (k + j == dk) d = Av;
+        }
+        if (PAIR) {   // k is a multiple of 8 and k + 8 <= len: these are four complete pairs -> one 16-B (8-B) store each
+          using A2 = typename Pair2<AT>::type;
+          A2* ap = reinterpret_cast<A2*>(vA + base) + lane;
+#pragma unroll
+          for (int j = 0; j < 8; j += 2) {
+            A2 t;
+            t.x = (AT)A8[j];
+            t.y = (AT)A8[j + 1];
+            ap[(int64_t)((k + j) >> 1) * GL_WAVE] = t;
+          }
         }
       }
       if (k < len) {   // ragged tail: one more batch, loads issued together
@@ -322,7 +348,8 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
         for (int j = 0; j < 8; ++j)
           if (k + j < len) {
             const double Av = S8[j] + two_dt * acc[(k + j) * GL_WAVE + lane];
-            if (NT) __builtin_nontemporal_store((AT)Av, av + (int64_t)(k + j) * GL_WAVE);
+            if (PAIR) vA[base + pair_off(k + j, len, lane)] = (AT)Av;
+            else if (NT) __builtin_nontemporal_store((AT)Av, av + (int64_t)(k + j) * GL_WAVE);
             else av[(int64_t)(k + j) * GL_WAVE] = (AT)Av;
             r += 0.5 * (Av + S8[j]) * cn[(k + j) * GL_WAVE + lane];
             if (k + j == dk) d = Av;
@@ -432,8 +459,60 @@ __device__ __forceinline__ double spmv_row(const int32_t* __restrict__ cc, const
   return acc;
 }
 
+
+// one lane's row through the pair layout (16-bit codes on every slice is a precondition of this layout)
+template <int WANT_DIAG, class VT>
+__device__ __forceinline__ double spmv_row_pair(const uint16_t* __restrict__ c16s, const VT* __restrict__ vs, int32_t wb,
+                                                 const double* __restrict__ x, int len, int lane, int dk,
+                                                 double& xdiag) {
+  using V2 = typename Pair2<VT>::type;
+  const V2* v2 = reinterpret_cast<const V2*>(vs) + lane;
+  const uint32_t* c2 = reinterpret_cast<const uint32_t*>(c16s) + lane;
+  const int np = len >> 1;
+  double acc = 0.0;
+  int q = 0;
+  for (; q + 2 <= np; q += 2) {   // two pairs = four entries in flight, like UNR = 4 of the slot-major kernel
+    uint32_t cc[2];
+    double va[4], xg[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) cc[j] = __builtin_nontemporal_load(c2 + (int64_t)(q + j) * GL_WAVE);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      va[2 * j] = (double)__builtin_nontemporal_load(&v2[(int64_t)(q + j) * GL_WAVE].x);
+      va[2 * j + 1] = (double)__builtin_nontemporal_load(&v2[(int64_t)(q + j) * GL_WAVE].y);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      xg[2 * j] = x[decode_col(cc[j] & 0xffffu, wb)];
+      xg[2 * j + 1] = x[decode_col(cc[j] >> 16, wb)];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc += va[j] * xg[j];
+    if (WANT_DIAG) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xdiag = (2 * q + j == dk) ? xg[j] : xdiag;
+    }
+  }
+  if (q < np) {                    // one more pair
+    const uint32_t c = __builtin_nontemporal_load(c2 + (int64_t)q * GL_WAVE);
+    const double a0 = (double)__builtin_nontemporal_load(&v2[(int64_t)q * GL_WAVE].x);
+    const double a1 = (double)__builtin_nontemporal_load(&v2[(int64_t)q * GL_WAVE].y);
+    const double x0 = x[decode_col(c & 0xffffu, wb)], x1 = x[decode_col(c >> 16, wb)];
+    acc += a0 * x0;   // same summation order as the slot-major kernel: the two layouts give the same bits
+    acc += a1 * x1;
+    if (WANT_DIAG) xdiag = (2 * q == dk) ? x0 : (2 * q + 1 == dk) ? x1 : xdiag;
+  }
+  if (len & 1) {                   // odd last slot
+    const int64_t t = (int64_t)np * (2 * GL_WAVE) + lane;
+    const double xl = x[decode_col(c16s[t], wb)];
+    acc += (double)vs[t] * xl;
+    if (WANT_DIAG) xdiag = (len - 1 == dk) ? xl : xdiag;
+  }
+  return acc;
+}
+
 // VT = double; float only for the optional single-precision copy of the Newton Jacobian (GLIMS_FLAG_FP32_JACOBIAN).
-template <int DOTS, int UNR, int NT, int CIDX, class VT = double>
+template <int DOTS, int UNR, int NT, int CIDX, class VT = double, int PAIR = 0>
 __global__ __launch_bounds__(256) void k_spmv(int n_launch, int chunk, const int32_t* __restrict__ slice_list,
                                                int64_t n_own, const int64_t* __restrict__ slice_ptr,
                                                const int32_t* __restrict__ cols, const uint16_t* __restrict__ cols16,
@@ -459,7 +538,10 @@ __global__ __launch_bounds__(256) void k_spmv(int n_launch, int chunk, const int
     const VT* v = vals + base + lane;
     double acc, xd = 0.0;
     const int dk = DOTS ? (int)diag_k[row] : -1;   // diag_k covers the padded rows of the last slice as well
-    if (CIDX && win_ok[s]) {   // wave-uniform
+    if constexpr (PAIR != 0) {   // vals / cols16 are the slot-pair copies
+      const int32_t wb = win_base[(int64_t)s * GL_N_WIN + (lane & (GL_N_WIN - 1))];
+      acc = spmv_row_pair<DOTS, VT>(cols16 + base, vals + base, wb, x, len, lane, dk, xd);
+    } else if (CIDX && win_ok[s]) {   // wave-uniform
       const int32_t wb = win_base[(int64_t)s * GL_N_WIN + (lane & (GL_N_WIN - 1))];
       acc = spmv_row<1, UNR, NT, DOTS, VT>(nullptr, cols16 + base + lane, wb, v, x, len, dk, xd);
     } else {
@@ -498,6 +580,16 @@ __global__ void k_to_pairs(int n_slices, const int64_t* __restrict__ slice_ptr, 
     pvals[d] = vals[src];
     pc16[d] = c16[src];
   }
+}
+
+// slot-major -> slot-pair copy of one per-entry array
+template <class TI, class TO>
+__global__ void k_plane_to_pairs(int n_slices, const int64_t* __restrict__ slice_ptr, const TI* __restrict__ in,
+                                 TO* __restrict__ out) {
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const int64_t base = slice_ptr[s];
+  const int len = (int)((slice_ptr[s + 1] - base) >> 6);
+  for (int k = 0; k < len; ++k) out[base + pair_off(k, len, lane)] = (TO)in[base + (int64_t)k * GL_WAVE + lane];
 }
 
 template <int DOTS>
@@ -756,13 +848,27 @@ static void assemble_static_t(glims_ctx* h, int with_mechanics) {
   h->vA.alloc(ne);
   assemble_plane<D>(h, MODE_M, 0, 0, h->vM.p, 1, 0);
   assemble_plane<D>(h, MODE_S, 0, 0, h->vS.p, 1, 0);
-  GL_HIP(hipMemcpyAsync(h->vA.p, h->vS.p, ne * sizeof(double), hipMemcpyDeviceToDevice, h->st));
+  if (h->pair_A)
+    hipLaunchKernelGGL((k_plane_to_pairs<double, double>), dim3(p.n_slices), dim3(GL_WAVE), 0, h->st, p.n_slices,
+                       p.slice_ptr.p, h->vS.p, h->vA.p);
+  else
+    GL_HIP(hipMemcpyAsync(h->vA.p, h->vS.p, ne * sizeof(double), hipMemcpyDeviceToDevice, h->st));
   if (h->jac32) {
     h->vA32.alloc(ne);
-    hipLaunchKernelGGL(k_to_float, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, h->st, (int64_t)ne, h->vS.p,
-                       h->vA32.p);
+    if (h->pair_A)
+      hipLaunchKernelGGL((k_plane_to_pairs<double, float>), dim3(p.n_slices), dim3(GL_WAVE), 0, h->st, p.n_slices,
+                         p.slice_ptr.p, h->vS.p, h->vA32.p);
+    else
+      hipLaunchKernelGGL(k_to_float, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, h->st, (int64_t)ne, h->vS.p,
+                         h->vA32.p);
     GL_HIP(hipGetLastError());
   }
+  if (h->pair_A && p.cols16p.n != (size_t)p.total_entries) {
+    p.cols16p.alloc((size_t)p.total_entries);
+    hipLaunchKernelGGL((k_plane_to_pairs<uint16_t, uint16_t>), dim3(p.n_slices), dim3(GL_WAVE), 0, h->st, p.n_slices,
+                       p.slice_ptr.p, p.cols16.p, p.cols16p.p);
+  }
+  GL_HIP(hipGetLastError());
   p.cw.alloc((size_t)p.total_corners);
   {
     const int bs = 256;
@@ -828,6 +934,24 @@ void gl_rd_assemble(glims_ctx* h, const double* c, const double* b, const double
                      : part == GL_PART_INTERIOR ? n_int : p.bucket_count[bk] - n_int;
     if (grid <= 0) continue;
     const int32_t* list = p.bucket_slices[bk]->p + (part == GL_PART_BOUNDARY ? n_int : 0);
+    if (h->pair_A) {   // Jacobian in the slot-pair layout (fp64 or, with the option, fp32): default configuration only
+      const size_t ldsp = (size_t)2 * cap * GL_WAVE * sizeof(double);
+#define GL_RDP(NV, AT, APTR)                                                                                        \
+  do {                                                                                                             \
+    set_lds(k_rd_assemble<NV, 0, 24, 1, AT, 1>, ldsp);                                                             \
+    hipLaunchKernelGGL((k_rd_assemble<NV, 0, 24, 1, AT, 1>), dim3(grid), dim3(GL_WAVE), ldsp, h->st, list,          \
+                       h->n_own, p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, p.win_ok.p, p.cslice_ptr.p,     \
+                       p.cslots.p, p.cw.p, p.diag_k.p, h->vS.p, APTR, c, b, b2, r_out, r2_out, h->dinv.p, fx,        \
+                       2.0 * h->opt.dt, partials, cap, h->tune_rd_remap);                                          \
+  } while (0)
+      if (h->jac32) {
+        if (h->nv == 3) GL_RDP(3, float, h->vA32.p); else GL_RDP(4, float, h->vA32.p);
+      } else {
+        if (h->nv == 3) GL_RDP(3, double, h->vA.p); else GL_RDP(4, double, h->vA.p);
+      }
+#undef GL_RDP
+      continue;
+    }
     if (h->jac32) {   // Jacobian stored in single precision (option): default kernel configuration only
       const size_t lds32 = (size_t)2 * cap * GL_WAVE * sizeof(double);
 #define GL_RD32(NV)                                                                                                 \
@@ -870,6 +994,21 @@ void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* s
   const int grid = gl_spmv_grid(n_launch);
   const int chunk = (n_launch + grid - 1) / grid;
   const int remap = slice_list ? 0 : h->tune_xcd_remap;   // 0 plain, 1 contiguous eighths, G > 1 chunks of G blocks
+  if (h->pair_A && (vals == h->vA.p || (vals32 && vals32 == h->vA32.p))) {
+    // Newton Jacobian in the slot-pair layout (default kernel configuration only; tuning knobs do not apply)
+#define GL_SPMV_PAIR(DOTS, VT, VPTR)                                                                                  \
+  hipLaunchKernelGGL((k_spmv<DOTS, 4, 1, 1, VT, 1>), dim3(grid), dim3(256), 0, st, n_launch, chunk, slice_list,        \
+                     h->n_own, p.slice_ptr.p, p.cols.p, p.cols16p.p, p.win_base.p, p.win_ok.p, p.diag_k.p, VPTR, x, y, \
+                     fixed, addv, r, partials, partial_off, done, remap)
+    if (vals32) {
+      if (r) GL_SPMV_PAIR(1, float, vals32); else GL_SPMV_PAIR(0, float, vals32);
+    } else {
+      if (r) GL_SPMV_PAIR(1, double, vals); else GL_SPMV_PAIR(0, double, vals);
+    }
+#undef GL_SPMV_PAIR
+    GL_HIP(hipGetLastError());
+    return;
+  }
   if (vals32) {   // single-precision operator copy: only the default kernel configuration is built for it
     if (r)
       hipLaunchKernelGGL((k_spmv<1, 4, 1, 1, float>), dim3(grid), dim3(256), 0, st, n_launch, chunk, slice_list,
