@@ -245,3 +245,45 @@ def test_partition_plans_are_mutually_consistent():
         assert off == p.n_local
         # every cell touching an owned node is local, with consistent local numbering
         np.testing.assert_array_equal(p.global_ids[p.cells], mesh.cells[p.cell_ids])
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_partition_plans_on_random_meshes_and_world_sizes(seed):
+    """The halo plans of partition_mesh for random box / rectangle / jittered meshes and 2-9 ranks: every node owned
+    exactly once, ghost k of a rank is the k-th value its owner sends, cells complete and consistently numbered,
+    peers symmetric, and a halo exchange emulated on the host turns owned values into the right ghost values."""
+    from glimslib_amd.mesh import Mesh
+    from glimslib_amd.partition import partition_mesh
+    rng = np.random.default_rng(300 + seed)
+    if seed % 2:
+        n = rng.integers(2, 9, size=3)
+        mesh = fenics.BoxMesh((0, 0, 0), tuple(float(v) for v in n * rng.uniform(0.5, 2, size=3)), *[int(v) for v in n])
+    else:
+        n = rng.integers(3, 30, size=2)
+        mesh = fenics.RectangleMesh((0, 0), tuple(float(v) for v in n * rng.uniform(0.5, 2, size=2)), *[int(v) for v in n])
+    if seed >= 4:
+        mesh = Mesh(mesh.points + 0.1 * rng.standard_normal(mesh.points.shape) * (np.ptp(mesh.points, axis=0) / n),
+                    mesh.cells)
+    world = int(rng.integers(2, 10))
+    parts = partition_mesh(mesh.points, mesh.cells, world)
+    assert sorted(np.concatenate([p.owned_global for p in parts])) == list(range(mesh.num_vertices()))
+    field = rng.standard_normal(mesh.num_vertices())
+    for p in parts:
+        assert p.n_own > 0
+        local = np.full(p.n_local, np.nan)
+        local[:p.n_own] = field[p.global_ids[:p.n_own]]
+        off = p.n_own
+        for q, cnt in zip(p.peer_rank, p.recv_count):
+            other = parts[q]
+            assert p.rank in list(other.peer_rank)                                  # symmetric peer relation
+            j = list(other.peer_rank).index(p.rank)
+            send_nodes = other.send_idx[other.send_ptr[j]:other.send_ptr[j + 1]]
+            assert (send_nodes < other.n_own).all()                                 # only owned values are sent
+            np.testing.assert_array_equal(other.global_ids[send_nodes], p.global_ids[off:off + cnt])
+            local[off:off + cnt] = field[other.global_ids[send_nodes]]              # what the exchange delivers
+            off += cnt
+        assert off == p.n_local
+        np.testing.assert_array_equal(local, field[p.global_ids])                   # ghosts end up with the owners' values
+        np.testing.assert_array_equal(p.global_ids[p.cells], mesh.cells[p.cell_ids])
+        touching = np.isin(mesh.cells, p.global_ids[:p.n_own]).any(axis=1)
+        np.testing.assert_array_equal(np.sort(p.cell_ids), np.flatnonzero(touching))   # exactly the cells touching owned nodes
