@@ -20,6 +20,8 @@ GLIMS_UNIQUE_ID_BYTES = 256
 FLAG_EXTRAPOLATE_GUESS = 1
 FLAG_WARM_START = 2
 FLAG_FP32_JACOBIAN = 4
+PRECOND_BLOCK_JACOBI, PRECOND_MULTIGRID = 0, 1
+ABI_VERSION = 2
 
 
 class BackendError(RuntimeError):
@@ -32,7 +34,9 @@ class Options(C.Structure):
     _fields_ = [("dt", C.c_double), ("newton_rtol", C.c_double), ("newton_atol", C.c_double),
                 ("newton_maxit", C.c_int), ("cg_rtol", C.c_double), ("cg_atol", C.c_double),
                 ("cg_maxit", C.c_int), ("mech_rtol", C.c_double), ("mech_atol", C.c_double),
-                ("mech_maxit", C.c_int), ("check_every", C.c_int), ("flags", C.c_int)]
+                ("mech_maxit", C.c_int), ("check_every", C.c_int), ("flags", C.c_int),
+                ("mech_precond", C.c_int), ("mech_mixed", C.c_int), ("mech_history", C.c_int),
+                ("mg_smooth", C.c_int), ("mg_coarse_nodes", C.c_int), ("mg_h_factor", C.c_double)]
 
 
 class Stats(C.Structure):
@@ -41,7 +45,9 @@ class Stats(C.Structure):
                 ("last_newton_res", C.c_double), ("last_cg_res", C.c_double), ("last_mech_res", C.c_double),
                 ("ms_steps", C.c_double), ("ms_spmv", C.c_double), ("n_rows", C.c_int64), ("nnz", C.c_int64),
                 ("nnz_padded", C.c_int64), ("n_corners", C.c_int64), ("nnz_idx16", C.c_int64),
-                ("ms_spmv_steps", C.c_double), ("n_spmv_steps", C.c_int64)]
+                ("ms_spmv_steps", C.c_double), ("n_spmv_steps", C.c_int64),
+                ("failed_steps", C.c_int64), ("mg_levels", C.c_int64), ("mg_cycles", C.c_int64),
+                ("mg_complexity", C.c_double), ("ms_mg_setup", C.c_double), ("ms_mech", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -104,6 +110,10 @@ def load_library():
             "glimslib_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C glimslib_amd/csrc`. There is no CPU fallback." % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
+    lib.glims_abi_version.restype = C.c_int
+    if lib.glims_abi_version() != ABI_VERSION:
+        raise ImportError("glimslib_amd: %s has ABI version %d, this binding needs %d -- rebuild it (make -C glimslib_amd/csrc)"
+                          % (LIB_PATH, lib.glims_abi_version(), ABI_VERSION))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError if the .so does not export a declared symbol
         fn.restype = res

@@ -32,8 +32,6 @@ void read_tuning(glims_ctx* h) {
   if (const char* e = getenv("GLIMS_TIME_SPMV")) h->time_spmv = atoi(e) != 0;
   if (const char* e = getenv("GLIMS_PAIR_A")) h->tune_pair_A = atoi(e);
   if (const char* e = getenv("GLIMS_FUSED_PACK")) h->tune_fused_pack = atoi(e);
-  if (const char* e = getenv("GLIMS_MECH_MIXED")) h->mech_mixed = atoi(e);
-  if (const char* e = getenv("GLIMS_MHIST")) h->mh_depth = std::max(0, std::min((int)glims_ctx::MHIST, atoi(e)));
   if (const char* e = getenv("GLIMS_UPD_NT")) h->tune_upd_nt = atoi(e);
   if (const char* e = getenv("GLIMS_BLK_VARIANT")) h->tune_blk_variant = atoi(e);
   if (const char* e = getenv("GLIMS_LIN_MARGIN")) h->tune_lin_margin = atof(e);
@@ -117,6 +115,12 @@ int glims_options_default(glims_options* o) {
   o->mech_maxit = 200000;
   o->check_every = 8;
   o->flags = GLIMS_FLAG_WARM_START;
+  o->mech_precond = GLIMS_PRECOND_MULTIGRID;
+  o->mech_mixed = 1;
+  o->mech_history = 6;
+  o->mg_smooth = 2;
+  o->mg_coarse_nodes = 216;
+  o->mg_h_factor = 2.0;
   return GLIMS_OK;
 }
 
@@ -175,6 +179,8 @@ int glims_create(glims_ctx** out, int dim, int64_t n_nodes, int64_t n_own, int64
     HostPattern hp;
     build_host_pattern(hp, dim, n_nodes, n_own, n_cells, xyz, cells);
     lap("host pattern (total)");
+    gl_mesh_metrics(h, hp, xyz);
+    lap("mesh metrics (lattice test, edge lengths)");
     h->old2new = hp.old2new;
     h->new2old = hp.new2old;
     h->nnz = hp.nnz;
@@ -303,6 +309,7 @@ int glims_set_materials(glims_ctx* h, int n_labels, const double* D, const doubl
                         const double* E, const double* nu) {
   return guarded(h, [&]() {
     h->mh_count = h->mh_next = 0;   // the elasticity solve history belongs to one operator
+    h->mg.ready = false;
     GL_REQUIRE(n_labels > 0 && n_labels <= GL_MAX_LABELS, "n_labels out of range");
     GL_REQUIRE(D && rho && gamma && E && nu, "null material table");
     std::vector<double> m(5 * GL_MAX_LABELS, 0.0);
@@ -334,6 +341,14 @@ int glims_set_options(glims_ctx* h, const glims_options* opt) {
     GL_REQUIRE(opt, "null options");
     GL_REQUIRE(opt->dt > 0.0 && std::isfinite(opt->dt), "dt must be positive");
     GL_REQUIRE(opt->newton_maxit >= 0 && opt->cg_maxit > 0 && opt->mech_maxit > 0, "bad iteration caps");
+    GL_REQUIRE(opt->mech_precond == GLIMS_PRECOND_BLOCK_JACOBI || opt->mech_precond == GLIMS_PRECOND_MULTIGRID,
+               "unknown mech_precond");
+    GL_REQUIRE(opt->mech_mixed >= 0 && opt->mech_mixed <= 2 && opt->mech_history >= 0 && opt->mg_smooth >= 1 &&
+                   opt->mg_coarse_nodes >= 1 && opt->mg_h_factor > 0.0,
+               "bad elasticity solver options");
+    if (opt->mg_smooth != h->opt.mg_smooth || opt->mg_coarse_nodes != h->opt.mg_coarse_nodes ||
+        opt->mg_h_factor != h->opt.mg_h_factor)
+      h->mg.ready = false;
     if (opt->dt != h->opt.dt) h->is_setup = false;
     if ((opt->flags ^ h->opt.flags) & GLIMS_FLAG_FP32_JACOBIAN) h->is_setup = false;
     h->opt = *opt;
@@ -350,16 +365,19 @@ int glims_set_dirichlet_c(glims_ctx* h, int64_t n, const int64_t* node_ids, cons
       return GLIMS_OK;
     }
     GL_REQUIRE(node_ids && values, "null Dirichlet arrays");
-    // the values themselves enter through glims_set_state (the caller writes them into c); here only the row mask
-    (void)values;
     std::vector<uint8_t> fx(h->n_nodes, 0);
+    std::vector<double> val(h->n_nodes, 0.0);
     for (int64_t k = 0; k < n; ++k) {
       GL_REQUIRE(node_ids[k] >= 0 && node_ids[k] < h->n_nodes, "Dirichlet node out of range");
+      GL_REQUIRE(std::isfinite(values[k]), "non-finite Dirichlet value");
       fx[h->old2new[node_ids[k]]] = 1;
+      val[h->old2new[node_ids[k]]] = values[k];
     }
     h->fixed_c.upload(fx, h->st);
-    GL_HIP(hipStreamSynchronize(h->st));
+    h->fixed_c_val.upload(val, h->st);
     h->have_fixed_c = true;
+    gl_apply_dirichlet_c(h);   // a state is present: time-dependent data take effect with the next step
+    GL_HIP(hipStreamSynchronize(h->st));
     return GLIMS_OK;
   });
 }
@@ -367,6 +385,7 @@ int glims_set_dirichlet_c(glims_ctx* h, int64_t n, const int64_t* node_ids, cons
 int glims_set_dirichlet_u(glims_ctx* h, int64_t n, const int64_t* dof_ids, const double* values) {
   return guarded(h, [&]() {
     h->mh_count = h->mh_next = 0;   // the elasticity solve history belongs to one operator
+    h->mg.ready = false;            // ... and so does the multigrid hierarchy (constrained dofs are eliminated in it)
     if (n <= 0) {
       h->have_fixed_u = false;
       return GLIMS_OK;
@@ -421,6 +440,7 @@ int glims_set_mech_load(glims_ctx* h, const double* f) {
 int glims_setup(glims_ctx* h, int with_mechanics) {
   return guarded(h, [&]() {
     h->mh_count = h->mh_next = 0;   // the elasticity solve history belongs to one operator
+    h->mg.ready = false;
     GL_REQUIRE(h->have_materials, "glims_setup before glims_set_materials");
     if (with_mechanics) {
       const size_t nd = (size_t)h->n_nodes * h->dim;
@@ -453,6 +473,8 @@ int glims_set_state(glims_ctx* h, const double* c, const double* u) {
     h->pending = false;
     h->have_c_old = false;
     to_device_perm(h, c, h->c.p, 1);
+    h->have_state = true;
+    gl_apply_dirichlet_c(h);
     if (h->U.p) {
       if (u)
         to_device_perm(h, u, h->U.p, h->dim);
@@ -501,6 +523,9 @@ int glims_reset_stats(glims_ctx* h) {
   h->stats.nnz_padded = keep.nnz_padded;
   h->stats.n_corners = keep.n_corners;
   h->stats.nnz_idx16 = keep.nnz_idx16;
+  h->stats.mg_levels = keep.mg_levels;
+  h->stats.mg_complexity = keep.mg_complexity;
+  h->stats.ms_mg_setup = keep.ms_mg_setup;
   h->tev_used = 0;
   h->stats.steps = keep.steps;   // step counter drives the extrapolated guess; keep it
   return GLIMS_OK;

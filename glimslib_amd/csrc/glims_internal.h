@@ -144,6 +144,51 @@ struct NodeMail {
   long long timeout_ticks = 60ll * 100000000ll;   // wall_clock64 runs at 100 MHz
 };
 
+// ---- elasticity multigrid (mg.hip) --------------------------------------------------------------------------
+// Auxiliary-grid geometric multigrid for K_el: level 0 is the mesh itself (SELL-64 blocks, single-precision copy),
+// level 1 a Cartesian grid of width H ~ 2h laid over the mesh (d-linear interpolation onto the mesh nodes), levels
+// 2.. its 2:1 coarsenings.  Coarse operators are Galerkin products stored as dense stencils: no column indices on
+// any coarse level, every stream unit-stride over the grid nodes.
+struct MgGrid {
+  int n[3] = {1, 1, 1};                    // nodes per axis (n[2] = 1 in 2-D)
+  int64_t nn = 1;
+};
+struct MgLevel {                           // one Cartesian level
+  MgGrid g;
+  int f[3] = {1, 1, 1};                    // coarsening factor per axis towards the next level (1 | 2)
+  dvec<float> A;                           // [S][bs*bs][nn] stencil-major planes
+  dvec<double> dinv;                       // [bs*bs][nn] inverse diagonal blocks
+  dvec<double> x, x2, r, d, res;           // [bs][nn] (component-major)
+  double lam = 1.0;                        // estimate of lambda_max(Dinv A)
+};
+struct MgHierarchy {
+  bool ready = false;
+  int R = 1, S = 27;                       // stencil radius / entries of the Cartesian levels
+  double lo[3] = {0, 0, 0}, H[3] = {1, 1, 1};
+  dvec<int32_t> cell0;                     // [n_own] lower-corner grid node of the level-1 cell that holds a mesh node
+  dvec<double> wgt;                        // [n_own][dim] interpolation weight towards the upper node, per axis
+  dvec<int32_t> cell_ptr, cell_nodes;      // mesh nodes sorted by level-1 cell (children lists of the grid nodes)
+  dvec<double> x, x2, d, res;              // level-0 work vectors [n_nodes*bs] (ghost slots stay zero)
+  double lam0 = 1.0;
+  std::vector<MgLevel*> lv;                // owned
+  dvec<double> coarse_inv;                 // dense inverse of the coarsest operator [nc][nc], nc = lv.back()->g.nn * bs
+  int64_t entries = 0;                     // stored operator entries of the coarse levels (scalars)
+  void clear() {
+    for (auto* l : lv) delete l;
+    lv.clear();
+    ready = false;
+  }
+  ~MgHierarchy() { clear(); }
+};
+// what glims_create keeps of the mesh geometry for the multigrid set-up
+struct MeshMetrics {
+  double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  double h_lattice[3] = {0, 0, 0};         // lattice constant per axis if the nodes form a lattice
+  bool lattice = false;
+  double mean_edge = 0.0;
+  std::vector<double> xyz;                 // owned nodes, internal numbering [n_own][dim]
+};
+
 // scalar slots of the Krylov recurrence (device array `scal`)
 enum { SC_ALPHA = 0, SC_BETA, SC_GAMMA, SC_IT, SC_COUNT = 8 };
 
@@ -209,14 +254,16 @@ struct glims_ctx {
   // independent, so the least-squares fit of a new right-hand side by the stored ones gives the initial guess
   static constexpr int MHIST = 8;   // GLIMS_MHIST <= 8 limits the depth actually used
   dvec<double> mh_rhs[MHIST], mh_x[MHIST];
-  int mh_count = 0, mh_next = 0, mh_depth = 6;
-  int mech_mixed = 1;                      // GLIMS_MECH_MIXED: fp32 K_el in the inner PCG under an fp64 refinement loop
+  int mh_count = 0, mh_next = 0;           // depth: glims_options.mech_history
   bool have_c_old = false;                                    // c_old holds the state at the start of the previous step
   bool pending = false;                                      // cg_r / b / vA already hold the first assembly of the next step
   double pending_r0 = 0.0;
   dvec<double> U, mload, m_rhs, m_p, m_s, m_u, m_w, m_r, m_dinv, m_uD;   // mechanics, [n_nodes*dim]
   dvec<uint8_t> fixed_c, fixed_u;
   bool have_fixed_c = false, have_fixed_u = false, have_load_rd = false, have_mload = false;
+  MgHierarchy mg;
+  MeshMetrics mm;
+  dvec<double> fixed_c_val;                 // Dirichlet values of the concentration [n_nodes] (internal numbering)
   std::vector<dvec<double>*> snapshots;     // device-resident recorded concentrations (owned)
   dvec<double> stage;                      // staging for host<->device permuted transfers [n_nodes*dim]
 
@@ -276,3 +323,14 @@ void gl_comm_destroy(glims_ctx* h);
 int gl_comm_selftest(glims_ctx* h);
 int gl_mailbox_selftest(glims_ctx* h);
 int gl_project(glims_ctx* h, double* rhs_dev /*[n_nodes], overwritten*/, double* x_dev /*[n_nodes]*/, double rtol);
+double gl_dot(glims_ctx* h, const double* a, const double* b, int64_t n, bool global = true);   // deterministic; host value
+void gl_apply_dirichlet_c(glims_ctx* h);                                     // c[fixed] = stored values (+ halo)
+void gl_block_dinv(glims_ctx* h);                                            // m_dinv of the constrained K_el
+
+// mg.hip --------------------------------------------------------------------------------------------
+void gl_mesh_metrics(glims_ctx* h, const HostPattern& hp, const double* xyz_old);
+void gl_mg_setup(glims_ctx* h);
+void gl_mg_apply(glims_ctx* h, const double* r, double* u, const int* done = nullptr);   // u = V-cycle(r); r zero on constrained dofs
+// level-0 operator pass of the multigrid (kernels.hip): mode 0 out = r - A x, 1 Chebyshev step, 2 out = Dinv A x
+void gl_launch_mg_fine(glims_ctx* h, int mode, const double* xin, const double* r, double* d, double* xout, double c1,
+                       double c2, const int* done = nullptr);

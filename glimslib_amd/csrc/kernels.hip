@@ -765,6 +765,84 @@ __global__ __launch_bounds__(256) void k_spmv_block2(int n_launch, int chunk, co
   }
 }
 
+// Level-0 pass of the elasticity multigrid (mg.hip): one sweep over the single-precision copy of K_el with the
+// smoother's vector work in the epilogue -- the row owner has (A x)_row in registers, so the residual, the Chebyshev
+// direction and the new iterate cost no extra pass over the vectors.  Constrained dofs: rows masked here, columns see
+// x = 0 there (the iterates are zero on constrained dofs by construction).  xout must not alias xin.
+//   MODE 0: xout = r - A xin          MODE 1: d = c1 d + c2 Dinv (r - A xin), xout = xin + d          MODE 2: xout = Dinv A xin
+template <int BS, int MODE, int KB>
+__global__ __launch_bounds__(256) void k_mg_fine(int n_launch, int chunk, int64_t n_own,
+                                                  const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ cols,
+                                                  const float* __restrict__ vals, const double* __restrict__ dinv,
+                                                  const uint8_t* __restrict__ fixed, const double* __restrict__ xin,
+                                                  const double* __restrict__ r, double* __restrict__ d,
+                                                  double* __restrict__ xout, double c1, double c2, int remap,
+                                                  const int* __restrict__ done) {
+  constexpr int B2 = BS * BS;
+  if (done && *done) return;   // enqueued past the Krylov solver's convergence: nobody reads the result
+  const int b = remap > 1 ? xcd_chunk_remap(blockIdx.x, gridDim.x, remap) : blockIdx.x;
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int s_end = min(n_launch, (b + 1) * chunk);
+  for (int s = b * chunk + wid; s < s_end; s += 4) {
+    const int64_t row = (int64_t)s * GL_WAVE + lane;
+    const int64_t base = slice_ptr[s];
+    const int len = (int)((slice_ptr[s + 1] - base) >> 6);
+    const int32_t* cc = cols + base + lane;
+    const float* vb = vals + base * B2 + lane;
+    double acc[BS];
+#pragma unroll
+    for (int a = 0; a < BS; ++a) acc[a] = 0.0;
+    for (int k = 0; k < len; k += KB) {
+      int32_t cj[KB];
+      double v[KB][B2], xj[KB][BS];
+#pragma unroll
+      for (int j = 0; j < KB; ++j) cj[j] = __builtin_nontemporal_load(cc + (int64_t)min(k + j, len - 1) * GL_WAVE);
+#pragma unroll
+      for (int j = 0; j < KB; ++j) {
+        const float* vk = vb + (int64_t)min(k + j, len - 1) * (GL_WAVE * B2);
+#pragma unroll
+        for (int e = 0; e < B2; ++e) v[j][e] = (double)__builtin_nontemporal_load(vk + e * GL_WAVE);
+      }
+#pragma unroll
+      for (int j = 0; j < KB; ++j)
+#pragma unroll
+        for (int bb = 0; bb < BS; ++bb) xj[j][bb] = (k + j < len) ? xin[(int64_t)cj[j] * BS + bb] : 0.0;
+#pragma unroll
+      for (int j = 0; j < KB; ++j)
+#pragma unroll
+        for (int a = 0; a < BS; ++a)
+#pragma unroll
+          for (int bb = 0; bb < BS; ++bb) acc[a] += v[j][a * BS + bb] * xj[j][bb];
+    }
+    if (row >= n_own) continue;
+    double t[BS];
+#pragma unroll
+    for (int a = 0; a < BS; ++a) {
+      const bool fx = fixed && fixed[row * BS + a];
+      if (MODE == 2) t[a] = fx ? 0.0 : acc[a];
+      else t[a] = fx ? 0.0 : r[row * BS + a] - acc[a];
+    }
+    if (MODE == 0) {
+#pragma unroll
+      for (int a = 0; a < BS; ++a) xout[row * BS + a] = t[a];
+    } else {
+#pragma unroll
+      for (int a = 0; a < BS; ++a) {
+        double z = 0.0;
+#pragma unroll
+        for (int bb = 0; bb < BS; ++bb) z += dinv[row * B2 + a * BS + bb] * t[bb];
+        if (MODE == 2) {
+          xout[row * BS + a] = z;
+        } else {
+          const double dn = (c1 != 0.0 ? c1 * d[row * BS + a] : 0.0) + c2 * z;
+          d[row * BS + a] = dn;
+          xout[row * BS + a] = xin[row * BS + a] + dn;
+        }
+      }
+    }
+  }
+}
+
 // y[(row,a)] = sum_k G[(row,a),col_k] c[col_k]
 template <int BS>
 __global__ __launch_bounds__(256) void k_apply_G(int n_slices, int64_t n_own, const int64_t* __restrict__ slice_ptr,
@@ -1127,5 +1205,23 @@ void gl_apply_G(glims_ctx* h, const double* c, double* y) {
   else
     hipLaunchKernelGGL(k_apply_G<3>, dim3(grid), dim3(256), 0, h->st, p.n_slices, h->n_own, p.slice_ptr.p, p.cols.p,
                        h->vG.p, c, addv, y);
+  GL_HIP(hipGetLastError());
+}
+
+void gl_launch_mg_fine(glims_ctx* h, int mode, const double* xin, const double* r, double* d, double* xout, double c1,
+                       double c2, const int* done) {
+  const DevPattern& p = h->pat;
+  const int grid = gl_spmv_grid(p.n_slices);
+  const int chunk = (p.n_slices + grid - 1) / grid;
+  const uint8_t* fx = h->have_fixed_u ? h->fixed_u.p : nullptr;
+#define GL_MGF(BS, MODE)                                                                                             \
+  hipLaunchKernelGGL((k_mg_fine<BS, MODE, 2>), dim3(grid), dim3(256), 0, h->st, p.n_slices, chunk, h->n_own,          \
+                     p.slice_ptr.p, p.cols.p, h->vKel32.p, h->m_dinv.p, fx, xin, r, d, xout, c1, c2, h->tune_xcd_remap, done)
+  if (h->dim == 2) {
+    if (mode == 0) GL_MGF(2, 0); else if (mode == 1) GL_MGF(2, 1); else GL_MGF(2, 2);
+  } else {
+    if (mode == 0) GL_MGF(3, 0); else if (mode == 1) GL_MGF(3, 1); else GL_MGF(3, 2);
+  }
+#undef GL_MGF
   GL_HIP(hipGetLastError());
 }

@@ -1,0 +1,1061 @@
+// Multigrid preconditioner for the elasticity block K_el u = G c + f  (the F_m block, simulation_tumor_growth.py:110-113).
+//
+// What it stands in for: the reference solves the monolithic system with a sparse LU (simulation_tumor_growth.py:126-130,
+// DOLFIN default) and names 'amg' as the alternative where LU no longer fits (simulation_tumor_growth_brain_quad.py:116-119).
+// Block-Jacobi PCG needs O(1/h) iterations (800 at 1 M nodes, 1 650 at 10 M); one V-cycle of this hierarchy per PCG
+// iteration makes the count independent of the mesh width (tools/proto_gmg.py: 47 / 51 / 53 at n = 16 / 24 / 32).
+//
+// Design (MI355X first): *geometric multigrid on auxiliary Cartesian grids*.
+//   level 0   the mesh (any P1 simplex mesh): block SELL-64 operator, single-precision copy, smoother fused into the SpMV
+//   level 1   a Cartesian grid of width H ~ 2h laid over the mesh; prolongation = d-linear interpolation from the
+//             grid nodes onto the mesh nodes (8 parents per node, weights from coordinates alone -- no graph
+//             algorithms, no aggregates, no QR)
+//   level 2.. 2:1 coarsenings with d-linear interpolation
+//   coarse operators = Galerkin products P^T A P, stored as *dense stencils* [(2R+1)^d][d*d][nodes] in single
+//   precision: no column indices, every load unit-stride over the grid nodes, the neighbour gather of x contiguous.
+//   R = 1 (27-point) when the mesh nodes sit on a lattice that the grid can align with (the BASELINE box meshes),
+//   R = 2 (125-point) for general meshes.  Rigid-body modes are d-linear, i.e. reproduced exactly on every level, which
+//   is what smoothed aggregation buys with its near-nullspace vectors.
+//   All set-up products are *gathers by the output entry* (one thread per (grid node, stencil offset)): no atomics,
+//   bitwise reproducible hierarchies.
+//   Smoother: Chebyshev of degree k (k = 1: damped block-Jacobi) on Dinv A, lambda_max by power iteration at set-up.
+//   Coarsest grid (<= mg_coarse_nodes nodes): dense inverse computed once on the host, applied as one GEMV.
+//   Partitioned runs: the hierarchy covers the rank's owned rows (ghost couplings dropped inside the preconditioner =
+//   non-overlapping additive Schwarz with one V-cycle per subdomain); the Krylov operator itself stays exact.
+#include "glims_internal.h"
+
+#include <omp.h>
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+struct GridDev {
+  int n0, n1, n2;
+  long long nn;
+};
+inline GridDev gdev(const MgGrid& g) { return GridDev{g.n[0], g.n[1], g.n[2], (long long)g.nn}; }
+
+__device__ __forceinline__ void lin2v(long long I, const GridDev& g, int* v) {
+  v[0] = (int)(I % g.n0);
+  const long long t = I / g.n0;
+  v[1] = (int)(t % g.n1);
+  v[2] = (int)(t / g.n1);
+}
+__device__ __forceinline__ long long v2lin(const int* v, const GridDev& g) {
+  return ((long long)v[2] * g.n1 + v[1]) * g.n0 + v[0];
+}
+__device__ __forceinline__ int gn(const GridDev& g, int a) { return a == 0 ? g.n0 : a == 1 ? g.n1 : g.n2; }
+
+template <int D>
+__device__ __forceinline__ void off2v(int off, int R, int* o) {
+  const int W = 2 * R + 1;
+  o[0] = off % W - R;
+  o[1] = (off / W) % W - R;
+  o[2] = D == 3 ? off / (W * W) - R : 0;
+}
+template <int D>
+__device__ __forceinline__ int v2off(const int* o, int R) {
+  const int W = 2 * R + 1;
+  return (D == 3 ? (o[2] + R) * W * W : 0) + (o[1] + R) * W + (o[0] + R);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// set-up kernels
+// ---------------------------------------------------------------------------------------------------
+// how far the Galerkin product mesh -> grid reaches: max over mesh edges (i, j) of the index distance between a parent
+// of i and a parent of j (parents with non-zero weight only)
+template <int D>
+__global__ void k_mg_reach(int64_t n_own, GridDev g1, const int64_t* __restrict__ slice_ptr,
+                           const int32_t* __restrict__ cols, const int32_t* __restrict__ cell0,
+                           const double* __restrict__ wgt, int* __restrict__ reach) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_own) return;
+  const int64_t base = slice_ptr[i >> 6];
+  const int len = (int)((slice_ptr[(i >> 6) + 1] - base) >> 6);
+  int ci[3], m = 0;
+  lin2v(cell0[i], g1, ci);
+  for (int k = 0; k < len; ++k) {
+    const int64_t j = cols[base + (int64_t)k * GL_WAVE + (i & 63)];
+    if (j >= n_own) continue;
+    int cj[3];
+    lin2v(cell0[j], g1, cj);
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      const double wi = wgt[i * D + a], wj = wgt[j * D + a];
+      const int lo_i = ci[a] + (wi == 1.0 ? 1 : 0), hi_i = ci[a] + (wi == 0.0 ? 0 : 1);
+      const int lo_j = cj[a] + (wj == 1.0 ? 1 : 0), hi_j = cj[a] + (wj == 0.0 ? 0 : 1);
+      m = max(m, max(hi_j - lo_i, hi_i - lo_j));
+    }
+  }
+  if (m > 0) atomicMax(reach, m);
+}
+
+// A1[I, off] = sum_{i child of I} sum_{j in row i, I + off parent of j} w_iI w_j(I+off) F_i K_ij F_j
+// one thread per (grid node, stencil offset): a gather in a fixed order
+template <int D>
+__global__ void k_mg_rap0(GridDev g1, int R, int S, int64_t n_own, const int32_t* __restrict__ cell_ptr,
+                          const int32_t* __restrict__ cell_nodes, const int32_t* __restrict__ cell0,
+                          const double* __restrict__ wgt, const int64_t* __restrict__ slice_ptr,
+                          const int32_t* __restrict__ cols, const double* __restrict__ vK,
+                          const uint8_t* __restrict__ fixed, float* __restrict__ A1) {
+  constexpr int BS = D, B2 = D * D;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= g1.nn * S) return;
+  const long long I = t / S;
+  const int off = (int)(t - I * S);
+  int Iv[3], o[3], Jv[3] = {0, 0, 0};
+  lin2v(I, g1, Iv);
+  off2v<D>(off, R, o);
+  bool inside = true;
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    Jv[a] = Iv[a] + o[a];
+    inside = inside && Jv[a] >= 0 && Jv[a] < gn(g1, a);
+  }
+  double acc[B2];
+#pragma unroll
+  for (int e = 0; e < B2; ++e) acc[e] = 0.0;
+  if (inside) {
+    for (int corner = 0; corner < (1 << D); ++corner) {
+      int cv[3] = {0, 0, 0};
+      bool ok = true;
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        cv[a] = Iv[a] - ((corner >> a) & 1);
+        ok = ok && cv[a] >= 0 && cv[a] <= gn(g1, a) - 2;
+      }
+      if (!ok) continue;
+      const long long c = v2lin(cv, g1);
+      for (int32_t q = cell_ptr[c]; q < cell_ptr[c + 1]; ++q) {
+        const int64_t i = cell_nodes[q];
+        double wi = 1.0;
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+          const double w = wgt[i * D + a];
+          wi *= ((corner >> a) & 1) ? w : 1.0 - w;
+        }
+        if (wi == 0.0) continue;
+        const int lane = (int)(i & 63);
+        const int64_t base = slice_ptr[i >> 6];
+        const int len = (int)((slice_ptr[(i >> 6) + 1] - base) >> 6);
+        for (int k = 0; k < len; ++k) {
+          const int64_t j = cols[base + (int64_t)k * GL_WAVE + lane];
+          if (j >= n_own) continue;   // ghost column: outside this rank's preconditioner
+          int cj[3];
+          lin2v(cell0[j], g1, cj);
+          double wj = 1.0;
+#pragma unroll
+          for (int a = 0; a < D; ++a) {
+            const int dj = Jv[a] - cj[a];
+            const double w = wgt[j * D + a];
+            wj *= dj == 0 ? 1.0 - w : dj == 1 ? w : 0.0;
+          }
+          if (wj == 0.0) continue;
+          const double ww = wi * wj;
+          const double* v = vK + (base + (int64_t)k * GL_WAVE) * B2 + lane;
+#pragma unroll
+          for (int e = 0; e < B2; ++e) {
+            double val = v[e * GL_WAVE];
+            if (fixed && (fixed[i * BS + e / BS] || fixed[j * BS + e % BS])) val = 0.0;
+            acc[e] += ww * val;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < B2; ++e) A1[((long long)off * B2 + e) * g1.nn + I] = (float)acc[e];
+}
+
+struct Fac {
+  int f[3];
+};
+// 1-D interpolation weight of fine index j with respect to coarse index J (factor f)
+__device__ __forceinline__ double w1d(int f, int j, int J) {
+  if (f == 1) return j == J ? 1.0 : 0.0;
+  const int dlt = j - 2 * J;
+  return dlt == 0 ? 1.0 : (dlt == 1 || dlt == -1) ? 0.5 : 0.0;
+}
+
+// Galerkin product between two Cartesian levels, one thread per (coarse node, stencil offset)
+template <int D>
+__global__ void k_mg_rap(GridDev gf, GridDev gc, Fac fc, int R, int S, const float* __restrict__ Af,
+                         float* __restrict__ Ac) {
+  constexpr int B2 = D * D;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= gc.nn * S) return;
+  const long long I = t / S;
+  const int off = (int)(t - I * S);
+  int Iv[3], o[3], Jv[3] = {0, 0, 0};
+  lin2v(I, gc, Iv);
+  off2v<D>(off, R, o);
+  bool inside = true;
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    Jv[a] = Iv[a] + o[a];
+    inside = inside && Jv[a] >= 0 && Jv[a] < gn(gc, a);
+  }
+  double acc[B2];
+#pragma unroll
+  for (int e = 0; e < B2; ++e) acc[e] = 0.0;
+  if (inside) {
+    const int nch = D == 3 ? 27 : 9;
+    for (int ch = 0; ch < nch; ++ch) {
+      int dv[3] = {ch % 3 - 1, (ch / 3) % 3 - 1, D == 3 ? ch / 9 - 1 : 0};
+      int iv[3] = {0, 0, 0};
+      double wi = 1.0;
+      bool ok = true;
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        if (fc.f[a] == 1) {
+          if (dv[a] != 0) ok = false;
+          iv[a] = Iv[a];
+        } else {
+          iv[a] = 2 * Iv[a] + dv[a];
+          wi *= dv[a] == 0 ? 1.0 : 0.5;
+        }
+        ok = ok && iv[a] >= 0 && iv[a] < gn(gf, a);
+      }
+      if (!ok) continue;
+      const long long i = v2lin(iv, gf);
+      // fine stencil offsets that land on a child of J: |iv + of - f J| <= f - 1
+      int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        const int ctr = fc.f[a] * Jv[a] - iv[a];
+        lo[a] = max(-R, ctr - (fc.f[a] - 1));
+        hi[a] = min(R, ctr + (fc.f[a] - 1));
+      }
+      int of[3] = {0, 0, 0};
+      for (of[2] = lo[2]; of[2] <= hi[2]; ++of[2])
+        for (of[1] = lo[1]; of[1] <= hi[1]; ++of[1])
+          for (of[0] = lo[0]; of[0] <= hi[0]; ++of[0]) {
+            double wj = 1.0;
+            bool in = true;
+#pragma unroll
+            for (int a = 0; a < D; ++a) {
+              const int jv = iv[a] + of[a];
+              in = in && jv >= 0 && jv < gn(gf, a);
+              wj *= w1d(fc.f[a], jv, Jv[a]);
+            }
+            if (!in || wj == 0.0) continue;
+            const int oi = v2off<D>(of, R);
+            const double ww = wi * wj;
+#pragma unroll
+            for (int e = 0; e < B2; ++e) acc[e] += ww * (double)Af[((long long)oi * B2 + e) * gf.nn + i];
+          }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < B2; ++e) Ac[((long long)off * B2 + e) * gc.nn + I] = (float)acc[e];
+}
+
+template <int BS>
+__device__ __forceinline__ void inv_block(double (*A)[BS], double* o) {
+  // dofs without any stiffness (no free child): identity, so that the block stays invertible and the dof stays zero
+#pragma unroll
+  for (int a = 0; a < BS; ++a)
+    if (!(A[a][a] > 0.0)) {
+#pragma unroll
+      for (int b = 0; b < BS; ++b) A[a][b] = A[b][a] = 0.0;
+      A[a][a] = 1.0;
+    }
+  if constexpr (BS == 2) {
+    const double inv = 1.0 / (A[0][0] * A[1][1] - A[0][1] * A[1][0]);
+    o[0] = A[1][1] * inv;
+    o[1] = -A[0][1] * inv;
+    o[2] = -A[1][0] * inv;
+    o[3] = A[0][0] * inv;
+  } else {
+    const double c00 = A[1][1] * A[2][2] - A[1][2] * A[2][1];
+    const double c01 = A[1][2] * A[2][0] - A[1][0] * A[2][2];
+    const double c02 = A[1][0] * A[2][1] - A[1][1] * A[2][0];
+    const double inv = 1.0 / (A[0][0] * c00 + A[0][1] * c01 + A[0][2] * c02);
+    o[0] = c00 * inv;
+    o[1] = (A[0][2] * A[2][1] - A[0][1] * A[2][2]) * inv;
+    o[2] = (A[0][1] * A[1][2] - A[0][2] * A[1][1]) * inv;
+    o[3] = c01 * inv;
+    o[4] = (A[0][0] * A[2][2] - A[0][2] * A[2][0]) * inv;
+    o[5] = (A[0][2] * A[1][0] - A[0][0] * A[1][2]) * inv;
+    o[6] = c02 * inv;
+    o[7] = (A[0][1] * A[2][0] - A[0][0] * A[2][1]) * inv;
+    o[8] = (A[0][0] * A[1][1] - A[0][1] * A[1][0]) * inv;
+  }
+}
+
+template <int D>
+__global__ void k_mg_dinv(GridDev g, int S, const float* __restrict__ A, double* __restrict__ dinv) {
+  constexpr int BS = D, B2 = D * D;
+  const long long I = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (I >= g.nn) return;
+  const int ctr = S / 2;
+  double M[BS][BS], o[B2];
+#pragma unroll
+  for (int a = 0; a < BS; ++a)
+#pragma unroll
+    for (int b = 0; b < BS; ++b) M[a][b] = (double)A[((long long)ctr * B2 + a * BS + b) * g.nn + I];
+  // the product is symmetric up to the single-precision rounding of its entries: symmetrise the block
+#pragma unroll
+  for (int a = 0; a < BS; ++a)
+#pragma unroll
+    for (int b = a + 1; b < BS; ++b) M[a][b] = M[b][a] = 0.5 * (M[a][b] + M[b][a]);
+  inv_block<BS>(M, o);
+#pragma unroll
+  for (int e = 0; e < B2; ++e) dinv[(long long)e * g.nn + I] = o[e];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// cycle kernels, Cartesian levels (vectors component-major [BS][nn])
+// ---------------------------------------------------------------------------------------------------
+// MODE 0: xout = r - A xin     MODE 1: d = c1 d + c2 Dinv (r - A xin); xout = xin + d     MODE 2: xout = Dinv A xin
+template <int D, int MODE>
+__global__ __launch_bounds__(256) void k_mg_cart(GridDev g, int R, const float* __restrict__ A,
+                                                  const double* __restrict__ dinv, const double* __restrict__ xin,
+                                                  const double* __restrict__ r, double* __restrict__ d,
+                                                  double* __restrict__ xout, double c1, double c2,
+                                                  const int* __restrict__ done) {
+  constexpr int BS = D, B2 = D * D;
+  if (done && *done) return;   // launches enqueued past the Krylov solver's convergence: nobody reads the result
+  const long long I = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (I >= g.nn) return;
+  int Iv[3];
+  lin2v(I, g, Iv);
+  double acc[BS];
+#pragma unroll
+  for (int a = 0; a < BS; ++a) acc[a] = 0.0;
+  const int W = 2 * R + 1;
+  const int zlo = D == 3 ? max(-R, -Iv[2]) : 0, zhi = D == 3 ? min(R, g.n2 - 1 - Iv[2]) : 0;
+  const int ylo = max(-R, -Iv[1]), yhi = min(R, g.n1 - 1 - Iv[1]);
+  const int xlo = max(-R, -Iv[0]), xhi = min(R, g.n0 - 1 - Iv[0]);
+  for (int oz = zlo; oz <= zhi; ++oz)
+    for (int oy = ylo; oy <= yhi; ++oy) {
+      const long long nb0 = I + ((long long)oz * g.n1 + oy) * g.n0;
+      const int off0 = (D == 3 ? (oz + R) * W * W : 0) + (oy + R) * W + R;
+      for (int ox = xlo; ox <= xhi; ++ox) {
+        const long long nb = nb0 + ox;
+        const float* a0 = A + (long long)(off0 + ox) * B2 * g.nn + I;
+        double xb[BS];
+#pragma unroll
+        for (int b = 0; b < BS; ++b) xb[b] = xin[(long long)b * g.nn + nb];
+#pragma unroll
+        for (int a = 0; a < BS; ++a)
+#pragma unroll
+          for (int b = 0; b < BS; ++b) acc[a] += (double)a0[(long long)(a * BS + b) * g.nn] * xb[b];
+      }
+    }
+  double t[BS];
+#pragma unroll
+  for (int a = 0; a < BS; ++a) t[a] = MODE == 2 ? acc[a] : r[(long long)a * g.nn + I] - acc[a];
+  if (MODE == 0) {
+#pragma unroll
+    for (int a = 0; a < BS; ++a) xout[(long long)a * g.nn + I] = t[a];
+    return;
+  }
+#pragma unroll
+  for (int a = 0; a < BS; ++a) {
+    double z = 0.0;
+#pragma unroll
+    for (int b = 0; b < BS; ++b) z += dinv[(long long)(a * BS + b) * g.nn + I] * t[b];
+    if (MODE == 2) {
+      xout[(long long)a * g.nn + I] = z;
+    } else {
+      const double dn = (c1 != 0.0 ? c1 * d[(long long)a * g.nn + I] : 0.0) + c2 * z;
+      d[(long long)a * g.nn + I] = dn;
+      xout[(long long)a * g.nn + I] = xin[(long long)a * g.nn + I] + dn;
+    }
+  }
+}
+
+// first smoothing step from a zero iterate: d = c2 Dinv r, x = d   (no operator pass)
+template <int D>
+__global__ void k_mg_first_cart(GridDev g, const double* __restrict__ dinv, const double* __restrict__ r,
+                                double* __restrict__ d, double* __restrict__ x, double c2) {
+  constexpr int BS = D;
+  const long long I = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (I >= g.nn) return;
+  double rv[BS];
+#pragma unroll
+  for (int a = 0; a < BS; ++a) rv[a] = r[(long long)a * g.nn + I];
+#pragma unroll
+  for (int a = 0; a < BS; ++a) {
+    double z = 0.0;
+#pragma unroll
+    for (int b = 0; b < BS; ++b) z += dinv[(long long)(a * BS + b) * g.nn + I] * rv[b];
+    d[(long long)a * g.nn + I] = c2 * z;
+    x[(long long)a * g.nn + I] = c2 * z;
+  }
+}
+template <int BS>
+__global__ void k_mg_first_fine(int64_t n_own, const double* __restrict__ dinv, const double* __restrict__ r,
+                                double* __restrict__ d, double* __restrict__ x, double c2) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_own) return;
+  double rv[BS];
+#pragma unroll
+  for (int a = 0; a < BS; ++a) rv[a] = r[i * BS + a];
+#pragma unroll
+  for (int a = 0; a < BS; ++a) {
+    double z = 0.0;
+#pragma unroll
+    for (int b = 0; b < BS; ++b) z += dinv[i * BS * BS + a * BS + b] * rv[b];
+    d[i * BS + a] = c2 * z;
+    x[i * BS + a] = c2 * z;
+  }
+}
+
+// restriction mesh -> grid: r1[I] = sum_{children i} w_iI res_i   (gather over the sorted children lists)
+template <int D>
+__global__ void k_mg_restrict0(GridDev g1, const int32_t* __restrict__ cell_ptr,
+                               const int32_t* __restrict__ cell_nodes, const double* __restrict__ wgt,
+                               const double* __restrict__ res, double* __restrict__ r1) {
+  constexpr int BS = D;
+  const long long I = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (I >= g1.nn) return;
+  int Iv[3];
+  lin2v(I, g1, Iv);
+  double acc[BS];
+#pragma unroll
+  for (int a = 0; a < BS; ++a) acc[a] = 0.0;
+  for (int corner = 0; corner < (1 << D); ++corner) {
+    int cv[3] = {0, 0, 0};
+    bool ok = true;
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      cv[a] = Iv[a] - ((corner >> a) & 1);
+      ok = ok && cv[a] >= 0 && cv[a] <= gn(g1, a) - 2;
+    }
+    if (!ok) continue;
+    const long long c = v2lin(cv, g1);
+    for (int32_t q = cell_ptr[c]; q < cell_ptr[c + 1]; ++q) {
+      const int64_t i = cell_nodes[q];
+      double wi = 1.0;
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        const double w = wgt[i * D + a];
+        wi *= ((corner >> a) & 1) ? w : 1.0 - w;
+      }
+#pragma unroll
+      for (int a = 0; a < BS; ++a) acc[a] += wi * res[i * BS + a];
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < BS; ++a) r1[(long long)a * g1.nn + I] = acc[a];
+}
+
+// prolongation grid -> mesh: xout_i = xin_i + F_i sum_{parents} w e_J
+template <int D>
+__global__ void k_mg_prolong0(GridDev g1, int64_t n_own, const int32_t* __restrict__ cell0,
+                              const double* __restrict__ wgt, const uint8_t* __restrict__ fixed,
+                              const double* __restrict__ e1, const double* __restrict__ xin,
+                              double* __restrict__ xout) {
+  constexpr int BS = D;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_own) return;
+  int cv[3];
+  lin2v(cell0[i], g1, cv);
+  double acc[BS];
+#pragma unroll
+  for (int a = 0; a < BS; ++a) acc[a] = 0.0;
+  for (int corner = 0; corner < (1 << D); ++corner) {
+    int pv[3] = {0, 0, 0};
+    double w = 1.0;
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      const int up = (corner >> a) & 1;
+      pv[a] = cv[a] + up;
+      const double wa = wgt[i * D + a];
+      w *= up ? wa : 1.0 - wa;
+    }
+    if (w == 0.0) continue;
+    const long long J = v2lin(pv, g1);
+#pragma unroll
+    for (int a = 0; a < BS; ++a) acc[a] += w * e1[(long long)a * g1.nn + J];
+  }
+#pragma unroll
+  for (int a = 0; a < BS; ++a)
+    xout[i * BS + a] = (fixed && fixed[i * BS + a]) ? 0.0 : xin[i * BS + a] + acc[a];
+}
+
+template <int D>
+__global__ void k_mg_restrict(GridDev gf, GridDev gc, Fac fc, const double* __restrict__ res,
+                              double* __restrict__ rc) {
+  constexpr int BS = D;
+  const long long I = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (I >= gc.nn) return;
+  int Iv[3];
+  lin2v(I, gc, Iv);
+  double acc[BS];
+#pragma unroll
+  for (int a = 0; a < BS; ++a) acc[a] = 0.0;
+  const int nch = D == 3 ? 27 : 9;
+  for (int ch = 0; ch < nch; ++ch) {
+    int dv[3] = {ch % 3 - 1, (ch / 3) % 3 - 1, D == 3 ? ch / 9 - 1 : 0};
+    int iv[3] = {0, 0, 0};
+    double wi = 1.0;
+    bool ok = true;
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      if (fc.f[a] == 1) {
+        if (dv[a] != 0) ok = false;
+        iv[a] = Iv[a];
+      } else {
+        iv[a] = 2 * Iv[a] + dv[a];
+        wi *= dv[a] == 0 ? 1.0 : 0.5;
+      }
+      ok = ok && iv[a] >= 0 && iv[a] < gn(gf, a);
+    }
+    if (!ok) continue;
+    const long long i = v2lin(iv, gf);
+#pragma unroll
+    for (int a = 0; a < BS; ++a) acc[a] += wi * res[(long long)a * gf.nn + i];
+  }
+#pragma unroll
+  for (int a = 0; a < BS; ++a) rc[(long long)a * gc.nn + I] = acc[a];
+}
+
+template <int D>
+__global__ void k_mg_prolong(GridDev gf, GridDev gc, Fac fc, const double* __restrict__ ec,
+                             const double* __restrict__ xin, double* __restrict__ xout) {
+  constexpr int BS = D;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= gf.nn) return;
+  int iv[3];
+  lin2v(i, gf, iv);
+  double acc[BS];
+#pragma unroll
+  for (int a = 0; a < BS; ++a) acc[a] = 0.0;
+  for (int corner = 0; corner < (1 << D); ++corner) {
+    int pv[3] = {0, 0, 0};
+    double w = 1.0;
+    bool ok = true;
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      const int up = (corner >> a) & 1;
+      if (fc.f[a] == 1) {
+        if (up) ok = false;
+        pv[a] = iv[a];
+      } else if ((iv[a] & 1) == 0) {
+        if (up) ok = false;
+        pv[a] = iv[a] >> 1;
+      } else {
+        pv[a] = (iv[a] >> 1) + up;
+        w *= 0.5;
+      }
+    }
+    if (!ok) continue;
+    const long long J = v2lin(pv, gc);
+#pragma unroll
+    for (int a = 0; a < BS; ++a) acc[a] += w * ec[(long long)a * gc.nn + J];
+  }
+#pragma unroll
+  for (int a = 0; a < BS; ++a) xout[(long long)a * gf.nn + i] = xin[(long long)a * gf.nn + i] + acc[a];
+}
+
+// coarsest level: x = Ainv r, one wave per row of the dense inverse
+__global__ __launch_bounds__(256) void k_mg_dense(int n, const double* __restrict__ Ainv, const double* __restrict__ r,
+                                                   double* __restrict__ x) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= n) return;
+  double v = 0.0;
+  for (int k = lane; k < n; k += GL_WAVE) v += Ainv[(size_t)row * n + k] * r[k];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if (lane == 0) x[row] = v;
+}
+
+__global__ void k_mg_fill(int64_t n, double* __restrict__ x, const uint8_t* __restrict__ fixed) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // deterministic pseudo-random start vector of the power iteration
+  unsigned long long z = (unsigned long long)i * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  x[i] = (fixed && fixed[i]) ? 0.0 : (double)(z >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+}
+__global__ void k_mg_scale(int64_t n, double* __restrict__ x, double s) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] *= s;
+}
+
+inline unsigned gridn(long long n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
+
+// Chebyshev coefficients of step m (0-based) for the spectrum [lmax / ratio, lmax] of Dinv A
+struct Cheb {
+  double theta, delta, sigma, rho;
+  explicit Cheb(double lam) {
+    const double lmax = 1.1 * lam, lmin = lmax / 4.0;
+    theta = 0.5 * (lmax + lmin);
+    delta = 0.5 * (lmax - lmin);
+    sigma = theta / delta;
+    rho = 1.0 / sigma;
+  }
+  void next(int m, double* c1, double* c2) {
+    if (m == 0) {
+      *c1 = 0.0;
+      *c2 = 1.0 / theta;
+      rho = 1.0 / sigma;
+      return;
+    }
+    const double rn = 1.0 / (2.0 * sigma - rho);
+    *c1 = rn * rho;
+    *c2 = 2.0 * rn / delta;
+    rho = rn;
+  }
+};
+
+}  // namespace
+
+// ===================================================================================================
+// mesh metrics (glims_create): bounding box, lattice detection, mean edge length, coordinates in internal numbering
+// ===================================================================================================
+void gl_mesh_metrics(glims_ctx* h, const HostPattern& hp, const double* xyz_old) {
+  MeshMetrics& mm = h->mm;
+  const int d = h->dim;
+  const int64_t n = h->n_own;
+  mm.xyz.resize((size_t)n * d);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i)
+    for (int a = 0; a < d; ++a) mm.xyz[i * d + a] = xyz_old[(int64_t)hp.new2old[i] * d + a];
+  for (int a = 0; a < 3; ++a) {
+    mm.lo[a] = 1e300;
+    mm.hi[a] = -1e300;
+  }
+  for (int64_t i = 0; i < n; ++i)
+    for (int a = 0; a < d; ++a) {
+      mm.lo[a] = std::min(mm.lo[a], mm.xyz[i * d + a]);
+      mm.hi[a] = std::max(mm.hi[a], mm.xyz[i * d + a]);
+    }
+  for (int a = d; a < 3; ++a) mm.lo[a] = mm.hi[a] = 0.0;
+  // edges from the SELL pattern (owned columns only): smallest positive coordinate difference per axis, mean length
+  double hmin[3] = {1e300, 1e300, 1e300}, esum = 0.0;
+  int64_t ecnt = 0;
+  double ext[3];
+  for (int a = 0; a < 3; ++a) ext[a] = std::max(mm.hi[a] - mm.lo[a], 1e-300);
+#pragma omp parallel
+  {
+    double hm[3] = {1e300, 1e300, 1e300}, es = 0.0;
+    int64_t ec = 0;
+#pragma omp for schedule(static) nowait
+    for (int32_t s = 0; s < hp.n_slices; ++s) {
+      const int64_t base = hp.slice_ptr[s];
+      const int len = (int)((hp.slice_ptr[s + 1] - base) / GL_WAVE);
+      for (int l = 0; l < GL_WAVE; ++l) {
+        const int64_t i = (int64_t)s * GL_WAVE + l;
+        if (i >= n) break;
+        for (int k = 0; k < len; ++k) {
+          const int64_t j = hp.cols[base + (int64_t)k * GL_WAVE + l];
+          if (j <= i || j >= n) continue;
+          double e2 = 0.0;
+          for (int a = 0; a < d; ++a) {
+            const double dl = std::fabs(mm.xyz[i * d + a] - mm.xyz[j * d + a]);
+            e2 += dl * dl;
+            if (dl > 1e-9 * ext[a]) hm[a] = std::min(hm[a], dl);
+          }
+          es += std::sqrt(e2);
+          ++ec;
+        }
+      }
+    }
+#pragma omp critical
+    {
+      for (int a = 0; a < 3; ++a) hmin[a] = std::min(hmin[a], hm[a]);
+      esum += es;
+      ecnt += ec;
+    }
+  }
+  mm.mean_edge = ecnt > 0 ? esum / (double)ecnt : ext[0];
+  // lattice test: every coordinate an integer multiple of the axis' smallest edge component (box meshes)
+  bool lat = true;
+  for (int a = 0; a < d && lat; ++a) {
+    if (!(hmin[a] < 1e299) || (mm.hi[a] - mm.lo[a]) / hmin[a] > 1e5) {
+      lat = false;
+      break;
+    }
+    int bad = 0;
+#pragma omp parallel for schedule(static) reduction(+ : bad)
+    for (int64_t i = 0; i < n; ++i) {
+      const double t = (mm.xyz[i * d + a] - mm.lo[a]) / hmin[a];
+      if (std::fabs(t - std::round(t)) > 1e-6) ++bad;
+    }
+    lat = bad == 0;
+    mm.h_lattice[a] = hmin[a];
+  }
+  mm.lattice = lat;
+}
+
+// ===================================================================================================
+// set-up
+// ===================================================================================================
+namespace {
+
+template <int D>
+void mg_apply_cart(glims_ctx* h, MgLevel& L, int R, int mode, const double* xin, const double* r, double* d,
+                   double* xout, double c1, double c2, const int* done = nullptr) {
+  const GridDev g = gdev(L.g);
+  const unsigned grid = gridn(g.nn);
+  if (mode == 0)
+    hipLaunchKernelGGL((k_mg_cart<D, 0>), dim3(grid), dim3(256), 0, h->st, g, R, L.A.p, L.dinv.p, xin, r, d, xout, c1, c2, done);
+  else if (mode == 1)
+    hipLaunchKernelGGL((k_mg_cart<D, 1>), dim3(grid), dim3(256), 0, h->st, g, R, L.A.p, L.dinv.p, xin, r, d, xout, c1, c2, done);
+  else
+    hipLaunchKernelGGL((k_mg_cart<D, 2>), dim3(grid), dim3(256), 0, h->st, g, R, L.A.p, L.dinv.p, xin, r, d, xout, c1, c2, done);
+  GL_HIP(hipGetLastError());
+}
+
+// dense inverse of the coarsest operator (host): A + shift, Cholesky, inverse
+bool dense_spd_inverse(std::vector<double>& A, int n, double shift_rel) {
+  double dmax = 0.0;
+  for (int i = 0; i < n; ++i) dmax = std::max(dmax, A[(size_t)i * n + i]);
+  std::vector<double> L(A);
+  for (int i = 0; i < n; ++i) L[(size_t)i * n + i] += shift_rel * dmax;
+  for (int j = 0; j < n; ++j) {
+    double s = L[(size_t)j * n + j];
+    for (int k = 0; k < j; ++k) s -= L[(size_t)j * n + k] * L[(size_t)j * n + k];
+    if (!(s > 0.0)) return false;
+    const double ljj = std::sqrt(s);
+    L[(size_t)j * n + j] = ljj;
+#pragma omp parallel for schedule(static) if (n - j > 256)
+    for (int i = j + 1; i < n; ++i) {
+      double t = L[(size_t)i * n + j];
+      for (int k = 0; k < j; ++k) t -= L[(size_t)i * n + k] * L[(size_t)j * n + k];
+      L[(size_t)i * n + j] = t / ljj;
+    }
+  }
+  // inverse column by column: L y = e_c, L^T x = y
+#pragma omp parallel for schedule(dynamic, 8)
+  for (int c = 0; c < n; ++c) {
+    std::vector<double> y(n, 0.0);
+    for (int i = c; i < n; ++i) {
+      double t = i == c ? 1.0 : 0.0;
+      for (int k = c; k < i; ++k) t -= L[(size_t)i * n + k] * y[k];
+      y[i] = t / L[(size_t)i * n + i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+      double t = y[i];
+      for (int k = i + 1; k < n; ++k) t -= L[(size_t)k * n + i] * y[k];
+      y[i] = t / L[(size_t)i * n + i];
+    }
+    for (int i = 0; i < n; ++i) A[(size_t)i * n + c] = y[i];
+  }
+  return true;
+}
+
+template <int D>
+void mg_setup_t(glims_ctx* h) {
+  constexpr int BS = D, B2 = D * D;
+  MgHierarchy& mg = h->mg;
+  const MeshMetrics& mm = h->mm;
+  const DevPattern& p = h->pat;
+  const int64_t n = h->n_own;
+  const double t_start = omp_get_wtime();
+  mg.clear();
+  GL_REQUIRE(h->vKel32.n != 0 && h->vKel.n != 0, "multigrid set-up before the elasticity operator was assembled");
+  GL_REQUIRE(!mm.xyz.empty(), "mesh metrics missing");
+  const uint8_t* fx = h->have_fixed_u ? h->fixed_u.p : nullptr;
+  const double hf = h->opt.mg_h_factor > 0.5 ? h->opt.mg_h_factor : 2.0;
+  const int coarse_max = std::max(8, h->opt.mg_coarse_nodes);
+
+  // ---- level 1 grid: spacing, origin, node -> cell map (host), children lists ------------------------------------
+  double H[3] = {1, 1, 1};
+  for (int a = 0; a < D; ++a) H[a] = mm.lattice ? hf * mm.h_lattice[a] : hf * mm.mean_edge / 1.2;
+  MgGrid g1;
+  std::vector<int32_t> cell0(n);
+  std::vector<double> wgt((size_t)n * D);
+  for (int attempt = 0;; ++attempt) {
+    g1 = MgGrid();
+    g1.nn = 1;
+    for (int a = 0; a < D; ++a) {
+      const int cells = std::max(1, (int)std::ceil((mm.hi[a] - mm.lo[a]) / H[a] - 1e-9));
+      g1.n[a] = cells + 1;
+      g1.nn *= g1.n[a];
+      mg.lo[a] = mm.lo[a];
+      mg.H[a] = H[a];
+    }
+    GL_REQUIRE(g1.nn < (int64_t(1) << 31), "auxiliary grid too large");
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+      int64_t lin = 0, stride = 1;
+      for (int a = 0; a < D; ++a) {
+        const double t = (mm.xyz[i * D + a] - mm.lo[a]) / H[a];
+        int c = (int)std::floor(t);
+        c = std::max(0, std::min(g1.n[a] - 2, c));
+        double w = t - c;
+        if (std::fabs(w) < 1e-6) w = 0.0;            // lattice-aligned nodes: exact weights, compact stencils
+        if (std::fabs(w - 1.0) < 1e-6) w = 1.0;
+        w = std::max(0.0, std::min(1.0, w));
+        wgt[i * D + a] = w;
+        lin += (int64_t)c * stride;
+        stride *= g1.n[a];
+      }
+      cell0[i] = (int32_t)lin;
+    }
+    mg.cell0.upload(cell0, h->st);
+    mg.wgt.upload(wgt, h->st);
+    dvec<int> reach;
+    reach.alloc_zero(1, h->st);
+    hipLaunchKernelGGL(k_mg_reach<D>, dim3(gridn(n)), dim3(256), 0, h->st, n, gdev(g1), p.slice_ptr.p, p.cols.p,
+                       mg.cell0.p, mg.wgt.p, reach.p);
+    GL_HIP(hipGetLastError());
+    int rc = 0;
+    GL_HIP(hipMemcpyAsync(&rc, reach.p, sizeof(int), hipMemcpyDeviceToHost, h->st));
+    GL_HIP(hipStreamSynchronize(h->st));
+    if (rc <= 2) {
+      mg.R = std::max(1, rc);
+      break;
+    }
+    GL_REQUIRE(attempt < 6, "multigrid: mesh edges span more than two cells of every auxiliary grid tried "
+                            "(strongly graded mesh); use GLIMS_PRECOND_BLOCK_JACOBI");
+    for (int a = 0; a < D; ++a) H[a] *= 0.5 * (rc + 1);   // edges then span at most two cells
+  }
+  mg.S = 1;
+  for (int a = 0; a < D; ++a) mg.S *= 2 * mg.R + 1;
+  {   // children lists: counting sort of the mesh nodes by cell
+    std::vector<int32_t> ptr((size_t)g1.nn + 1, 0), nodes((size_t)n);
+    for (int64_t i = 0; i < n; ++i) ptr[(size_t)cell0[i] + 1]++;
+    for (int64_t c = 0; c < g1.nn; ++c) ptr[c + 1] += ptr[c];
+    std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
+    for (int64_t i = 0; i < n; ++i) nodes[fill[cell0[i]]++] = (int32_t)i;
+    mg.cell_ptr.upload(ptr, h->st);
+    mg.cell_nodes.upload(nodes, h->st);
+    GL_HIP(hipStreamSynchronize(h->st));
+  }
+  const size_t nd0 = (size_t)h->n_nodes * BS;
+  mg.x.alloc_zero(nd0, h->st);
+  mg.x2.alloc_zero(nd0, h->st);
+  mg.d.alloc_zero(nd0, h->st);
+  mg.res.alloc_zero(nd0, h->st);
+
+  // ---- Galerkin products ------------------------------------------------------------------------------------------
+  auto new_level = [&](const MgGrid& g) {
+    MgLevel* L = new MgLevel();
+    L->g = g;
+    L->A.alloc((size_t)mg.S * B2 * g.nn);
+    L->dinv.alloc((size_t)B2 * g.nn);
+    for (dvec<double>* v : {&L->x, &L->x2, &L->r, &L->d, &L->res}) v->alloc_zero((size_t)BS * g.nn, h->st);
+    mg.lv.push_back(L);
+    return L;
+  };
+  MgLevel* L1 = new_level(g1);
+  hipLaunchKernelGGL(k_mg_rap0<D>, dim3(gridn((long long)g1.nn * mg.S)), dim3(256), 0, h->st, gdev(g1), mg.R, mg.S, n,
+                     mg.cell_ptr.p, mg.cell_nodes.p, mg.cell0.p, mg.wgt.p, p.slice_ptr.p, p.cols.p, h->vKel.p, fx,
+                     L1->A.p);
+  GL_HIP(hipGetLastError());
+  mg.entries = (int64_t)mg.S * B2 * g1.nn;
+  while (mg.lv.back()->g.nn > coarse_max) {
+    MgLevel* Lf = mg.lv.back();
+    MgGrid gc;
+    gc.nn = 1;
+    bool any = false;
+    for (int a = 0; a < D; ++a) {
+      if (Lf->g.n[a] > 2) {
+        Lf->f[a] = 2;
+        gc.n[a] = Lf->g.n[a] / 2 + 1;
+        any = true;
+      } else {
+        Lf->f[a] = 1;
+        gc.n[a] = Lf->g.n[a];
+      }
+      gc.nn *= gc.n[a];
+    }
+    if (!any) break;
+    MgLevel* Lc = new_level(gc);
+    Lf = mg.lv[mg.lv.size() - 2];
+    Fac fc{{Lf->f[0], Lf->f[1], Lf->f[2]}};
+    hipLaunchKernelGGL(k_mg_rap<D>, dim3(gridn((long long)gc.nn * mg.S)), dim3(256), 0, h->st, gdev(Lf->g), gdev(gc),
+                       fc, mg.R, mg.S, Lf->A.p, Lc->A.p);
+    GL_HIP(hipGetLastError());
+    mg.entries += (int64_t)mg.S * B2 * gc.nn;
+  }
+  for (MgLevel* L : mg.lv) {
+    hipLaunchKernelGGL(k_mg_dinv<D>, dim3(gridn(L->g.nn)), dim3(256), 0, h->st, gdev(L->g), mg.S, L->A.p, L->dinv.p);
+    GL_HIP(hipGetLastError());
+  }
+
+  // ---- lambda_max(Dinv A) per smoothed level: power iteration -----------------------------------------------------
+  gl_block_dinv(h);
+  const int pit = 12;
+  {
+    const int64_t nd = n * BS;
+    hipLaunchKernelGGL(k_mg_fill, dim3(gridn(nd)), dim3(256), 0, h->st, nd, mg.x.p, fx);
+    double lam = 1.0;
+    for (int it = 0; it < pit; ++it) {
+      gl_launch_mg_fine(h, 2, mg.x.p, nullptr, nullptr, mg.x2.p, 0.0, 0.0);
+      lam = std::sqrt(gl_dot(h, mg.x2.p, mg.x2.p, nd, false));   // = |Dinv A x| / |x| once x is normalised (it > 0)
+      if (!(lam > 0.0) || !std::isfinite(lam)) break;
+      hipLaunchKernelGGL(k_mg_scale, dim3(gridn(nd)), dim3(256), 0, h->st, nd, mg.x2.p, 1.0 / lam);
+      std::swap(mg.x.p, mg.x2.p);
+    }
+    mg.lam0 = (std::isfinite(lam) && lam > 0.0) ? lam : 2.0;
+    GL_HIP(hipMemsetAsync(mg.x.p, 0, nd0 * sizeof(double), h->st));
+    GL_HIP(hipMemsetAsync(mg.x2.p, 0, nd0 * sizeof(double), h->st));
+  }
+  for (size_t l = 0; l + 1 < mg.lv.size(); ++l) {
+    MgLevel& L = *mg.lv[l];
+    const int64_t nd = L.g.nn * BS;
+    hipLaunchKernelGGL(k_mg_fill, dim3(gridn(nd)), dim3(256), 0, h->st, nd, L.x.p, (const uint8_t*)nullptr);
+    double lam = 1.0;
+    for (int it = 0; it < pit; ++it) {
+      mg_apply_cart<D>(h, L, mg.R, 2, L.x.p, nullptr, nullptr, L.x2.p, 0.0, 0.0);
+      lam = std::sqrt(gl_dot(h, L.x2.p, L.x2.p, nd, false));
+      if (!(lam > 0.0) || !std::isfinite(lam)) break;
+      hipLaunchKernelGGL(k_mg_scale, dim3(gridn(nd)), dim3(256), 0, h->st, nd, L.x2.p, 1.0 / lam);
+      std::swap(L.x.p, L.x2.p);
+    }
+    L.lam = (std::isfinite(lam) && lam > 0.0) ? lam : 2.0;
+  }
+
+  // ---- coarsest level: dense inverse on the host ------------------------------------------------------------------
+  {
+    MgLevel& L = *mg.lv.back();
+    const int64_t nn = L.g.nn;
+    const int nc = (int)(nn * BS);
+    GL_REQUIRE(nc <= 6000, "coarsest multigrid level too large for the dense solve (mg_coarse_nodes)");
+    std::vector<float> Ah((size_t)mg.S * B2 * nn);
+    GL_HIP(hipMemcpyAsync(Ah.data(), L.A.p, Ah.size() * sizeof(float), hipMemcpyDeviceToHost, h->st));
+    GL_HIP(hipStreamSynchronize(h->st));
+    std::vector<double> M((size_t)nc * nc, 0.0);
+    const int W = 2 * mg.R + 1;
+    for (int64_t I = 0; I < nn; ++I) {
+      const int iv[3] = {(int)(I % L.g.n[0]), (int)((I / L.g.n[0]) % L.g.n[1]), (int)(I / ((int64_t)L.g.n[0] * L.g.n[1]))};
+      for (int off = 0; off < mg.S; ++off) {
+        const int o[3] = {off % W - mg.R, (off / W) % W - mg.R, D == 3 ? off / (W * W) - mg.R : 0};
+        bool in = true;
+        int jv[3] = {0, 0, 0};
+        for (int a = 0; a < D; ++a) {
+          jv[a] = iv[a] + o[a];
+          in = in && jv[a] >= 0 && jv[a] < L.g.n[a];
+        }
+        if (!in) continue;
+        const int64_t J = ((int64_t)jv[2] * L.g.n[1] + jv[1]) * L.g.n[0] + jv[0];
+        for (int a = 0; a < BS; ++a)
+          for (int b = 0; b < BS; ++b)
+            M[(size_t)(a * nn + I) * nc + (b * nn + J)] = (double)Ah[((size_t)off * B2 + a * BS + b) * nn + I];
+      }
+    }
+    for (int i = 0; i < nc; ++i)   // symmetrise (single-precision entries), identity on dofs without stiffness
+      for (int j = i + 1; j < nc; ++j) M[(size_t)i * nc + j] = M[(size_t)j * nc + i] = 0.5 * (M[(size_t)i * nc + j] + M[(size_t)j * nc + i]);
+    for (int i = 0; i < nc; ++i)
+      if (!(M[(size_t)i * nc + i] > 0.0)) {
+        for (int j = 0; j < nc; ++j) M[(size_t)i * nc + j] = M[(size_t)j * nc + i] = 0.0;
+        M[(size_t)i * nc + i] = 1.0;
+      }
+    // a body without Dirichlet data has the rigid-body modes in the kernel of every level: the small relative shift
+    // keeps the factorisation defined there and changes a regular operator by 1e-9
+    bool ok = false;
+    for (double shift = 1e-9; shift < 1.0 && !ok; shift *= 100.0) {
+      std::vector<double> T(M);
+      ok = dense_spd_inverse(T, nc, shift);
+      if (ok) M.swap(T);
+    }
+    GL_REQUIRE(ok, "multigrid: the coarsest operator is not positive definite");
+    mg.coarse_inv.upload(M, h->st);
+    GL_HIP(hipStreamSynchronize(h->st));
+  }
+  mg.ready = true;
+  h->stats.mg_levels = (int64_t)mg.lv.size() + 1;
+  h->stats.mg_complexity = 1.0 + (double)mg.entries / ((double)p.total_entries * B2);
+  h->stats.ms_mg_setup = 1e3 * (omp_get_wtime() - t_start);
+  if (getenv("GLIMS_VERBOSE")) {
+    fprintf(stderr, "glims multigrid: %s mesh, H = (%.4g, %.4g, %.4g), stencil radius %d, levels:", mm.lattice ? "lattice" : "general",
+            mg.H[0], mg.H[1], D == 3 ? mg.H[2] : 0.0, mg.R);
+    fprintf(stderr, " mesh(%lld nodes, lam %.2f)", (long long)n, mg.lam0);
+    for (MgLevel* L : mg.lv) fprintf(stderr, " %dx%dx%d(lam %.2f)", L->g.n[0], L->g.n[1], L->g.n[2], L->lam);
+    fprintf(stderr, "; operator complexity %.2f; set-up %.1f ms\n", h->stats.mg_complexity, h->stats.ms_mg_setup);
+  }
+}
+
+// one V-cycle on the Cartesian levels l.. : x_l = approx A_l^-1 r_l (result left in L.x)
+template <int D>
+void mg_cycle_cart(glims_ctx* h, size_t l, const int* done) {
+  constexpr int BS = D;
+  MgHierarchy& mg = h->mg;
+  MgLevel& L = *mg.lv[l];
+  const GridDev g = gdev(L.g);
+  if (l + 1 == mg.lv.size()) {
+    const int nc = (int)(L.g.nn * BS);
+    hipLaunchKernelGGL(k_mg_dense, dim3((nc + 3) / 4), dim3(256), 0, h->st, nc, mg.coarse_inv.p, L.r.p, L.x.p);
+    GL_HIP(hipGetLastError());
+    return;
+  }
+  const int deg = std::max(1, std::min(8, h->opt.mg_smooth));
+  Cheb ch(L.lam);
+  double c1, c2;
+  ch.next(0, &c1, &c2);
+  hipLaunchKernelGGL(k_mg_first_cart<D>, dim3(gridn(g.nn)), dim3(256), 0, h->st, g, L.dinv.p, L.r.p, L.d.p, L.x.p, c2);
+  double *xa = L.x.p, *xb = L.x2.p;
+  for (int m = 1; m < deg; ++m) {
+    ch.next(m, &c1, &c2);
+    mg_apply_cart<D>(h, L, mg.R, 1, xa, L.r.p, L.d.p, xb, c1, c2, done);
+    std::swap(xa, xb);
+  }
+  mg_apply_cart<D>(h, L, mg.R, 0, xa, L.r.p, nullptr, L.res.p, 0.0, 0.0, done);
+  MgLevel& C = *mg.lv[l + 1];
+  const Fac fc{{L.f[0], L.f[1], L.f[2]}};
+  hipLaunchKernelGGL(k_mg_restrict<D>, dim3(gridn(C.g.nn)), dim3(256), 0, h->st, g, gdev(C.g), fc, L.res.p, C.r.p);
+  GL_HIP(hipGetLastError());
+  mg_cycle_cart<D>(h, l + 1, done);
+  hipLaunchKernelGGL(k_mg_prolong<D>, dim3(gridn(g.nn)), dim3(256), 0, h->st, g, gdev(C.g), fc, C.x.p, xa, xb);
+  GL_HIP(hipGetLastError());
+  std::swap(xa, xb);
+  Cheb cp(L.lam);
+  for (int m = 0; m < deg; ++m) {
+    cp.next(m, &c1, &c2);
+    mg_apply_cart<D>(h, L, mg.R, 1, xa, L.r.p, L.d.p, xb, c1, c2, done);
+    std::swap(xa, xb);
+  }
+  if (xa != L.x.p) std::swap(L.x.p, L.x2.p);   // the result is always handed up in L.x
+}
+
+template <int D>
+void mg_apply_t(glims_ctx* h, const double* r, double* u, const int* done) {
+  constexpr int BS = D;
+  MgHierarchy& mg = h->mg;
+  const int64_t n = h->n_own;
+  const uint8_t* fx = h->have_fixed_u ? h->fixed_u.p : nullptr;
+  const int deg = std::max(1, std::min(8, h->opt.mg_smooth));
+  Cheb ch(mg.lam0);
+  double c1, c2;
+  ch.next(0, &c1, &c2);
+  hipLaunchKernelGGL(k_mg_first_fine<BS>, dim3(gridn(n)), dim3(256), 0, h->st, n, h->m_dinv.p, r, mg.d.p, mg.x.p, c2);
+  double *xa = mg.x.p, *xb = mg.x2.p;
+  for (int m = 1; m < deg; ++m) {
+    ch.next(m, &c1, &c2);
+    gl_launch_mg_fine(h, 1, xa, r, mg.d.p, xb, c1, c2, done);
+    std::swap(xa, xb);
+  }
+  gl_launch_mg_fine(h, 0, xa, r, nullptr, mg.res.p, 0.0, 0.0, done);
+  MgLevel& L1 = *mg.lv[0];
+  const GridDev g1 = gdev(L1.g);
+  hipLaunchKernelGGL(k_mg_restrict0<D>, dim3(gridn(g1.nn)), dim3(256), 0, h->st, g1, mg.cell_ptr.p, mg.cell_nodes.p,
+                     mg.wgt.p, mg.res.p, L1.r.p);
+  GL_HIP(hipGetLastError());
+  mg_cycle_cart<D>(h, 0, done);
+  hipLaunchKernelGGL(k_mg_prolong0<D>, dim3(gridn(n)), dim3(256), 0, h->st, g1, n, mg.cell0.p, mg.wgt.p, fx, L1.x.p,
+                     xa, xb);
+  GL_HIP(hipGetLastError());
+  std::swap(xa, xb);
+  Cheb cp(mg.lam0);
+  for (int m = 0; m < deg; ++m) {
+    cp.next(m, &c1, &c2);
+    double* out = m == deg - 1 ? u : xb;   // the last step writes the preconditioned residual where the solver wants it
+    gl_launch_mg_fine(h, 1, xa, r, mg.d.p, out, c1, c2, done);
+    std::swap(xa, xb);
+  }
+  h->stats.mg_cycles++;
+}
+
+}  // namespace
+
+void gl_mg_setup(glims_ctx* h) {
+  if (h->dim == 2) mg_setup_t<2>(h);
+  else mg_setup_t<3>(h);
+}
+
+void gl_mg_apply(glims_ctx* h, const double* r, double* u, const int* done) {
+  GL_REQUIRE(h->mg.ready, "multigrid hierarchy not built");
+  if (h->dim == 2) mg_apply_t<2>(h, r, u, done);
+  else mg_apply_t<3>(h, r, u, done);
+}

@@ -19,6 +19,8 @@
 // identical on all ranks.
 #include "glims_internal.h"
 
+#include <omp.h>
+
 #include <atomic>
 #include <cmath>
 #include <cstring>
@@ -73,9 +75,10 @@ __global__ __launch_bounds__(256) void k_cg_init(int64_t n_own, const double* __
                                                   const double* __restrict__ dinv, double* __restrict__ u,
                                                   double* __restrict__ p, double* __restrict__ s,
                                                   double* __restrict__ pv, double* __restrict__ scal,
-                                                  int* __restrict__ done, const PackMap pm) {
+                                                  int* __restrict__ done, const PackMap pm, int ext) {
   if (blockIdx.x == 0 && threadIdx.x < 2 * SC_COUNT + 2) scal[threadIdx.x] = 0.0;
   if (blockIdx.x == 0 && threadIdx.x == 0) *done = 0;
+  if (ext) return;   // external preconditioner (multigrid): u and the (r.u, r.r) partials come from k_dot2 after the cycle
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   double pg = 0.0, pr = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_own; i += stride) {
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256) void k_cg_update(int64_t n_own, const double* 
                                                     double* __restrict__ x, double* __restrict__ r,
                                                     double* __restrict__ u, const double* __restrict__ w,
                                                     const double* __restrict__ dinv, double* __restrict__ pv, int nt,
-                                                    const PackMap pm) {
+                                                    const PackMap pm, int ext) {
   if (*done) return;
   const double gamma = red[0], delta = red[1], rr = red[2];
   const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(256) void k_cg_update(int64_t n_own, const double* 
   }
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   double pg = 0.0, pr = 0.0;   // partials of the NEXT iteration's gamma = r.u and rr = r.r
-  if constexpr (BS == 1) {
+  if (BS == 1 && !ext) {
     // 16 B per lane (two rows per thread): all seven streams are hipMalloc-aligned
     const int64_t n2 = n_own >> 1;
     double2* p2 = reinterpret_cast<double2*>(p);
@@ -230,6 +233,17 @@ __global__ __launch_bounds__(256) void k_cg_update(int64_t n_own, const double* 
       pr += ri * ri;
     }
     block_sum2(pg, pr, pv);
+    return;
+  }
+  if (ext) {   // external preconditioner: p, s, x, r only (u currently holds M^-1 of the old r; the cycle follows)
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_own * BS; j += stride) {
+      const double pi = u[j] + (first ? 0.0 : beta * p[j]);
+      const double si = w[j] + (first ? 0.0 : beta * s[j]);
+      p[j] = pi;
+      s[j] = si;
+      x[j] += alpha * pi;
+      r[j] -= alpha * si;
+    }
     return;
   }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_own; i += stride) {
@@ -535,6 +549,20 @@ __global__ void k_block_dinv(int64_t n_own, const int64_t* __restrict__ slice_pt
   }
 }
 
+// (r.u, r.r) partial pairs per block, the layout k_reduce_cg expects from the vector kernels (external preconditioner)
+__global__ __launch_bounds__(256) void k_dot2(int64_t n, const double* __restrict__ r, const double* __restrict__ u,
+                                               double* __restrict__ pv, const int* __restrict__ done) {
+  if (done && *done) return;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double pg = 0.0, pr = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double ri = r[i];
+    pg += ri * u[i];
+    pr += ri * ri;
+  }
+  block_sum2(pg, pr, pv);
+}
+
 inline unsigned grid_for(int64_t n, int bs = 256, int64_t cap = 256 * 16) {
   int64_t g = (n + bs - 1) / bs;
   if (g < 1) g = 1;
@@ -665,6 +693,44 @@ static double read_red0(glims_ctx* h) {
   return v;
 }
 
+double gl_dot(glims_ctx* h, const double* a, const double* b, int64_t n, bool global) {
+  const unsigned gd = grid_for(n, 256, 1024);
+  hipLaunchKernelGGL(k_dot_partials, dim3(gd), dim3(256), 0, h->st, n, a, b, h->partials.p);
+  if (global) {
+    reduce_partials(h, (int)gd, 1, nullptr);
+    allreduce_sum(h, h->red.p, 1);
+  } else {   // rank-local value: no node-mailbox / RCCL step in the final block
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, (int)gd, 1, h->partials.p, h->red.p, (const int*)nullptr,
+                       NodeMail());
+    GL_HIP(hipGetLastError());
+  }
+  return read_red0(h);
+}
+
+// inverse diagonal blocks of the constrained K_el (block-Jacobi preconditioner; level-0 smoother of the multigrid)
+void gl_block_dinv(glims_ctx* h) {
+  const DevPattern& p = h->pat;
+  const uint8_t* fx = h->have_fixed_u ? h->fixed_u.p : nullptr;
+  if (h->dim == 2)
+    hipLaunchKernelGGL(k_block_dinv<2>, dim3(grid_exact(h->n_own)), dim3(256), 0, h->st, h->n_own, p.slice_ptr.p,
+                       p.diag_k.p, h->vKel.p, fx, h->m_dinv.p);
+  else
+    hipLaunchKernelGGL(k_block_dinv<3>, dim3(grid_exact(h->n_own)), dim3(256), 0, h->st, h->n_own, p.slice_ptr.p,
+                       p.diag_k.p, h->vKel.p, fx, h->m_dinv.p);
+  GL_HIP(hipGetLastError());
+}
+
+// c = Dirichlet value on the constrained nodes (owned and ghost alike: every rank lists the constrained nodes of its
+// whole sub-mesh), then the state-dependent caches are stale
+void gl_apply_dirichlet_c(glims_ctx* h) {
+  if (!h->have_fixed_c || !h->fixed_c_val.p || !h->have_state) return;
+  hipLaunchKernelGGL(k_mask_assign, dim3(grid_exact(h->n_nodes)), dim3(256), 0, h->st, h->n_nodes, h->c.p,
+                     h->fixed_c.p, (const double*)h->fixed_c_val.p);
+  GL_HIP(hipGetLastError());
+  h->pending = false;
+  h->have_c_old = false;
+}
+
 // ===================================================================================================
 // single-reduction PCG.  On entry: r = residual of the current x (owned rows), x = current iterate.
 // ===================================================================================================
@@ -676,6 +742,7 @@ struct CgVecs {
   int bs;
   bool k32 = false;         // block operator: stream the single-precision copy of K_el
   const float* vals32 = nullptr;   // scalar operator in single precision (optional; streamed instead of vals)
+  bool mg = false;          // u = V-cycle(r) (elasticity multigrid) instead of the (block-)Jacobi scaling
 };
 
 static void apply_with_halo(glims_ctx* h, const CgVecs& v) {
@@ -693,7 +760,7 @@ static void apply_with_halo(glims_ctx* h, const CgVecs& v) {
     return;
   }
   // interior slices overlap with the xGMI transfer; boundary slices run once the ghosts have landed
-  halo_start(h, v.u, v.bs, /*prepacked=*/h->tune_fused_pack != 0);
+  halo_start(h, v.u, v.bs, /*prepacked=*/h->tune_fused_pack != 0 && !v.mg);
   const int nbi = p.n_interior > 0 ? gl_spmv_grid(p.n_interior) : 0;   // partial-sum slots of the interior launch
   if (v.vals)
     gl_launch_spmv(h, h->st, p.n_interior, p.interior_slices.p, v.vals, v.u, v.w, v.fixed, nullptr, v.r,
@@ -742,7 +809,16 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
     pm.slot = h->send_slot.p;
     pm.sendbuf = h->sendbuf.p;
   }
-  GL_VEC(k_cg_init, n, v.r, v.dinv, v.u, v.p, v.s, h->partials_v.p, h->scal.p, h->done.p, pm);
+  const int ext = v.mg ? 1 : 0;
+  if (ext) pm = PackMap();   // the cycle's last kernel produces u: the halo payload is packed by k_pack
+  auto precondition = [&]() {
+    if (!ext) return;
+    gl_mg_apply(h, v.r, v.u, h->done.p);
+    hipLaunchKernelGGL(k_dot2, dim3(g), dim3(256), 0, h->st, n * v.bs, v.r, v.u, h->partials_v.p, h->done.p);
+    GL_HIP(hipGetLastError());
+  };
+  GL_VEC(k_cg_init, n, v.r, v.dinv, v.u, v.p, v.s, h->partials_v.p, h->scal.p, h->done.p, pm, ext);
+  precondition();
   int done = 0;
   double info[2] = {0.0, 0.0};
   const int batch = h->opt.check_every > 0 ? h->opt.check_every : 8;
@@ -771,7 +847,8 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
                          h->done.p, h->nm);
       allreduce_sum(h, h->red.p, 3);
       GL_VEC(k_cg_update, n, h->red.p, prev, cur, info_dev, h->done.p, tol2, v.p, v.s, v.x, v.r, v.u, v.w, v.dinv,
-             h->partials_v.p, h->tune_upd_nt, pm);
+             h->partials_v.p, h->tune_upd_nt, pm, ext);
+      precondition();
     }
     enq += nb;
     if (defer && hint > 0) {
@@ -942,7 +1019,8 @@ int gl_step(glims_ctx* h, int n_steps) {
       }
     }
     h->stats.last_newton_res = nr;
-    h->stats.steps++;
+    if (status == GLIMS_OK) h->stats.steps++;
+    else h->stats.failed_steps++;
   }
   GL_HIP(hipEventRecord(h->ev_b, h->st));
   GL_HIP(hipEventSynchronize(h->ev_b));
@@ -1009,14 +1087,14 @@ int gl_solve_mechanics(glims_ctx* h, const double* c_dev) {
   const int bs = h->dim;
   const int64_t nd = h->n_own * bs;
   const uint8_t* fx = h->have_fixed_u ? h->fixed_u.p : nullptr;
-  // block-Jacobi preconditioner of the constrained operator
-  if (bs == 2)
-    hipLaunchKernelGGL(k_block_dinv<2>, dim3(grid_exact(h->n_own)), dim3(256), 0, h->st, h->n_own, p.slice_ptr.p,
-                       p.diag_k.p, h->vKel.p, fx, h->m_dinv.p);
-  else
-    hipLaunchKernelGGL(k_block_dinv<3>, dim3(grid_exact(h->n_own)), dim3(256), 0, h->st, h->n_own, p.slice_ptr.p,
-                       p.diag_k.p, h->vKel.p, fx, h->m_dinv.p);
-  GL_HIP(hipGetLastError());
+  const int mh_depth = std::max(0, std::min((int)glims_ctx::MHIST, h->opt.mech_history));
+  if (h->mh_next >= std::max(1, mh_depth)) h->mh_count = h->mh_next = 0;   // the depth option shrank
+  const double t_wall0 = omp_get_wtime();
+  // preconditioner of the constrained operator: one multigrid V-cycle (built on first use, K_el does not change in
+  // time) or block-Jacobi
+  const bool use_mg = h->opt.mech_precond == GLIMS_PRECOND_MULTIGRID;
+  if (use_mg && !h->mg.ready) gl_mg_setup(h);
+  else gl_block_dinv(h);
   // rhs = G c + f - K u_D, zero on constrained dofs
   gl_apply_G(h, c_dev ? c_dev : h->c.p, h->m_rhs.p);
   if (fx) {
@@ -1036,7 +1114,7 @@ int gl_solve_mechanics(glims_ctx* h, const double* c_dev) {
   // right-hand sides then x ~ sum_k a_k x_k with residual rhs - sum_k a_k rhs_k: least-squares fit over the last
   // (up to 4) solves; the concentration evolves smoothly, the fit removes several decades of the initial residual.
   // Falls back to the previous displacement (the fit with a = e_last) when that is better or the history is empty.
-  if (h->mh_count > 0 && h->mh_depth > 0) {
+  if (h->mh_count > 0 && mh_depth > 0) {
     const int m = h->mh_count;
     // Gram matrix G_kl = (rhs_k, rhs_l) and g_k = (rhs_k, rhs): deterministic reductions, one value at a time
     double G[glims_ctx::MHIST][glims_ctx::MHIST], g[glims_ctx::MHIST];
@@ -1091,7 +1169,7 @@ int gl_solve_mechanics(glims_ctx* h, const double* c_dev) {
         return v;
       };
       double e_last[glims_ctx::MHIST] = {0.0};
-      const int last = (h->mh_next + h->mh_depth - 1) % h->mh_depth;
+      const int last = (h->mh_next + mh_depth - 1) % mh_depth;
       e_last[last] = 1.0;
       bool finite = ok;
       for (int k = 0; k < m; ++k) finite = finite && std::isfinite(a[k]);
@@ -1114,13 +1192,14 @@ int gl_solve_mechanics(glims_ctx* h, const double* c_dev) {
   hipLaunchKernelGGL(k_sub, dim3(grid_exact(nd)), dim3(256), 0, h->st, nd, h->m_r.p, h->m_rhs.p, h->m_w.p, fx);
   GL_HIP(hipGetLastError());
   CgVecs v{h->U.p, h->m_r.p, h->m_u.p, h->m_w.p, h->m_p.p, h->m_s.p, h->m_dinv.p, nullptr, fx, bs};
+  v.mg = use_mg;
   int64_t its = 0;
   double res = 0.0;
   int cs = GLIMS_OK;
   // worth it only where the operator is streamed from HBM: below ~256 MB (Infinity Cache) an iteration is latency
   // bound and the restarts of the refinement loop only add iterations (GLIMS_MECH_MIXED: 0 off, 1 auto, 2 always)
   const bool big = (size_t)p.total_entries * bs * bs * sizeof(double) > ((size_t)256 << 20);
-  const bool mixed = h->vKel32.n != 0 && (h->mech_mixed == 2 || (h->mech_mixed == 1 && big));
+  const bool mixed = h->vKel32.n != 0 && (h->opt.mech_mixed == 2 || (h->opt.mech_mixed == 1 && big));
   if (!mixed) {
     cs = cg_solve(h, v, tol, h->opt.mech_maxit, h->mech_hint, &its, &res);
     h->mech_hint = (int)its;
@@ -1169,19 +1248,20 @@ int gl_solve_mechanics(glims_ctx* h, const double* c_dev) {
   h->stats.mech_cg_its += its;
   h->stats.mech_solves++;
   h->stats.last_mech_res = res;
-  if (cs == GLIMS_OK && h->mh_depth > 0) {   // remember (rhs, free-dof solution) for the next initial guess
+  if (cs == GLIMS_OK && mh_depth > 0) {   // remember (rhs, free-dof solution) for the next initial guess
     const int slot = h->mh_next;
     h->mh_rhs[slot].alloc((size_t)h->n_nodes * bs);
     h->mh_x[slot].alloc((size_t)h->n_nodes * bs);
     GL_HIP(hipMemcpyAsync(h->mh_rhs[slot].p, h->m_rhs.p, (size_t)nd * sizeof(double), hipMemcpyDeviceToDevice, h->st));
     GL_HIP(hipMemcpyAsync(h->mh_x[slot].p, h->U.p, (size_t)nd * sizeof(double), hipMemcpyDeviceToDevice, h->st));
-    h->mh_next = (slot + 1) % h->mh_depth;
-    h->mh_count = std::min(h->mh_count + 1, h->mh_depth);
+    h->mh_next = (slot + 1) % mh_depth;
+    h->mh_count = std::min(h->mh_count + 1, mh_depth);
   }
   if (fx) hipLaunchKernelGGL(k_mask_assign, dim3(grid_exact(nd)), dim3(256), 0, h->st, nd, h->U.p, fx,
                              (const double*)h->m_uD.p);
   gl_halo_exchange(h, h->U.p, bs);
   GL_HIP(hipStreamSynchronize(h->st));
+  h->stats.ms_mech += 1e3 * (omp_get_wtime() - t_wall0);
   return cs;
 }
 

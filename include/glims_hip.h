@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GLIMS_ABI_VERSION 1
+#define GLIMS_ABI_VERSION 2
 
 enum {
   GLIMS_OK = 0,
@@ -62,7 +62,24 @@ typedef struct glims_options {
   int    check_every;     /* Krylov iterations enqueued between host convergence polls when the
                              iteration count cannot be predicted from the previous solve    default 8     */
   int    flags;           /* GLIMS_FLAG_*                                                   default WARM_START */
+  /* ---- ABI 2: elasticity solver.  The reference gets its robustness for nu -> 0.5 from a sparse LU of the monolithic
+   * system (simulation_tumor_growth.py:126-130) and names AMG as the alternative
+   * (simulation_tumor_growth_brain_quad.py:116-119); here: PCG preconditioned by one multigrid V-cycle. */
+  int    mech_precond;    /* GLIMS_PRECOND_BLOCK_JACOBI | GLIMS_PRECOND_MULTIGRID                default MULTIGRID */
+  int    mech_mixed;      /* inner PCG streams a single-precision copy of K_el under an fp64 iterative-refinement
+                             loop: 0 off, 1 when K_el exceeds the Infinity Cache, 2 always          default 1     */
+  int    mech_history;    /* right-hand sides / solutions of the last k solves kept for the least-squares initial
+                             guess (K_el is linear and time independent), 0..8                      default 6     */
+  int    mg_smooth;       /* Chebyshev degree of the pre- and of the post-smoother on every level
+                             (1 = damped block-Jacobi)                                             default 2     */
+  int    mg_coarse_nodes; /* coarsen until a grid has at most this many nodes; that level is solved with a dense
+                             inverse computed once on the host                                      default 216   */
+  double mg_h_factor;     /* spacing of the first auxiliary Cartesian grid in units of the mesh width
+                             (lattice meshes: of the lattice constant per axis)                    default 2.0   */
 } glims_options;
+
+#define GLIMS_PRECOND_BLOCK_JACOBI 0
+#define GLIMS_PRECOND_MULTIGRID 1
 
 #define GLIMS_FLAG_EXTRAPOLATE_GUESS 1  /* Newton guess c^n + (c^n - c^{n-1}) instead of c^n (reference: c^n) */
 #define GLIMS_FLAG_FP32_JACOBIAN 4       /* OFF by default.  The Newton Jacobian A(c) is stored and streamed in single
@@ -91,6 +108,14 @@ typedef struct glims_stats {
   int64_t nnz_idx16;        /* stored entries whose column is streamed as a 16-bit (window, offset) code */
   double  ms_spmv_steps;    /* GLIMS_TIME_SPMV=1 only: HIP-event time of the Krylov SpMV launches inside glims_step */
   int64_t n_spmv_steps;     /*   ... and how many of them really ran (launches skipped behind the decision word excluded) */
+  /* ---- ABI 2 */
+  int64_t failed_steps;     /* time steps whose Newton / Krylov solve gave up (not counted in `steps`) */
+  int64_t mg_levels;        /* levels of the elasticity multigrid hierarchy incl. the mesh itself (0 = not built) */
+  int64_t mg_cycles;        /* V-cycles applied */
+  double  mg_complexity;    /* stored operator entries of all levels / entries of K_el */
+  double  ms_mg_setup;      /* wall time of the last hierarchy set-up (transfer lists, Galerkin products, eigenvalue
+                               estimates, coarse inverse) */
+  double  ms_mech;          /* wall time spent in elasticity solves */
 } glims_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------------------- */
@@ -121,8 +146,9 @@ int glims_set_options(glims_ctx* h, const glims_options* opt);
 
 /* Dirichlet data (fenics.DirichletBC lists built at helper_classes.py:632-723).  n == 0 clears. */
 int glims_set_dirichlet_u(glims_ctx* h, int64_t n, const int64_t* dof_ids, const double* values);
-/* Concentration: the listed nodes keep the value they have in the state passed to glims_set_state (write the
- * Dirichlet data into c there); `values` documents them and is checked for presence only. */
+/* Concentration: the listed nodes are held at `values`.  The values are written into the state at once when a state
+ * is present (time-dependent data: call again before the next glims_step, as BoundaryConditions.time_update_bcs does
+ * for every step, helper_classes.py:839-859) and again by every later glims_set_state. */
 int glims_set_dirichlet_c(glims_ctx* h, int64_t n, const int64_t* node_ids, const double* values);
 
 /* Load vectors already integrated by the host (NULL clears):
@@ -144,7 +170,9 @@ int glims_setup(glims_ctx* h, int with_mechanics);
 int glims_set_state(glims_ctx* h, const double* c, const double* u);
 int glims_get_state(glims_ctx* h, double* c, double* u);   /* either may be NULL */
 
-/* n_steps backward-Euler steps of the concentration equation, entirely on the device
+/* `steps` counts converged steps only; a step whose solve gave up is counted in `failed_steps`, ends the call with
+ * GLIMS_NOT_CONVERGED / GLIMS_NAN and leaves the iterate where the solver stopped (reference: simulation_base.py:301-305).
+ * n_steps backward-Euler steps of the concentration equation, entirely on the device
  * (the `while` loop body solver.solve() + u_previous.assign, simulation_base.py:297-312, for the F_rd block). */
 int glims_step(glims_ctx* h, int n_steps);
 

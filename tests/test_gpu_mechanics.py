@@ -1,0 +1,250 @@
+"""
+GPU tests of the elasticity block (F_m, simulation_tumor_growth.py:110-113) and of BASELINE config C5 (coupled model,
+4 DoF per node): the multigrid-preconditioned PCG against the CPU oracle's sparse LU, against the block-Jacobi path,
+and -- at C5's full size -- through oracle-free properties.  All through the C-ABI.
+"""
+import numpy as np
+import pytest
+
+from glimslib_amd import workloads
+from glimslib_amd.mesh import BoxMesh, RectangleMesh
+from oracle.glims_oracle import OracleTumorGrowth, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _c5_reduced(n):
+    """C5 on a coarser box: the seed of the full-size config (a Gaussian of width 1 mm) falls between the nodes of a
+    coarse mesh, so the reduced cases start from one that spans a few cells."""
+    w = workloads.config_c5(n)
+    hx = 240.0 / n
+    w.c0 = np.exp(-((w.mesh.points - np.array([118.0, -109.0, 72.0])) ** 2).sum(axis=1) / (2.0 * (2.5 * hx) ** 2))
+    return w
+
+
+def _c5_handle(backend, w, **opts):
+    h = backend.Handle(w.mesh.points, w.mesh.cells, w.cell_label)
+    t = w.tables
+    h.set_materials(t['D'], t['rho'], t['gamma'], t['E'], t['nu'])
+    h.set_options(dt=w.dt, **opts)
+    d = w.mesh.points.shape[1]
+    dofs = (np.asarray(w.dirichlet_nodes)[:, None] * d + np.arange(d)).ravel()
+    h.set_dirichlet_u(dofs, np.zeros(len(dofs)))
+    h.setup(True)
+    h.set_state(w.c0)
+    return h, dofs
+
+
+def _c5_oracle(w, dofs):
+    return OracleTumorGrowth(w.mesh.points, w.mesh.cells, w.per_cell('D'), w.per_cell('rho'), w.per_cell('gamma'),
+                             w.per_cell('E'), w.per_cell('nu'), w.dt, dirichlet_u=(dofs, np.zeros(len(dofs))))
+
+
+def _free_residual(h, c, u, dofs):
+    """|| (K u - G c) on the free dofs || / || G c ||, through the operator hooks (no oracle)."""
+    Ku = h.apply(3, u)[0]
+    Gc = h.apply(4, c)[0]
+    r = Ku - Gc
+    r[dofs] = 0.0
+    g = Gc.copy()
+    g[dofs] = 0.0
+    return np.linalg.norm(r) / np.linalg.norm(g)
+
+
+@pytest.mark.parametrize("n,monolithic,steps", [(24, False, 3), (14, True, 3)])
+def test_config_c5_reduced_matches_the_oracle(backend, n, monolithic, steps):
+    """C5 (brain-extent box, WM ellipsoid in GM, u = 0 on the hull) at a size the sparse-LU oracle finishes in seconds:
+    split loop (n = 24, 62 500 unknowns) and the reference's monolithic Newton (n = 14)."""
+    w = _c5_reduced(n)
+    h, dofs = _c5_handle(backend, w)
+    o = _c5_oracle(w, dofs)
+    uo, co = o.run(w.c0, steps * w.dt, monolithic=monolithic)
+    assert h.step(steps) == 0 and h.solve_mechanics() == 0
+    c, u = h.get_state()
+    st = h.stats()
+    print("C5 n=%d (%s): c %.2e, u %.2e, %d PCG its, %d multigrid levels" %
+          (n, "monolithic" if monolithic else "split", rel_l2(c, co), rel_l2(u, uo), st['mech_cg_its'], st['mg_levels']))
+    assert rel_l2(c, co) < 1e-9 and rel_l2(u, uo) < 1e-8
+    assert st['mg_levels'] >= 3 and st['mg_cycles'] > 0
+    h.close()
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+@pytest.mark.parametrize("smooth", [1, 2, 3])
+def test_multigrid_and_block_jacobi_give_the_same_displacement(backend, dim, smooth):
+    """Inhomogeneous Dirichlet data on part of the boundary, two tissues with different stiffness and Poisson ratio,
+    body load: both preconditioners against the oracle's LU; the multigrid one needs far fewer iterations."""
+    if dim == 3:
+        mesh = BoxMesh((0, 0, 0), (10.0, 9.0, 8.0), 20, 18, 16)
+    else:
+        mesh = RectangleMesh((-5, -5), (5, 5), 60, 52)
+    mid = mesh.cell_midpoints()
+    lab = (1 + (mid[:, 0] > mesh.points[:, 0].mean())).astype(np.int32)
+    tabs = dict(D=[0, .1, .02], rho=[0, .1, .05], gamma=[0, .2, .1], E=[1.0, 1e-3, 3e-3], nu=[.3, .40, .45])
+    f = mesh.facets()
+    bn = np.unique(f['vertices'][f['exterior']])
+    bn = bn[mesh.points[bn, 0] < mesh.points[:, 0].mean()]          # clamp only the left half of the hull
+    dofs = (bn[:, None] * dim + np.arange(dim)).ravel()
+    vals = 1e-3 * np.cos(np.arange(len(dofs)))
+    rng = np.random.default_rng(dim)
+    mload = 1e-6 * rng.standard_normal(mesh.num_vertices() * dim)
+    c0 = np.exp(-0.2 * ((mesh.points - mesh.points.mean(0)) ** 2).sum(1))
+    per = {k: np.asarray(v)[lab] for k, v in tabs.items()}
+    o = OracleTumorGrowth(mesh.points, mesh.cells, per['D'], per['rho'], per['gamma'], per['E'], per['nu'], 1.0,
+                          dirichlet_u=(dofs, vals), mech_load=mload)
+    uo = o.mech_solve(c0)
+    out = {}
+    for pre in (backend.PRECOND_MULTIGRID, backend.PRECOND_BLOCK_JACOBI):
+        h = backend.Handle(mesh.points, mesh.cells, lab)
+        h.set_materials(tabs['D'], tabs['rho'], tabs['gamma'], tabs['E'], tabs['nu'])
+        h.set_options(dt=1.0, mech_precond=pre, mg_smooth=smooth, mech_mixed=0)
+        h.set_dirichlet_u(dofs, vals)
+        h.set_mech_load(mload)
+        h.setup(True)
+        h.set_state(c0)
+        assert h.solve_mechanics() == 0
+        out[pre] = (h.get_state()[1], h.stats()['mech_cg_its'])
+        h.close()
+    (um, im), (ub, ib) = out[backend.PRECOND_MULTIGRID], out[backend.PRECOND_BLOCK_JACOBI]
+    print("dim %d, Chebyshev degree %d: multigrid %d its, block-Jacobi %d its" % (dim, smooth, im, ib))
+    assert rel_l2(um, uo) < 1e-8 and rel_l2(ub, uo) < 1e-8
+    assert np.array_equal(um.reshape(-1)[dofs], vals)
+    assert im < 0.5 * ib
+
+
+def test_multigrid_iteration_count_does_not_grow_with_the_mesh(backend):
+    """C5 at n = 16 / 24 / 32 / 48 from a zero guess to rtol 1e-10: mesh-independent iteration count (block-Jacobi:
+    168 / 251 / 329 / ...), answers equal to the block-Jacobi path."""
+    its = []
+    for n in (16, 24, 32, 48):
+        w = _c5_reduced(n)
+        h, dofs = _c5_handle(backend, w, mech_history=0)
+        assert h.solve_mechanics() == 0
+        c, u = h.get_state()
+        its.append(h.stats()['mech_cg_its'])
+        assert _free_residual(h, c, u, dofs) < 1e-9
+        h.close()
+    print("multigrid PCG iterations at n = 16, 24, 32, 48:", its)
+    assert max(its) <= 60 and its[-1] <= its[0] + 8
+
+
+def test_multigrid_on_an_unstructured_mesh_and_a_misaligned_lattice(backend):
+    """General meshes take the 125-point coarse stencils: a Delaunay mesh (volumes over three decades) and a box mesh
+    whose nodes were jittered off the lattice; both against the oracle."""
+    w = workloads.config_unstructured(4000, mechanics=True)
+    h, dofs = _c5_handle(backend, w, mech_history=0)
+    o = _c5_oracle(w, dofs)
+    assert h.solve_mechanics() == 0
+    st = h.stats()
+    print("Delaunay mesh: %d its, %d levels, operator complexity %.2f" % (st['mech_cg_its'], st['mg_levels'], st['mg_complexity']))
+    assert rel_l2(h.get_state()[1], o.mech_solve(w.c0)) < 1e-6       # slivers: ill-conditioned K_el, PCG at rtol 1e-10
+    assert st['mech_cg_its'] < 200
+    h.close()
+    mesh = BoxMesh((0, 0, 0), (1.0, 1.2, 0.9), 18, 16, 14)
+    rng = np.random.default_rng(3)
+    hmin = np.array([1.0 / 18, 1.2 / 16, 0.9 / 14])
+    f = mesh.facets()
+    bn = np.unique(f['vertices'][f['exterior']])
+    interior = np.ones(mesh.num_vertices(), bool)
+    interior[bn] = False
+    mesh.points[interior] += 0.2 * hmin * (rng.random((interior.sum(), 3)) - 0.5)
+    w2 = workloads.Workload("jittered box", mesh, np.ones(mesh.num_cells(), np.int32),
+                            dict(D=[0, .1], rho=[0, .1], gamma=[0, .2], E=[1.0, 2e-3], nu=[.3, .42]),
+                            np.exp(-6 * ((mesh.points - 0.5) ** 2).sum(1)), 1.0, 1, True, bn)
+    h, dofs = _c5_handle(backend, w2, mech_history=0)
+    o = _c5_oracle(w2, dofs)
+    assert h.solve_mechanics() == 0
+    st = h.stats()
+    print("jittered box: %d its, complexity %.2f" % (st['mech_cg_its'], st['mg_complexity']))
+    assert rel_l2(h.get_state()[1], o.mech_solve(w2.c0)) < 1e-8
+    assert st['mech_cg_its'] <= 70
+    h.close()
+
+
+def test_unclamped_body_and_single_pinned_node(backend):
+    """No Dirichlet data at all (reference quirk q3: every level then has the rigid-body modes in its kernel) and
+    the minimal set of pins: the multigrid path must still converge; strains equal the oracle's."""
+    mesh = BoxMesh((0, 0, 0), (4.0, 3.0, 2.0), 12, 10, 8)
+    lab = np.ones(mesh.num_cells(), np.int32)
+    tabs = dict(D=[0, .1], rho=[0, .1], gamma=[0, .15], E=[1.0, 2e-3], nu=[.3, .4])
+    n = mesh.num_vertices()
+    # pins that remove exactly the rigid-body motions: node 0 fully, its x-neighbour in y and z, its y-neighbour in z
+    i0 = 0
+    ix = int(np.flatnonzero((mesh.points[:, 1] == 0) & (mesh.points[:, 2] == 0) & (mesh.points[:, 0] > 0))[0])
+    iy = int(np.flatnonzero((mesh.points[:, 0] == 0) & (mesh.points[:, 2] == 0) & (mesh.points[:, 1] > 0))[0])
+    dofs = np.array([3 * i0, 3 * i0 + 1, 3 * i0 + 2, 3 * ix + 1, 3 * ix + 2, 3 * iy + 2])
+    c_uni = np.full(n, 0.6)
+    h = backend.Handle(mesh.points, mesh.cells, lab)
+    h.set_materials(tabs['D'], tabs['rho'], tabs['gamma'], tabs['E'], tabs['nu'])
+    h.set_options(dt=1.0)
+    h.set_dirichlet_u(dofs, np.zeros(6))
+    h.setup(True)
+    h.set_state(c_uni)
+    assert h.solve_mechanics() == 0
+    u = h.get_state()[1].reshape(-1, 3)
+    # K4: stress-free growth u = gamma c (x - x0)
+    assert np.abs(u - 0.15 * 0.6 * (mesh.points - mesh.points[i0])).max() < 1e-8
+    h.close()
+
+
+def test_config_c5_full_size_properties(backend):
+    """BASELINE config C5 at FULL size (n = 99: 1 000 000 nodes, 4 000 000 unknowns).  Concentration against the C
+    oracle; displacement through oracle-free checks: the residual of K_el u = G c on the free dofs through the operator
+    hooks, symmetry of the K_el hook, equality of the mixed-precision and the all-fp64 solve and of the multigrid and
+    the block-Jacobi solve, K4 (u = gamma c (x - x0) for a uniform field with rigid-motion pins), iteration count."""
+    from oracle.c_port import COracle
+    w = workloads.config_c5()
+    n = w.mesh.num_vertices()
+    co = COracle(w.mesh.points, w.mesh.cells, w.per_cell('D'), w.per_cell('rho'), w.dt)
+    ref = co.step(w.c0, 2, rtol=1e-11, cg_rtol=1e-4)
+    co.close()
+    h, dofs = _c5_handle(backend, w)
+    assert h.step(2) == 0 and h.solve_mechanics() == 0
+    c, u = h.get_state()
+    st = h.stats()
+    its_mg = st['mech_cg_its']
+    print("C5 full size: c vs C oracle %.2e; multigrid PCG %d its, %d levels, complexity %.2f, set-up %.0f ms, solve %.0f ms"
+          % (rel_l2(c, ref), its_mg, st['mg_levels'], st['mg_complexity'], st['ms_mg_setup'], st['ms_mech']))
+    assert rel_l2(c, ref) < 1e-9
+    assert its_mg <= 60
+    assert _free_residual(h, c, u, dofs) < 5e-10
+    assert np.all(u[dofs] == 0.0) and np.isfinite(u).all() and np.abs(u).max() > 0
+    rng = np.random.default_rng(7)
+    x, y = rng.standard_normal(3 * n), rng.standard_normal(3 * n)
+    Kx, Ky = h.apply(3, x)[0], h.apply(3, y)[0]
+    assert abs(x @ Ky - y @ Kx) < 1e-11 * abs(x @ Ky)
+    h.close()
+    # all-fp64 inner solve and block-Jacobi preconditioner: same displacement
+    h2, _ = _c5_handle(backend, w, mech_mixed=0)
+    h2.set_state(c)
+    assert h2.solve_mechanics() == 0
+    assert rel_l2(h2.get_state()[1], u) < 1e-8
+    h2.close()
+    h3, _ = _c5_handle(backend, w, mech_precond=backend.PRECOND_BLOCK_JACOBI)
+    h3.set_state(c)
+    assert h3.solve_mechanics() == 0
+    its_bj = h3.stats()['mech_cg_its']
+    assert rel_l2(h3.get_state()[1], u) < 1e-8
+    h3.close()
+    print("C5 full size: block-Jacobi PCG %d its" % its_bj)
+    assert its_mg < 0.2 * its_bj
+    # K4 at full size: uniform materials (C5's two tissues share E, nu, gamma), uniform c, rigid-motion pins only
+    pts = w.mesh.points
+    i0 = 0
+    ix = int(np.flatnonzero((pts[:, 1] == pts[i0, 1]) & (pts[:, 2] == pts[i0, 2]) & (pts[:, 0] > pts[i0, 0]))[0])
+    iy = int(np.flatnonzero((pts[:, 0] == pts[i0, 0]) & (pts[:, 2] == pts[i0, 2]) & (pts[:, 1] > pts[i0, 1]))[0])
+    pins = np.array([3 * i0, 3 * i0 + 1, 3 * i0 + 2, 3 * ix + 1, 3 * ix + 2, 3 * iy + 2])
+    h4 = backend.Handle(pts, w.mesh.cells, w.cell_label)
+    t = w.tables
+    h4.set_materials(t['D'], t['rho'], t['gamma'], t['E'], t['nu'])
+    h4.set_options(dt=w.dt)
+    h4.set_dirichlet_u(pins, np.zeros(6))
+    h4.setup(True)
+    h4.set_state(np.full(n, 0.5))
+    assert h4.solve_mechanics() == 0
+    uk = h4.get_state()[1].reshape(-1, 3)
+    exact = 0.1 * 0.5 * (pts - pts[i0])
+    print("K4 at full size: %d its, max error %.2e of max |u| %.2e" %
+          (h4.stats()['mech_cg_its'], np.abs(uk - exact).max(), np.abs(exact).max()))
+    assert np.abs(uk - exact).max() < 1e-7 * np.abs(exact).max()
+    h4.close()

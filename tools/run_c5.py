@@ -1,27 +1,37 @@
 #!/usr/bin/env python3
-"""Config C5 (coupled model on the brain-extent box): time the displacement solve at recorded steps."""
+"""Config C5 (coupled model on the brain-extent box): elasticity solve after every RD step, per preconditioner.
+    python tools/run_c5.py [n] [steps]      env: PRECOND=mg|bj  SMOOTH=k  MIXED=0|1|2  HIST=k  MECH_RTOL"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from glimslib_amd import workloads
+from glimslib_amd import _backend
 from glimslib_amd._backend import Handle
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 99
-w = workloads.config_c5(n)
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+w = workloads.config_c5(n) if n < 100000 else workloads.config_unstructured(n, mechanics=True)
 t0 = time.perf_counter()
 h = Handle(w.mesh.points, w.mesh.cells, w.cell_label)
 t = w.tables
 h.set_materials(t['D'], t['rho'], t['gamma'], t['E'], t['nu'])
-h.set_options(dt=w.dt, mech_rtol=float(os.environ.get("MECH_RTOL", "1e-8")))
+pre = _backend.PRECOND_BLOCK_JACOBI if os.environ.get("PRECOND", "mg") == "bj" else _backend.PRECOND_MULTIGRID
+h.set_options(dt=w.dt, mech_rtol=float(os.environ.get("MECH_RTOL", "1e-10")), mech_precond=pre,
+              mg_smooth=int(os.environ.get("SMOOTH", "2")), mech_mixed=int(os.environ.get("MIXED", "1")),
+              mech_history=int(os.environ.get("HIST", "6")), mg_h_factor=float(os.environ.get("HFAC", "2.0")))
 dofs = (w.dirichlet_nodes[:, None] * 3 + np.arange(3)).ravel()
 h.set_dirichlet_u(dofs, np.zeros(len(dofs)))
 h.setup(True)
 h.set_state(w.c0)
-print("setup %.1f s, %d nodes" % (time.perf_counter() - t0, h.n_nodes), flush=True)
-for rec in range(3):
-    t0 = time.perf_counter(); st = h.step(10); t1 = time.perf_counter()
+print("setup %.1f s, %d nodes, precond %s" % (time.perf_counter() - t0, h.n_nodes, "mg" if pre else "bj"), flush=True)
+prev = 0
+for rec in range(steps):
+    t0 = time.perf_counter(); st = h.step(1); t1 = time.perf_counter()
     sm = h.solve_mechanics(); t2 = time.perf_counter()
     s = h.stats()
-    print("record %d: 10 RD steps %.3f s (status %d), mechanics %.3f s (status %d), mech its so far %d, res %.2e" %
-          (rec, t1 - t0, st, t2 - t1, sm, s['mech_cg_its'], s['last_mech_res']), flush=True)
+    print("step %d: RD %.2f ms (status %d), mechanics %.2f ms (status %d), %d PCG its, res %.2e%s" %
+          (rec, 1e3 * (t1 - t0), st, 1e3 * (t2 - t1), sm, s['mech_cg_its'] - prev, s['last_mech_res'],
+           "  [mg set-up %.0f ms, %d levels, complexity %.2f]" % (s['ms_mg_setup'], s['mg_levels'], s['mg_complexity'])
+           if rec == 0 and pre else ""), flush=True)
+    prev = s['mech_cg_its']
 c, u = h.get_state()
 print("max |u| = %.3e, max c = %.3f" % (np.abs(u).max(), c.max()))
