@@ -20,6 +20,7 @@ GLIMS_UNIQUE_ID_BYTES = 256
 FLAG_EXTRAPOLATE_GUESS = 1
 FLAG_WARM_START = 2
 FLAG_FP32_JACOBIAN = 4
+FLAG_MG_FP32_SMOOTHER = 8
 PRECOND_BLOCK_JACOBI, PRECOND_MULTIGRID = 0, 1
 ABI_VERSION = 2
 

@@ -170,6 +170,8 @@ struct MgHierarchy {
   dvec<int32_t> cell_ptr, cell_nodes;      // mesh nodes sorted by level-1 cell (children lists of the grid nodes)
   dvec<double> x, x2, d, res;              // level-0 work vectors [n_nodes*bs] (ghost slots stay zero)
   double lam0 = 1.0;
+  bool half_smoother = true;               // level-0 smoother streams the half-precision copy of K_el
+  double half_unscale = 1.0;               // K_el = half_unscale * (half copy)
   std::vector<MgLevel*> lv;                // owned
   dvec<double> coarse_inv;                 // dense inverse of the coarsest operator [nc][nc], nc = lv.back()->g.nn * bs
   int64_t entries = 0;                     // stored operator entries of the coarse levels (scalars)
@@ -245,6 +247,7 @@ struct glims_ctx {
   bool pair_A = false;                     // vA / vA32 and cols16p use the slot-pair layout (GLIMS_PAIR_A, needs 16-bit codes everywhere)
   int tune_pair_A = 1;
   dvec<float> vKel32;                      // single-precision copy of K_el (inner solves of the elasticity solver)
+  dvec<uint16_t> vKel16;                   // scaled half-precision copy (bit pattern of _Float16): level-0 multigrid smoother
   // vectors (internal numbering; length n_nodes unless noted)
   dvec<double> c, c_old, b, load_rd, dinv;
   dvec<double> cg_p, cg_s, cg_u, cg_w, cg_r, cg_r2, b2;     // scalar CG work vectors; r2/b2: speculative next step
@@ -255,6 +258,7 @@ struct glims_ctx {
   static constexpr int MHIST = 8;   // GLIMS_MHIST <= 8 limits the depth actually used
   dvec<double> mh_rhs[MHIST], mh_x[MHIST];
   int mh_count = 0, mh_next = 0;           // depth: glims_options.mech_history
+  double mh_G[MHIST][MHIST] = {{0.0}};     // Gram matrix (rhs_k, rhs_l) of the stored right-hand sides (host copy)
   bool have_c_old = false;                                    // c_old holds the state at the start of the previous step
   bool pending = false;                                      // cg_r / b / vA already hold the first assembly of the next step
   double pending_r0 = 0.0;
@@ -330,6 +334,7 @@ void gl_block_dinv(glims_ctx* h);                                            // 
 // mg.hip --------------------------------------------------------------------------------------------
 void gl_mesh_metrics(glims_ctx* h, const HostPattern& hp, const double* xyz_old);
 void gl_mg_setup(glims_ctx* h);
+void gl_make_half_copy(glims_ctx* h);
 void gl_mg_apply(glims_ctx* h, const double* r, double* u, const int* done = nullptr);   // u = V-cycle(r); r zero on constrained dofs
 // level-0 operator pass of the multigrid (kernels.hip): mode 0 out = r - A x, 1 Chebyshev step, 2 out = Dinv A x
 void gl_launch_mg_fine(glims_ctx* h, int mode, const double* xin, const double* r, double* d, double* xout, double c1,

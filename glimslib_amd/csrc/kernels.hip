@@ -9,6 +9,7 @@
 #include "glims_internal.h"
 
 #include <algorithm>
+#include <cmath>
 
 namespace {
 
@@ -770,10 +771,13 @@ __global__ __launch_bounds__(256) void k_spmv_block2(int n_launch, int chunk, co
 // direction and the new iterate cost no extra pass over the vectors.  Constrained dofs: rows masked here, columns see
 // x = 0 there (the iterates are zero on constrained dofs by construction).  xout must not alias xin.
 //   MODE 0: xout = r - A xin          MODE 1: d = c1 d + c2 Dinv (r - A xin), xout = xin + d          MODE 2: xout = Dinv A xin
-template <int BS, int MODE, int KB>
+template <int BS, int MODE, int KB, class VT, int CIDX>
 __global__ __launch_bounds__(256) void k_mg_fine(int n_launch, int chunk, int64_t n_own,
                                                   const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ cols,
-                                                  const float* __restrict__ vals, const double* __restrict__ dinv,
+                                                  const uint16_t* __restrict__ cols16,
+                                                  const int32_t* __restrict__ win_base,
+                                                  const VT* __restrict__ vals, double vscale,
+                                                  const double* __restrict__ dinv,
                                                   const uint8_t* __restrict__ fixed, const double* __restrict__ xin,
                                                   const double* __restrict__ r, double* __restrict__ d,
                                                   double* __restrict__ xout, double c1, double c2, int remap,
@@ -788,7 +792,9 @@ __global__ __launch_bounds__(256) void k_mg_fine(int n_launch, int chunk, int64_
     const int64_t base = slice_ptr[s];
     const int len = (int)((slice_ptr[s + 1] - base) >> 6);
     const int32_t* cc = cols + base + lane;
-    const float* vb = vals + base * B2 + lane;
+    const uint16_t* c16 = cols16 + base + lane;
+    const int32_t wb = CIDX ? win_base[(int64_t)s * GL_N_WIN + (lane & (GL_N_WIN - 1))] : 0;
+    const VT* vb = vals + base * B2 + lane;
     double acc[BS];
 #pragma unroll
     for (int a = 0; a < BS; ++a) acc[a] = 0.0;
@@ -796,12 +802,20 @@ __global__ __launch_bounds__(256) void k_mg_fine(int n_launch, int chunk, int64_
       int32_t cj[KB];
       double v[KB][B2], xj[KB][BS];
 #pragma unroll
-      for (int j = 0; j < KB; ++j) cj[j] = __builtin_nontemporal_load(cc + (int64_t)min(k + j, len - 1) * GL_WAVE);
+      for (int j = 0; j < KB; ++j) {
+        const int64_t kk = (int64_t)min(k + j, len - 1) * GL_WAVE;
+        if (CIDX) cj[j] = (int32_t)__builtin_nontemporal_load(c16 + kk);
+        else cj[j] = __builtin_nontemporal_load(cc + kk);
+      }
 #pragma unroll
       for (int j = 0; j < KB; ++j) {
-        const float* vk = vb + (int64_t)min(k + j, len - 1) * (GL_WAVE * B2);
+        const VT* vk = vb + (int64_t)min(k + j, len - 1) * (GL_WAVE * B2);
 #pragma unroll
-        for (int e = 0; e < B2; ++e) v[j][e] = (double)__builtin_nontemporal_load(vk + e * GL_WAVE);
+        for (int e = 0; e < B2; ++e) v[j][e] = (double)(float)__builtin_nontemporal_load(vk + e * GL_WAVE);
+      }
+      if (CIDX) {
+#pragma unroll
+        for (int j = 0; j < KB; ++j) cj[j] = decode_col((uint32_t)cj[j], wb);
       }
 #pragma unroll
       for (int j = 0; j < KB; ++j)
@@ -819,8 +833,8 @@ __global__ __launch_bounds__(256) void k_mg_fine(int n_launch, int chunk, int64_
 #pragma unroll
     for (int a = 0; a < BS; ++a) {
       const bool fx = fixed && fixed[row * BS + a];
-      if (MODE == 2) t[a] = fx ? 0.0 : acc[a];
-      else t[a] = fx ? 0.0 : r[row * BS + a] - acc[a];
+      if (MODE == 2) t[a] = fx ? 0.0 : vscale * acc[a];
+      else t[a] = fx ? 0.0 : r[row * BS + a] - vscale * acc[a];
     }
     if (MODE == 0) {
 #pragma unroll
@@ -841,6 +855,23 @@ __global__ __launch_bounds__(256) void k_mg_fine(int n_launch, int chunk, int64_
       }
     }
   }
+}
+
+// scaled half-precision copy of an operator plane set (multigrid smoother): out = (half)(in * scale)
+__global__ void k_to_half(int64_t n, const double* __restrict__ a, _Float16* __restrict__ b, double scale) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) b[i] = (_Float16)(float)(a[i] * scale);
+}
+__global__ __launch_bounds__(256) void k_absmax(int64_t n, const double* __restrict__ a, double* __restrict__ out) {
+  __shared__ double sm[4];
+  double v = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) v = fmax(v, fabs(a[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
 }
 
 // y[(row,a)] = sum_k G[(row,a),col_k] c[col_k]
@@ -1214,14 +1245,50 @@ void gl_launch_mg_fine(glims_ctx* h, int mode, const double* xin, const double* 
   const int grid = gl_spmv_grid(p.n_slices);
   const int chunk = (p.n_slices + grid - 1) / grid;
   const uint8_t* fx = h->have_fixed_u ? h->fixed_u.p : nullptr;
+  const bool half = h->vKel16.n != 0 && h->mg.half_smoother;
+  const bool c16 = h->tune_idx16 != 0 && h->stats.nnz_idx16 == h->stats.nnz_padded;   // every slice has 16-bit codes
+#define GL_MGF3(BS, MODE, VT, VPTR, SC, CIDX)                                                                        \
+  hipLaunchKernelGGL((k_mg_fine<BS, MODE, 2, VT, CIDX>), dim3(grid), dim3(256), 0, h->st, p.n_slices, chunk,          \
+                     h->n_own, p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, VPTR, SC, h->m_dinv.p, fx, xin, r, \
+                     d, xout, c1, c2, h->tune_xcd_remap, done)
+#define GL_MGF2(BS, MODE, CIDX)                                                                                      \
+  do {                                                                                                               \
+    if (half) GL_MGF3(BS, MODE, _Float16, (const _Float16*)h->vKel16.p, h->mg.half_unscale, CIDX);                    \
+    else GL_MGF3(BS, MODE, float, h->vKel32.p, 1.0, CIDX);                                                            \
+  } while (0)
 #define GL_MGF(BS, MODE)                                                                                             \
-  hipLaunchKernelGGL((k_mg_fine<BS, MODE, 2>), dim3(grid), dim3(256), 0, h->st, p.n_slices, chunk, h->n_own,          \
-                     p.slice_ptr.p, p.cols.p, h->vKel32.p, h->m_dinv.p, fx, xin, r, d, xout, c1, c2, h->tune_xcd_remap, done)
+  do {                                                                                                               \
+    if (c16) GL_MGF2(BS, MODE, 1); else GL_MGF2(BS, MODE, 0);                                                        \
+  } while (0)
   if (h->dim == 2) {
     if (mode == 0) GL_MGF(2, 0); else if (mode == 1) GL_MGF(2, 1); else GL_MGF(2, 2);
   } else {
     if (mode == 0) GL_MGF(3, 0); else if (mode == 1) GL_MGF(3, 1); else GL_MGF(3, 2);
   }
 #undef GL_MGF
+#undef GL_MGF2
+#undef GL_MGF3
   GL_HIP(hipGetLastError());
+}
+
+// scaled half-precision copy of K_el for the multigrid smoother: entries * (1 / max |entry|), so that the 5-bit
+// exponent of fp16 covers the operator's dynamic range whatever the units of E
+void gl_make_half_copy(glims_ctx* h) {
+  const size_t nk = (size_t)h->pat.total_entries * h->dim * h->dim;
+  dvec<double> part;
+  const int nb = 1024;
+  part.alloc(nb);
+  hipLaunchKernelGGL(k_absmax, dim3(nb), dim3(256), 0, h->st, (int64_t)nk, h->vKel.p, part.p);
+  GL_HIP(hipGetLastError());
+  std::vector<double> hp(nb);
+  GL_HIP(hipMemcpyAsync(hp.data(), part.p, nb * sizeof(double), hipMemcpyDeviceToHost, h->st));
+  GL_HIP(hipStreamSynchronize(h->st));
+  double mx = 0.0;
+  for (double v : hp) mx = std::max(mx, v);
+  if (!(mx > 0.0) || !std::isfinite(mx)) mx = 1.0;
+  h->vKel16.alloc(nk);
+  hipLaunchKernelGGL(k_to_half, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, h->st, (int64_t)nk, h->vKel.p,
+                     (_Float16*)h->vKel16.p, 1.0 / mx);
+  GL_HIP(hipGetLastError());
+  h->mg.half_unscale = mx;
 }

@@ -368,6 +368,74 @@ __global__ __launch_bounds__(256) void k_mg_cart(GridDev g, int R, const float* 
   }
 }
 
+// The same pass for SMALL grids: one wave per node, the stencil offsets dealt to the lanes, then a fixed shuffle tree.
+// A thread per node walks its 27 (125) offsets one after the other -- on a grid of a few thousand nodes that serial
+// chain, not bandwidth, is the whole kernel time (12-18 us per pass at 5^3 .. 26^3 nodes, measured).
+template <int D, int MODE>
+__global__ __launch_bounds__(256) void k_mg_cart_w(GridDev g, int R, int S, const float* __restrict__ A,
+                                                    const double* __restrict__ dinv, const double* __restrict__ xin,
+                                                    const double* __restrict__ r, double* __restrict__ d,
+                                                    double* __restrict__ xout, double c1, double c2,
+                                                    const int* __restrict__ done) {
+  constexpr int BS = D, B2 = D * D;
+  if (done && *done) return;
+  const long long I = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (I >= g.nn) return;
+  const int lane = threadIdx.x & 63;
+  int Iv[3];
+  lin2v(I, g, Iv);
+  double acc[BS];
+#pragma unroll
+  for (int a = 0; a < BS; ++a) acc[a] = 0.0;
+  for (int off = lane; off < S; off += GL_WAVE) {
+    int o[3], nv[3] = {0, 0, 0};
+    off2v<D>(off, R, o);
+    bool in = true;
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      nv[a] = Iv[a] + o[a];
+      in = in && nv[a] >= 0 && nv[a] < gn(g, a);
+    }
+    if (!in) continue;
+    const long long nb = v2lin(nv, g);
+    const float* a0 = A + (long long)off * B2 * g.nn + I;
+    double xb[BS];
+#pragma unroll
+    for (int b = 0; b < BS; ++b) xb[b] = xin[(long long)b * g.nn + nb];
+#pragma unroll
+    for (int a = 0; a < BS; ++a)
+#pragma unroll
+      for (int b = 0; b < BS; ++b) acc[a] += (double)a0[(long long)(a * BS + b) * g.nn] * xb[b];
+  }
+#pragma unroll
+  for (int a = 0; a < BS; ++a) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc[a] += __shfl_down(acc[a], o, 64);
+  }
+  if (lane != 0) return;
+  double t[BS];
+#pragma unroll
+  for (int a = 0; a < BS; ++a) t[a] = MODE == 2 ? acc[a] : r[(long long)a * g.nn + I] - acc[a];
+  if (MODE == 0) {
+#pragma unroll
+    for (int a = 0; a < BS; ++a) xout[(long long)a * g.nn + I] = t[a];
+    return;
+  }
+#pragma unroll
+  for (int a = 0; a < BS; ++a) {
+    double z = 0.0;
+#pragma unroll
+    for (int b = 0; b < BS; ++b) z += dinv[(long long)(a * BS + b) * g.nn + I] * t[b];
+    if (MODE == 2) {
+      xout[(long long)a * g.nn + I] = z;
+    } else {
+      const double dn = (c1 != 0.0 ? c1 * d[(long long)a * g.nn + I] : 0.0) + c2 * z;
+      d[(long long)a * g.nn + I] = dn;
+      xout[(long long)a * g.nn + I] = xin[(long long)a * g.nn + I] + dn;
+    }
+  }
+}
+
 // first smoothing step from a zero iterate: d = c2 Dinv r, x = d   (no operator pass)
 template <int D>
 __global__ void k_mg_first_cart(GridDev g, const double* __restrict__ dinv, const double* __restrict__ r,
@@ -405,30 +473,35 @@ __global__ void k_mg_first_fine(int64_t n_own, const double* __restrict__ dinv, 
   }
 }
 
-// restriction mesh -> grid: r1[I] = sum_{children i} w_iI res_i   (gather over the sorted children lists)
+// restriction mesh -> grid: r1[I] = sum_{children i} w_iI res_i.  One WAVE per grid node: the 2^D cells around the node
+// are dealt to groups of 64 / 2^D lanes, each lane takes the children of its cell with that stride; fixed lane -> child
+// assignment and a fixed shuffle tree, i.e. a gather in a reproducible order (a thread per grid node walked ~64
+// children one after the other: 232 us at 1 M mesh nodes against 134 us for a whole operator pass).
 template <int D>
-__global__ void k_mg_restrict0(GridDev g1, const int32_t* __restrict__ cell_ptr,
-                               const int32_t* __restrict__ cell_nodes, const double* __restrict__ wgt,
-                               const double* __restrict__ res, double* __restrict__ r1) {
-  constexpr int BS = D;
-  const long long I = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_mg_restrict0(GridDev g1, const int32_t* __restrict__ cell_ptr,
+                                                       const int32_t* __restrict__ cell_nodes,
+                                                       const double* __restrict__ wgt, const double* __restrict__ res,
+                                                       double* __restrict__ r1) {
+  constexpr int BS = D, NC = 1 << D, LPC = GL_WAVE / NC;   // lanes per cell
+  const long long I = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (I >= g1.nn) return;
+  const int lane = threadIdx.x & 63;
+  const int corner = lane / LPC, sub = lane % LPC;
   int Iv[3];
   lin2v(I, g1, Iv);
+  int cv[3] = {0, 0, 0};
+  bool ok = true;
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    cv[a] = Iv[a] - ((corner >> a) & 1);
+    ok = ok && cv[a] >= 0 && cv[a] <= gn(g1, a) - 2;
+  }
   double acc[BS];
 #pragma unroll
   for (int a = 0; a < BS; ++a) acc[a] = 0.0;
-  for (int corner = 0; corner < (1 << D); ++corner) {
-    int cv[3] = {0, 0, 0};
-    bool ok = true;
-#pragma unroll
-    for (int a = 0; a < D; ++a) {
-      cv[a] = Iv[a] - ((corner >> a) & 1);
-      ok = ok && cv[a] >= 0 && cv[a] <= gn(g1, a) - 2;
-    }
-    if (!ok) continue;
+  if (ok) {
     const long long c = v2lin(cv, g1);
-    for (int32_t q = cell_ptr[c]; q < cell_ptr[c + 1]; ++q) {
+    for (int32_t q = cell_ptr[c] + sub; q < cell_ptr[c + 1]; q += LPC) {
       const int64_t i = cell_nodes[q];
       double wi = 1.0;
 #pragma unroll
@@ -441,7 +514,14 @@ __global__ void k_mg_restrict0(GridDev g1, const int32_t* __restrict__ cell_ptr,
     }
   }
 #pragma unroll
-  for (int a = 0; a < BS; ++a) r1[(long long)a * g1.nn + I] = acc[a];
+  for (int a = 0; a < BS; ++a) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc[a] += __shfl_down(acc[a], o, 64);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int a = 0; a < BS; ++a) r1[(long long)a * g1.nn + I] = acc[a];
+  }
 }
 
 // prolongation grid -> mesh: xout_i = xin_i + F_i sum_{parents} w e_J
@@ -479,18 +559,21 @@ __global__ void k_mg_prolong0(GridDev g1, int64_t n_own, const int32_t* __restri
 }
 
 template <int D>
-__global__ void k_mg_restrict(GridDev gf, GridDev gc, Fac fc, const double* __restrict__ res,
-                              double* __restrict__ rc) {
+__global__ __launch_bounds__(256) void k_mg_restrict(GridDev gf, GridDev gc, Fac fc, const double* __restrict__ res,
+                                                      double* __restrict__ rc) {
+  // one wave per coarse node, its (up to) 3^D children dealt to the lanes, fixed shuffle tree
   constexpr int BS = D;
-  const long long I = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long I = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (I >= gc.nn) return;
+  const int lane = threadIdx.x & 63;
   int Iv[3];
   lin2v(I, gc, Iv);
   double acc[BS];
 #pragma unroll
   for (int a = 0; a < BS; ++a) acc[a] = 0.0;
   const int nch = D == 3 ? 27 : 9;
-  for (int ch = 0; ch < nch; ++ch) {
+  if (lane < nch) {
+    const int ch = lane;
     int dv[3] = {ch % 3 - 1, (ch / 3) % 3 - 1, D == 3 ? ch / 9 - 1 : 0};
     int iv[3] = {0, 0, 0};
     double wi = 1.0;
@@ -506,13 +589,21 @@ __global__ void k_mg_restrict(GridDev gf, GridDev gc, Fac fc, const double* __re
       }
       ok = ok && iv[a] >= 0 && iv[a] < gn(gf, a);
     }
-    if (!ok) continue;
-    const long long i = v2lin(iv, gf);
+    if (ok) {
+      const long long i = v2lin(iv, gf);
 #pragma unroll
-    for (int a = 0; a < BS; ++a) acc[a] += wi * res[(long long)a * gf.nn + i];
+      for (int a = 0; a < BS; ++a) acc[a] = wi * res[(long long)a * gf.nn + i];
+    }
   }
 #pragma unroll
-  for (int a = 0; a < BS; ++a) rc[(long long)a * gc.nn + I] = acc[a];
+  for (int a = 0; a < BS; ++a) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc[a] += __shfl_down(acc[a], o, 64);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int a = 0; a < BS; ++a) rc[(long long)a * gc.nn + I] = acc[a];
+  }
 }
 
 template <int D>
@@ -696,6 +787,18 @@ void mg_apply_cart(glims_ctx* h, MgLevel& L, int R, int mode, const double* xin,
                    double* xout, double c1, double c2, const int* done = nullptr) {
   const GridDev g = gdev(L.g);
   const unsigned grid = gridn(g.nn);
+  if (g.nn <= 6000) {   // small grid: one wave per node (see k_mg_cart_w; slower than a thread per node from ~17 k nodes)
+    const unsigned gw = gridn(g.nn, 4);
+    const int S = h->mg.S;
+    if (mode == 0)
+      hipLaunchKernelGGL((k_mg_cart_w<D, 0>), dim3(gw), dim3(256), 0, h->st, g, R, S, L.A.p, L.dinv.p, xin, r, d, xout, c1, c2, done);
+    else if (mode == 1)
+      hipLaunchKernelGGL((k_mg_cart_w<D, 1>), dim3(gw), dim3(256), 0, h->st, g, R, S, L.A.p, L.dinv.p, xin, r, d, xout, c1, c2, done);
+    else
+      hipLaunchKernelGGL((k_mg_cart_w<D, 2>), dim3(gw), dim3(256), 0, h->st, g, R, S, L.A.p, L.dinv.p, xin, r, d, xout, c1, c2, done);
+    GL_HIP(hipGetLastError());
+    return;
+  }
   if (mode == 0)
     hipLaunchKernelGGL((k_mg_cart<D, 0>), dim3(grid), dim3(256), 0, h->st, g, R, L.A.p, L.dinv.p, xin, r, d, xout, c1, c2, done);
   else if (mode == 1)
@@ -876,6 +979,8 @@ void mg_setup_t(glims_ctx* h) {
 
   // ---- lambda_max(Dinv A) per smoothed level: power iteration -----------------------------------------------------
   gl_block_dinv(h);
+  mg.half_smoother = (h->opt.flags & GLIMS_FLAG_MG_FP32_SMOOTHER) == 0;
+  if (mg.half_smoother) gl_make_half_copy(h);
   const int pit = 12;
   {
     const int64_t nd = n * BS;
@@ -994,7 +1099,7 @@ void mg_cycle_cart(glims_ctx* h, size_t l, const int* done) {
   mg_apply_cart<D>(h, L, mg.R, 0, xa, L.r.p, nullptr, L.res.p, 0.0, 0.0, done);
   MgLevel& C = *mg.lv[l + 1];
   const Fac fc{{L.f[0], L.f[1], L.f[2]}};
-  hipLaunchKernelGGL(k_mg_restrict<D>, dim3(gridn(C.g.nn)), dim3(256), 0, h->st, g, gdev(C.g), fc, L.res.p, C.r.p);
+  hipLaunchKernelGGL(k_mg_restrict<D>, dim3(gridn(C.g.nn, 4)), dim3(256), 0, h->st, g, gdev(C.g), fc, L.res.p, C.r.p);
   GL_HIP(hipGetLastError());
   mg_cycle_cart<D>(h, l + 1, done);
   hipLaunchKernelGGL(k_mg_prolong<D>, dim3(gridn(g.nn)), dim3(256), 0, h->st, g, gdev(C.g), fc, C.x.p, xa, xb);
@@ -1029,7 +1134,7 @@ void mg_apply_t(glims_ctx* h, const double* r, double* u, const int* done) {
   gl_launch_mg_fine(h, 0, xa, r, nullptr, mg.res.p, 0.0, 0.0, done);
   MgLevel& L1 = *mg.lv[0];
   const GridDev g1 = gdev(L1.g);
-  hipLaunchKernelGGL(k_mg_restrict0<D>, dim3(gridn(g1.nn)), dim3(256), 0, h->st, g1, mg.cell_ptr.p, mg.cell_nodes.p,
+  hipLaunchKernelGGL(k_mg_restrict0<D>, dim3(gridn(g1.nn, 4)), dim3(256), 0, h->st, g1, mg.cell_ptr.p, mg.cell_nodes.p,
                      mg.wgt.p, mg.res.p, L1.r.p);
   GL_HIP(hipGetLastError());
   mg_cycle_cart<D>(h, 0, done);

@@ -493,6 +493,34 @@ __global__ __launch_bounds__(256) void k_dot_partials(int64_t n, const double* _
   if (threadIdx.x == 0) partials[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
 }
 
+// up to three dot products against one vector in a single pass: partials[b][q] = (a_q, y) over block b
+struct Dot3 {
+  const double* a[3];
+};
+__global__ __launch_bounds__(256) void k_dot3(int64_t n, int nq, const Dot3 v, const double* __restrict__ y,
+                                               double* __restrict__ partials) {
+  __shared__ double sm[4][3];
+  double acc[3] = {0.0, 0.0, 0.0};
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double yi = y[i];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      if (q < nq) acc[q] += v.a[q][i] * yi;
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc[q] += __shfl_down(acc[q], o, 64);
+  }
+  if ((threadIdx.x & 63) == 0)
+    for (int q = 0; q < 3; ++q) sm[threadIdx.x >> 6][q] = acc[q];
+  __syncthreads();
+  if ((int)threadIdx.x < nq)
+    partials[(size_t)blockIdx.x * nq + threadIdx.x] =
+        sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+}
+
 // y = sum_k a[k] x_k  (k < m <= 8)
 struct LinComb {
   const double* x[8];
@@ -1102,32 +1130,43 @@ int gl_solve_mechanics(glims_ctx* h, const double* c_dev) {
     gl_spmv_block(h, h->m_uD.p, h->m_w.p, false);
     hipLaunchKernelGGL(k_sub, dim3(grid_exact(nd)), dim3(256), 0, h->st, nd, h->m_rhs.p, h->m_rhs.p, h->m_w.p, fx);
   }
-  // ||rhs|| for the relative tolerance
+  // ||rhs||^2 for the relative tolerance and g_k = (rhs_k, rhs) against the stored right-hand sides of the solve
+  // history: three products per pass over rhs and one host read per pass (one product per launch and read cost 27
+  // round trips = 0.8 ms per solve at depth 6); the Gram matrix of the stored right-hand sides is kept on the host
+  // and grows by the row g when this solve's right-hand side is stored
   const unsigned gd = grid_for(nd, 256, 1024);
-  hipLaunchKernelGGL(k_dot_partials, dim3(gd), dim3(256), 0, h->st, nd, h->m_rhs.p, h->m_rhs.p, h->partials.p);
-  reduce_partials(h, (int)gd, 1, nullptr);
-  allreduce_sum(h, h->red.p, 1);
-  const double nb = std::sqrt(read_red0(h));
+  const int m_hist = (h->mh_count > 0 && mh_depth > 0) ? h->mh_count : 0;
+  double g[glims_ctx::MHIST] = {0.0};
+  double nb2 = 0.0;
+  for (int q0 = -1; q0 < m_hist; q0 += 3) {   // value -1 = (rhs, rhs), values 0.. = (rhs_k, rhs)
+    Dot3 dv;
+    const int nq = std::min(3, m_hist - q0);
+    for (int q = 0; q < 3; ++q) {
+      const int k = q0 + q;
+      dv.a[q] = (q < nq) ? (k < 0 ? h->m_rhs.p : h->mh_rhs[k].p) : h->m_rhs.p;
+    }
+    hipLaunchKernelGGL(k_dot3, dim3(gd), dim3(256), 0, h->st, nd, nq, dv, h->m_rhs.p, h->partials.p);
+    GL_HIP(hipGetLastError());
+    reduce_partials(h, (int)gd, nq, nullptr);
+    allreduce_sum(h, h->red.p, nq);   // partitioned run: every rank gets the same sums, hence the same coefficients
+    double out[3];
+    read_red(h, nq, out);
+    for (int q = 0; q < nq; ++q) {
+      const int k = q0 + q;
+      if (k < 0) nb2 = out[q];
+      else g[k] = out[q];
+    }
+  }
+  const double nb = std::sqrt(nb2);
   if (!std::isfinite(nb)) return GLIMS_NAN;
   const double tol = std::max(h->opt.mech_atol, h->opt.mech_rtol * nb);
   // Initial guess.  K_el is linear and does not change in time, so if rhs ~ sum_k a_k rhs_k for previously solved
-  // right-hand sides then x ~ sum_k a_k x_k with residual rhs - sum_k a_k rhs_k: least-squares fit over the last
-  // (up to 4) solves; the concentration evolves smoothly, the fit removes several decades of the initial residual.
+  // right-hand sides then x ~ sum_k a_k x_k with residual rhs - sum_k a_k rhs_k: least-squares fit over the stored
+  // solves; the concentration evolves smoothly, the fit removes several decades of the initial residual.
   // Falls back to the previous displacement (the fit with a = e_last) when that is better or the history is empty.
-  if (h->mh_count > 0 && mh_depth > 0) {
-    const int m = h->mh_count;
-    // Gram matrix G_kl = (rhs_k, rhs_l) and g_k = (rhs_k, rhs): deterministic reductions, one value at a time
-    double G[glims_ctx::MHIST][glims_ctx::MHIST], g[glims_ctx::MHIST];
-    auto dot = [&](const double* a, const double* b) {
-      hipLaunchKernelGGL(k_dot_partials, dim3(gd), dim3(256), 0, h->st, nd, a, b, h->partials.p);
-      reduce_partials(h, (int)gd, 1, nullptr);
-      allreduce_sum(h, h->red.p, 1);   // partitioned run: every rank gets the same sums, hence the same coefficients
-      return read_red0(h);
-    };
-    for (int k = 0; k < m; ++k) {
-      g[k] = dot(h->mh_rhs[k].p, h->m_rhs.p);
-      for (int l = k; l < m; ++l) G[k][l] = G[l][k] = dot(h->mh_rhs[k].p, h->mh_rhs[l].p);
-    }
+  if (m_hist > 0) {
+    const int m = m_hist;
+    double (*G)[glims_ctx::MHIST] = h->mh_G;
     // normal equations with a small ridge (the right-hand sides of consecutive steps are nearly parallel)
     double a[glims_ctx::MHIST] = {0.0};
     {
@@ -1254,6 +1293,8 @@ int gl_solve_mechanics(glims_ctx* h, const double* c_dev) {
     h->mh_x[slot].alloc((size_t)h->n_nodes * bs);
     GL_HIP(hipMemcpyAsync(h->mh_rhs[slot].p, h->m_rhs.p, (size_t)nd * sizeof(double), hipMemcpyDeviceToDevice, h->st));
     GL_HIP(hipMemcpyAsync(h->mh_x[slot].p, h->U.p, (size_t)nd * sizeof(double), hipMemcpyDeviceToDevice, h->st));
+    for (int l = 0; l < m_hist; ++l) h->mh_G[slot][l] = h->mh_G[l][slot] = g[l];   // g against the slots that stay
+    h->mh_G[slot][slot] = nb2;
     h->mh_next = (slot + 1) % mh_depth;
     h->mh_count = std::min(h->mh_count + 1, mh_depth);
   }

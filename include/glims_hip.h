@@ -86,6 +86,8 @@ typedef struct glims_options {
                                            precision inside the Krylov solves (products, sums, all vectors and the Newton
                                            residual stay fp64, so the iteration still converges to the fp64 tolerance of
                                            the same fixed point); takes effect at glims_setup */
+#define GLIMS_FLAG_MG_FP32_SMOOTHER 8     /* OFF by default.  The level-0 smoother of the elasticity multigrid streams a
+                                           single-precision copy of K_el instead of the (scaled) half-precision one */
 #define GLIMS_FLAG_WARM_START 2         /* first linear solve of a step starts from the previous step's increment
                                            (ignored when GLIMS_FLAG_EXTRAPOLATE_GUESS is set) */
 
