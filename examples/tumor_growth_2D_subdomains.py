@@ -18,7 +18,7 @@ class Boundary(fenics.SubDomain):
 nx = ny = 50
 mesh = fenics.RectangleMesh(fenics.Point(-5, -5), fenics.Point(5, 5), nx, ny)
 # the reference projects this expression on DG1; the label rule int(label(midpoint)) is applied to its cell-vertex values
-labels = fenics.Expression('(x[0]>=0.0) ? (1.0) : (2.0)', degree=1)
+labels = fenics.project(fenics.Expression('(x[0]>=0.0) ? (1.0) : (2.0)', degree=1), fenics.FunctionSpace(mesh, "DG", 1))
 tissue_map = {0: 'outside', 1: 'A', 2: 'B'}
 dirichlet_bcs = {'clamped_outside': {'bc_value': fenics.Constant((0.0, 0.0)), 'named_boundary': 'boundary_all',
                                      'subspace_id': 0}}

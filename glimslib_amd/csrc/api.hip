@@ -363,6 +363,7 @@ int glims_set_dirichlet_c(glims_ctx* h, int64_t n, const int64_t* node_ids, cons
     h->pending = false;
     if (n <= 0) {
       h->have_fixed_c = false;
+      h->dirichlet_c_dirty = false;
       return GLIMS_OK;
     }
     GL_REQUIRE(node_ids && values, "null Dirichlet arrays");
@@ -377,7 +378,8 @@ int glims_set_dirichlet_c(glims_ctx* h, int64_t n, const int64_t* node_ids, cons
     h->fixed_c.upload(fx, h->st);
     h->fixed_c_val.upload(val, h->st);
     h->have_fixed_c = true;
-    gl_apply_dirichlet_c(h);   // a state is present: time-dependent data take effect with the next step
+    h->dirichlet_c_dirty = true;   // written into the iterate by the next step, after b = M c^n took the old values
+    h->pending = false;
     GL_HIP(hipStreamSynchronize(h->st));
     return GLIMS_OK;
   });
@@ -475,7 +477,7 @@ int glims_set_state(glims_ctx* h, const double* c, const double* u) {
     h->have_c_old = false;
     to_device_perm(h, c, h->c.p, 1);
     h->have_state = true;
-    gl_apply_dirichlet_c(h);
+    h->dirichlet_c_dirty = h->have_fixed_c;
     if (h->U.p) {
       if (u)
         to_device_perm(h, u, h->U.p, h->dim);

@@ -268,6 +268,7 @@ struct glims_ctx {
   MgHierarchy mg;
   MeshMetrics mm;
   dvec<double> fixed_c_val;                 // Dirichlet values of the concentration [n_nodes] (internal numbering)
+  bool dirichlet_c_dirty = false;           // values not yet written into the iterate (done by the next step)
   std::vector<dvec<double>*> snapshots;     // device-resident recorded concentrations (owned)
   dvec<double> stage;                      // staging for host<->device permuted transfers [n_nodes*dim]
 

@@ -751,11 +751,11 @@ void gl_block_dinv(glims_ctx* h) {
 // c = Dirichlet value on the constrained nodes (owned and ghost alike: every rank lists the constrained nodes of its
 // whole sub-mesh), then the state-dependent caches are stale
 void gl_apply_dirichlet_c(glims_ctx* h) {
+  h->dirichlet_c_dirty = false;
   if (!h->have_fixed_c || !h->fixed_c_val.p || !h->have_state) return;
   hipLaunchKernelGGL(k_mask_assign, dim3(grid_exact(h->n_nodes)), dim3(256), 0, h->st, h->n_nodes, h->c.p,
                      h->fixed_c.p, (const double*)h->fixed_c_val.p);
   GL_HIP(hipGetLastError());
-  h->pending = false;
   h->have_c_old = false;
 }
 
@@ -962,6 +962,9 @@ int gl_step(glims_ctx* h, int n_steps) {
       // b = M c^n + load          ('u_previous1 * v1 * dx', simulation_tumor_growth.py:117)
       gl_launch_spmv(h, h->st, p.n_slices, nullptr, h->vM.p, h->c.p, h->b.p, nullptr, load, nullptr, nullptr, 0,
                      nullptr);
+      // new Dirichlet data enter the ITERATE, after the old state went into b = M c^n: the reference's u_previous
+      // keeps the previous step's boundary values while the DirichletBC constrains the unknown
+      if (h->dirichlet_c_dirty) gl_apply_dirichlet_c(h);
       if (extrapolate) {
         hipLaunchKernelGGL(k_extrapolate, dim3(grid_exact(n)), dim3(256), 0, h->st, n, h->c.p, h->c_old.p,
                            h->have_fixed_c ? h->fixed_c.p : nullptr, h->stats.steps > 0 ? 1 : 0);

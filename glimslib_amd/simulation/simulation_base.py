@@ -176,7 +176,9 @@ class FenicsSimulation(ABC):
             except Exception as exc:            # reference: bare except around solver.solve() (:301-305)
                 self.logger.warning("    - Solver did not converge -- will shutdown simulation (%s)" % exc)
                 continue_simulation = False
-                done = max(1, getattr(self.solver, 'steps_done_in_last_call', 1))
+                # the device counts converged steps; the attempt that failed advances the clock too, as in the reference
+                # (t += dt precedes solver.solve(), :297-302)
+                done = getattr(self.solver, 'steps_done_in_last_call', 0) + 1
             current_sim_time += done * dt
             time_step += done
             if (time_step % keep_nth == 0) and continue_simulation:

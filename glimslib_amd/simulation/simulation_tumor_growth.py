@@ -185,8 +185,12 @@ class TumorGrowth(FenicsSimulation):
                     nu=self._table(p.poisson, n_labels))
 
     # -- loads / BCs --------------------------------------------------------------------------------------------
+    def _rd_source(self):
+        """The source term s of F_rd ('source_term', :95-96, :119)."""
+        return getattr(self, 'source_term', None)
+
     def _time_objects(self):
-        objs = [getattr(self, 'source_term', None), getattr(self, 'body_force', None)]
+        objs = [self._rd_source(), getattr(self, 'source_term', None), getattr(self, 'body_force', None)]
         for attr in ('dirichlet_bcs_dict', 'von_neumann_bcs_dict'):
             objs += [bc.get('bc_value') for bc in getattr(self.bcs, attr, {}).values()]
         return objs
@@ -217,7 +221,7 @@ class TumorGrowth(FenicsSimulation):
         labels = self._labels()
         # reaction-diffusion load: dt * ( int s w dx + oint g D w ds )                       (:119-120)
         rd = np.zeros(n)
-        src = getattr(self, 'source_term', None)
+        src = self._rd_source()
         if src is not None:
             if isinstance(src, (int, float)) or (isinstance(src, Constant)):
                 if float(src) != 0.0:
@@ -272,12 +276,11 @@ class TumorGrowth(FenicsSimulation):
         h.set_materials(t['D'], t['rho'], t['gamma'], t['E'], t['nu'])
         opts = {k: v for k, v in self.solver_options.items() if k != 'mechanics'}
         h.set_options(dt=float(self.params.sim_time_step), **opts)
-        cnodes, cvals = self._upload_loads_and_bcs(h)
+        self._upload_loads_and_bcs(h)
         h.setup(with_mechanics=mechanics)
-        c0 = u_previous.components[1].copy()
-        if len(cnodes):
-            c0[cnodes] = cvals
-        h.set_state(c0, u_previous.components[0].reshape(-1) if mechanics else None)
+        # the initial state is the initial-value function itself (simulation_base.py:253): Dirichlet data constrain the
+        # unknown of each step, not u_previous
+        h.set_state(u_previous.components[1], u_previous.components[0].reshape(-1) if mechanics else None)
         h.reset_stats()
         if hasattr(h, 'snapshot_clear'):
             h.snapshot_clear()

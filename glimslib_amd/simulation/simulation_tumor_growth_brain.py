@@ -7,6 +7,11 @@ Reference quirk q1: with an 'outside' subdomain the reference calls 
 ``mrd.compute_expansion`` (:75) and raises AttributeError.  The intended term -- the growth-induced strain with the
 global coupling, as in simulation_tumor_growth_brain_quad.py:76 -- is what is implemented here, with the hard-wired
 'outside' material E = 10e3, nu = 0.45 (:37-38).
+
+The reference's brain form names its source term ``rd_source_term`` (:46, :104) and carries neither a body force nor
+von Neumann terms (':105 No Von Neumann BC implemented here').  Here ``rd_source_term`` is read first (``source_term`` is
+accepted as a synonym); body force and Neumann data are honoured when given -- an extension over the reference's brain
+form, identical to it when they are absent, as in every bundled script.
 """
 from __future__ import annotations
 
@@ -26,6 +31,10 @@ class TumorGrowthBrain(TumorGrowth):
                                 'rho_GM', 'rho_WM',
                                 'coupling']
         self.optional_params = []
+
+    def _rd_source(self):
+        src = getattr(self, 'rd_source_term', None)
+        return src if src is not None else getattr(self, 'source_term', None)
 
     def _material_tables(self, n_labels):
         p = self.params

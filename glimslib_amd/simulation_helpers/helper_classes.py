@@ -353,10 +353,11 @@ class SubDomains:
 
     def _setup_subdomains_from_labelmapfunction(self, label_function):
         """
-        The label function is a P1 / DG1 function; at a cell midpoint it equals the mean of the cell's vertex values,
-        then ``int()`` truncates (helper_classes.py:441-442).  Accepted inputs: nodal array [N] or Function (P1),
-        array [M, d+1] (DG1 vertex values per cell), or an Expression/callable, which -- like a degree-1 dolfin
-        Expression projected on DG1 -- is sampled at each cell's vertices.
+        ``int(label_function(cell.midpoint()))`` per cell (helper_classes.py:441-442).  A P1 / DG1 function equals the
+        mean of the cell's vertex values at the midpoint: nodal array [N] or Function (P1), array [M, d+1] or
+        DG1Function (the reference's scripts and unit tests pass ``fenics.project(expr, DG1)``).  A raw Expression or
+        callable is evaluated AT the midpoint itself, as the reference's call does -- for a step function such as
+        '(x[0]>=0) ? 1 : 2' the two rules differ by the cell layer that touches the step.
         """
         self.label_function = label_function
         cells = self._mesh.cells
@@ -365,7 +366,12 @@ class SubDomains:
         elif isinstance(label_function, fenics.DG1Function):
             vals = label_function.cell_vertex_values
         elif isinstance(label_function, (Expression, Constant)) or callable(label_function):
-            vals = np.asarray(label_function(self._mesh.points), dtype=np.float64)[cells]
+            mid = np.asarray(label_function(self._mesh.cell_midpoints()), dtype=np.float64).reshape(-1)
+            if mid.shape != (len(cells),):
+                raise ValueError("label function has the wrong shape")
+            mid = np.where(np.abs(mid - np.round(mid)) < 1e-9, np.round(mid), mid)
+            self.subdomains = CellFunction(self._mesh, mid.astype(np.int64))
+            return
         else:
             a = np.asarray(label_function, dtype=np.float64)
             vals = a[cells] if a.shape == (self._mesh.num_vertices(),) else a

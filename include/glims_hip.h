@@ -148,9 +148,11 @@ int glims_set_options(glims_ctx* h, const glims_options* opt);
 
 /* Dirichlet data (fenics.DirichletBC lists built at helper_classes.py:632-723).  n == 0 clears. */
 int glims_set_dirichlet_u(glims_ctx* h, int64_t n, const int64_t* dof_ids, const double* values);
-/* Concentration: the listed nodes are held at `values`.  The values are written into the state at once when a state
- * is present (time-dependent data: call again before the next glims_step, as BoundaryConditions.time_update_bcs does
- * for every step, helper_classes.py:839-859) and again by every later glims_set_state. */
+/* Concentration: the listed nodes are held at `values` from the next glims_step on.  As with fenics.DirichletBC the
+ * data constrain the UNKNOWN of a step: the state that enters the step's 'u_previous' term keeps the values it has
+ * (simulation_tumor_growth.py:115-117), the new values are written into the Newton iterate.  Time-dependent data: call
+ * again before the next glims_step, as BoundaryConditions.time_update_bcs does for every step
+ * (helper_classes.py:839-859). */
 int glims_set_dirichlet_c(glims_ctx* h, int64_t n, const int64_t* node_ids, const double* values);
 
 /* Load vectors already integrated by the host (NULL clears):

@@ -25,7 +25,7 @@ class Boundary(fenics.SubDomain):
 def _c1_sim(sim_time=10, **kw):
     nx = ny = 50
     mesh = fenics.RectangleMesh(fenics.Point(-5, -5), fenics.Point(5, 5), nx, ny)
-    labels = fenics.Expression('(x[0]>=0.0) ? (1.0) : (2.0)', degree=1)
+    labels = fenics.project(fenics.Expression('(x[0]>=0.0) ? (1.0) : (2.0)', degree=1), fenics.FunctionSpace(mesh, "DG", 1))
     tissue_map = {0: 'outside', 1: 'A', 2: 'B'}
     dirichlet_bcs = {'clamped_outside': {'bc_value': fenics.Constant((0.0, 0.0)), 'named_boundary': 'boundary_all',
                                          'subspace_id': 0}}
@@ -308,4 +308,57 @@ def test_results_on_device_are_lazy_and_identical():
     pp = lazy.init_postprocess(None)                                      # derived fields work on lazy records too
     assert np.isfinite(pp.get_pressure(recording_step=5).values()).all()
     for s in sims.values():
+        s.close()
+
+
+class _Left(fenics.SubDomain):
+    def inside(self, x, on_boundary):
+        return on_boundary and x[0] < -5 + 1e-10
+
+
+def test_time_dependent_dirichlet_value_of_the_concentration():
+    """BoundaryConditions.time_update_bcs (helper_classes.py:839-859) sets `.t` on every BC value before each step, so a
+    DirichletBC whose value depends on t changes from step to step; the device must hold the NEW value (round 1 froze
+    it at t = 0).  Oracle: rd_step with the Dirichlet data of each step's time."""
+    nx = ny = 24
+    mesh = fenics.RectangleMesh(fenics.Point(-5, -5), fenics.Point(5, 5), nx, ny)
+    dirichlet_bcs = {'inflow': {'bc_value': fenics.Expression('0.1 + 0.05*t', degree=1, t=0.0), 'named_boundary': 'left',
+                                'subspace_id': 1}}
+    sim = TumorGrowth(mesh, solver_options={'mechanics': False})
+    sim.setup_global_parameters(domain_names={0: 'all'}, boundaries={'left': _Left()}, dirichlet_bcs=dirichlet_bcs,
+                                von_neumann_bcs={})
+    sim.setup_model_parameters(iv_expression={0: fenics.Constant((0.0, 0.0)), 1: fenics.Constant(0.0)},
+                               diffusion=0.3, coupling=0.0, proliferation=0.1, E=1.0, poisson=0.3,
+                               sim_time=4, sim_time_step=1)
+    sol = sim.run(save_method=None, plot=False)
+    left = np.flatnonzero(mesh.points[:, 0] < -5 + 1e-10)
+    assert len(left) == ny + 1
+    o = OracleTumorGrowth(mesh.points, mesh.cells, 0.3, 0.1, 0.0, 1.0, 0.3, 1.0)
+    c = np.zeros(mesh.num_vertices())                    # u_previous of the first step is the initial-value function
+    for t in (1.0, 2.0, 3.0, 4.0):
+        o.dirichlet_c = (left, np.full(len(left), 0.1 + 0.05 * t))
+        c, _ = o.rd_step(c)
+    got = sol.components[1]
+    assert np.allclose(got[left], 0.3, rtol=0, atol=1e-15)
+    assert rel_l2(got, c) < 1e-9
+    assert got.max() <= 0.3 + 1e-12 and got[mesh.points[:, 0] > 0].max() > 0     # the inflow diffuses into the domain
+    sim.close()
+
+
+def test_brain_model_reads_rd_source_term():
+    """The reference's brain form calls its source `rd_source_term` (simulation_tumor_growth_brain.py:46,104)."""
+    tissue_map = {1: 'CSF', 3: 'WM', 2: 'GM', 4: 'Ventricles'}
+    kw = dict(E_GM=3000E-6, E_WM=3000E-6, E_CSF=1000E-6, E_VENT=1000E-6, nu_GM=0.45, nu_WM=0.45, nu_CSF=0.45,
+              nu_VENT=0.3, D_GM=0.01, D_WM=0.05, rho_GM=0.05, rho_WM=0.05, coupling=0.1)
+    a = _atlas_like(TumorGrowthBrain, tissue_map, **kw)
+    a.rd_source_term = fenics.Constant(0.002)
+    b = _atlas_like(TumorGrowthBrain, tissue_map, **kw)
+    b.source_term = fenics.Constant(0.002)
+    c = _atlas_like(TumorGrowthBrain, tissue_map, **kw)
+    sa = a.run(save_method=None, plot=False).components[1]
+    sb = b.run(save_method=None, plot=False).components[1]
+    sc = c.run(save_method=None, plot=False).components[1]
+    assert np.array_equal(sa, sb)
+    assert (sa - sc).min() > 1e-4                         # four steps of a uniform source of 0.002
+    for s in (a, b, c):
         s.close()

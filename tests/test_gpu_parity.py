@@ -193,7 +193,8 @@ def test_failure_semantics_and_usage_errors(backend):
         h.step(1)                                                 # no state
     h.set_state(np.random.default_rng(0).random(mesh.num_vertices()))
     assert h.step(3) == backend.GLIMS_NOT_CONVERGED               # iteration cap -> status, not an exception
-    assert h.stats()['steps'] == 1                                # stops at the failing step
+    st = h.stats()
+    assert st["steps"] == 0 and st["failed_steps"] == 1             # stops at the failing step, which is not counted as done
     with pytest.raises(backend.BackendError):
         h.solve_mechanics()                                       # mechanics operators were not assembled
     with pytest.raises(backend.BackendError):
@@ -621,3 +622,54 @@ def test_optional_fp32_jacobian_converges_to_the_same_fixed_point(backend):
     assert st32['last_newton_res'] < 1e-9 * max(1.0, st64['last_newton_res'] / 1e-10)
     assert 1e-9 < rel_l2(A32, A64) < 1e-6                          # the hook shows the single-precision operator
     assert st32['newton_its'] <= st64['newton_its'] + 2
+
+
+def test_long_run_breakdown_is_the_schemes_and_happens_at_the_same_step_as_in_the_c_oracle(backend):
+    """
+    BASELINE config C4 names 500 steps; with the reference's parameters the consistent-mass P1 scheme undershoots at the
+    travelling front (front width sqrt(D/rho) below the mesh width), the logistic term amplifies negative values and
+    Newton stops converging when A(c) turns indefinite -- at step 483 on C4, 210-250 on C3 (profiles/r01_long_c*_run.txt).
+    Here the same mechanism on a mesh where it takes ~20 steps (n = 16, rho = 0.5, D = 0.05 / 0.25): device and C
+    oracle side by side, the same min c trajectory to 4 digits and the same failing step; the device reports
+    GLIMS_NOT_CONVERGED, counts the step as failed and keeps stepping possible (reference: simulation_base.py:301-305).
+    """
+    from oracle.c_port import COracle
+    w = workloads.config_c3(16)
+    hx = 240.0 / 16
+    tabs = dict(w.tables)
+    tabs['D'] = [0.0, 0.0, 0.05, 0.25, 0.0]
+    tabs['rho'] = [0.0, 0.0, 0.5, 0.5, 0.0]
+    c0 = np.exp(-((w.mesh.points - np.array([118.0, -109.0, 72.0])) ** 2).sum(1) / (2 * (1.5 * hx) ** 2))
+    Dc, rc = np.asarray(tabs['D'])[w.cell_label], np.asarray(tabs['rho'])[w.cell_label]
+    co = COracle(w.mesh.points, w.mesh.cells, Dc, rc, 1.0)
+    h = _handle(backend, w.mesh, w.cell_label, 1.0, tabs, mechanics=False)
+    h.set_state(c0)
+    c_or = c0.copy()
+    fail_or = fail_dev = None
+    traj = []
+    for k in range(1, 60):
+        if fail_or is None:
+            try:
+                c_or = co.step(c_or, 1)
+            except RuntimeError:
+                fail_or = k
+        if fail_dev is None:
+            st = h.step(1)
+            if st != 0:
+                fail_dev = k
+                assert st == backend.GLIMS_NOT_CONVERGED
+        if fail_or is not None or fail_dev is not None:
+            break
+        c_dev = h.get_state(want_u=False)[0]
+        traj.append((c_or.min(), c_dev.min()))
+        assert abs(c_dev.min() - c_or.min()) <= 1e-4 * max(abs(c_or.min()), 1e-3), (k, traj[-1])
+        # the nearer the indefinite Jacobian, the more the round-off of two different solvers is amplified
+        assert rel_l2(c_dev, c_or) < (1e-8 if k <= 10 else 1e-4)
+    print("min c (oracle, device) of the last steps before the breakdown:", ["%.4e / %.4e" % t for t in traj[-4:]])
+    print("Newton gives up at step: oracle %s, device %s" % (fail_or, fail_dev))
+    assert fail_or is not None and fail_or == fail_dev and 10 < fail_dev < 40
+    assert traj[-1][0] < -0.2                                        # the undershoot had grown to O(1)
+    st = h.stats()
+    assert st['steps'] == fail_dev - 1 and st['failed_steps'] == 1
+    h.close()
+    co.close()

@@ -38,7 +38,8 @@ def _mixed_space(mesh):
 @pytest.fixture
 def sd5():
     mesh = fenics.RectangleMesh(fenics.Point(-2, -2), fenics.Point(2, 2), 5, 5)
-    labels = fenics.Expression('(x[0]>=0) ? (1.0) : (2.0)', degree=1)
+    # as the reference's fixture does (test_unit_subDomains.py:14-17): the step function projected on DG1
+    labels = fenics.project(fenics.Expression('(x[0]>=0) ? (1.0) : (2.0)', degree=1), fenics.FunctionSpace(mesh, "DG", 1))
     tmap = {0: 'outside', 1: 'tissue', 2: 'tumor'}
     return mesh, SubDomains(mesh), labels, tmap
 
@@ -67,6 +68,23 @@ def test_setup_boundaries_and_measures(sd5):
     xs = mesh.points[f['vertices'][sd.subdomain_boundaries.array() == tid]][:, :, 0]
     assert np.allclose(xs, -0.4)
     assert sd.get_subdomain_id('tissue') == 1                                      # :96-99
+
+
+def test_raw_expression_labels_are_evaluated_at_the_cell_midpoint(sd5):
+    """helper_classes.py:441-442 evaluates the label function AT the midpoint: for a raw step Expression the interface
+    is the step itself (x = 0 is not a grid line of the 5 x 5 mesh: the straddling column takes the midpoint's side),
+    for its DG1 image (vertex mean, then int()) it moves to x = -0.4 -- the case the reference's unit test pins."""
+    mesh, sd, labels, tmap = sd5
+    sd.setup_subdomains(label_function=labels)
+    dg1 = sd.subdomains.array().copy()
+    sd.setup_subdomains(label_function=fenics.Expression('(x[0]>=0) ? (1.0) : (2.0)', degree=1), replace=True)
+    raw = sd.subdomains.array()
+    mx = mesh.cell_midpoints()[:, 0]
+    assert (raw == np.where(mx >= 0, 1, 2)).all()
+    assert (dg1 == np.where(mesh.points[mesh.cells][:, :, 0].max(axis=1) >= 0, 1, 2)).all()
+    assert (raw != dg1).sum() > 0
+    sd.setup_subdomains(label_function=lambda x: np.where(x[:, 0] >= 0, 1.0, 2.0), replace=True)
+    assert (sd.subdomains.array() == raw).all()
 
 
 def test_label_function_variants_agree(sd5):
@@ -106,7 +124,8 @@ def bc10():
     mesh = fenics.RectangleMesh(fenics.Point(-2, -2), fenics.Point(2, 2), 10, 10)
     fs = _mixed_space(mesh)
     sd = SubDomains(mesh)
-    sd.setup_subdomains(label_function=fenics.Expression('(x[0]>=0) ? (1.0) : (2.0)', degree=1))
+    sd.setup_subdomains(label_function=fenics.project(fenics.Expression('(x[0]>=0) ? (1.0) : (2.0)', degree=1),
+                                                      fenics.FunctionSpace(mesh, "DG", 1)))
     sd.setup_boundaries(tissue_map={0: 'outside', 1: 'tissue', 2: 'tumor'},
                         boundary_fct_dict={'boundary_pos': BoundaryPos(), 'boundary_neg': BoundaryNeg()})
     sd.setup_measures()
@@ -150,7 +169,8 @@ def test_parameters_bookkeeping():
     mesh = fenics.RectangleMesh((-2, -2), (2, 2), 5, 5)
     fs = _mixed_space(mesh)
     sd = SubDomains(mesh)
-    sd.setup_subdomains(label_function=fenics.Expression('(x[0]>=0) ? (1.0) : (2.0)', degree=1))
+    sd.setup_subdomains(label_function=fenics.project(fenics.Expression('(x[0]>=0) ? (1.0) : (2.0)', degree=1),
+                                                      fenics.FunctionSpace(mesh, "DG", 1)))
     sd.setup_boundaries(tissue_map={0: 'outside', 1: 'tissue', 2: 'tumor'})
     p = Parameters(fs, sd, time_dependent=True)
     p.set_initial_value_expressions({0: fenics.Constant((0., 0.)), 1: fenics.Expression('x[0] > 0 ? 1.0 : 0.0', degree=1)})
