@@ -30,37 +30,61 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(budget_s=15.0):
-    """
-    CPU baseline ("port"): the C/OpenMP restatement oracle/glims_oracle_c.c (Newton + Jacobi-PCG on CSR, fp64, same
-    tolerances as the device run) on this job's CPU share of the box (16 OpenMP threads unless GLIMS_ORACLE_THREADS
-    says otherwise; the box reports more cores than one job may use), on a bounded sample of the same workload: the
-    brain-extent box at n=99 (config C3, 1 000 000 DoF), as many implicit steps as fit in ~budget_s seconds.
-    FEniCS itself is not installed here, hence kind = "port", not "reference".
-    """
+def _time_c_oracle(w, budget_s, min_steps, warm=True):
+    """Time the C/OpenMP oracle on workload `w`: (DoF-updates/s, steps, seconds, setup seconds, stats)."""
     from oracle.c_port import COracle
-    from glimslib_amd import workloads
-    w = workloads.config_c3()
     t0 = time.perf_counter()
     o = COracle(w.mesh.points, w.mesh.cells, w.per_cell('D'), w.per_cell('rho'), w.dt)
     t_setup = time.perf_counter() - t0
-    c = o.step(w.c0, 1)                                             # warm-up step (not timed)
+    c = w.c0
+    if warm:
+        c = o.step(c, 1)                                            # warm-up step (not timed)
     steps = 0
     t0 = time.perf_counter()
     while True:
         c = o.step(c, 1)
         steps += 1
         el = time.perf_counter() - t0
-        if (steps >= 3 and el > budget_s) or steps >= 200:
+        if (steps >= min_steps and el > budget_s) or steps >= 200:
             break
-    n = w.mesh.num_vertices()
     st = o.stats()
-    return {"value": n * steps / el, "unit": "DoF-updates/s", "cores": COracle.threads(), "kind": "port",
-            "sample": "oracle/glims_oracle_c.c (C + OpenMP, CSR Newton/Jacobi-PCG, fp64) on the same brain-extent box "
-                      "at n=99 (%d DoF): %d implicit steps in %.1f s on %d threads (setup %.1f s excluded; "
-                      "%.1f Newton, %.1f PCG iterations per step)" %
-                      (n, steps, el, COracle.threads(), t_setup, st['newton_its'] / (steps + 1.0),
-                       st['cg_its'] / (steps + 1.0))}
+    n = w.mesh.num_vertices()
+    o.close()
+    return n * steps / el, steps, el, t_setup, st, n
+
+
+def cpu_baseline(w_headline=None, budget_s=12.0):
+    """
+    CPU baseline ("port"): the C/OpenMP restatement oracle/glims_oracle_c.c (Newton + Jacobi-PCG on CSR, fp64, same
+    tolerances as the device run) on this job's CPU share of the box (16 OpenMP threads unless GLIMS_ORACLE_THREADS
+    says otherwise; the box reports more cores than one job may use).  Two bounded samples, each one warm-up step and
+    then as many implicit steps as fit in ~budget_s seconds: (1) the workload of this very line (`w_headline`, e.g. C4
+    at its full 10 M DoF) -> `value`; (2) the same brain-extent box at n = 99 (config C3, 1 M DoF) -> `c3_sample`.  FEniCS itself is not installed here, hence kind = "port".
+    """
+    from oracle.c_port import COracle
+    from glimslib_amd import workloads
+    out = {"unit": "DoF-updates/s", "cores": COracle.threads(), "kind": "port"}
+    v3, steps, el, t_setup, st, n = _time_c_oracle(workloads.config_c3(), budget_s, 3)
+    c3 = {"value": v3, "workload": "C3 brain-extent box n=99 (%d DoF)" % n, "steps": steps, "seconds": el,
+          "setup_seconds": t_setup, "newton_its_per_step": st['newton_its'] / (steps + 1.0),
+          "cg_its_per_step": st['cg_its'] / (steps + 1.0)}
+    if w_headline is not None and w_headline.mesh is not None and w_headline.mesh.num_vertices() != n:
+        big = False
+        vh, hs, hel, hsetup, hst, hn = _time_c_oracle(w_headline, budget_s, 3)
+        out.update({"value": vh, "same_workload_as_value": True,
+                    "sample": "oracle/glims_oracle_c.c (C + OpenMP, CSR Newton/Jacobi-PCG, fp64) on THIS line's workload "
+                              "(%s, %d DoF): %d implicit steps in %.1f s on %d threads (setup %.1f s excluded; %.1f Newton, "
+                              "%.1f PCG iterations per step%s)" %
+                              (w_headline.name, hn, hs, hel, COracle.threads(), hsetup, hst['newton_its'] / float(hs),
+                               hst['cg_its'] / float(hs), "; first steps of the run, no warm-up step" if big else ""),
+                    "c3_sample": c3})
+    else:
+        out.update({"value": v3, "same_workload_as_value": w_headline is not None,
+                    "sample": "oracle/glims_oracle_c.c (C + OpenMP, CSR Newton/Jacobi-PCG, fp64) on the brain-extent box "
+                              "at n=99 (%d DoF): %d implicit steps in %.1f s on %d threads (setup %.1f s excluded; "
+                              "%.1f Newton, %.1f PCG iterations per step)" %
+                              (n, steps, el, COracle.threads(), t_setup, c3['newton_its_per_step'], c3['cg_its_per_step'])})
+    return out
 
 
 def main():
@@ -110,8 +134,6 @@ def main():
             dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
 
-    # HIP events around the Krylov SpMV launches of the timed steps (read by the library at glims_create)
-    os.environ.setdefault("GLIMS_TIME_SPMV", "1")
     from glimslib_amd import workloads
     from glimslib_amd._backend import Handle, GLIMS_OK, FLAG_EXTRAPOLATE_GUESS
     from glimslib_amd.partition import partition_mesh
@@ -157,7 +179,8 @@ def main():
         flags = (flags | 2) if args.warm_start else (flags & ~2)
     if args.fp32_jacobian:
         flags |= 4
-    h.set_options(dt=w.dt, flags=flags, **extra)
+    # HIP events around the Krylov SpMV launches of the timed steps (the dominant kernel's in-step roofline figure)
+    h.set_options(dt=w.dt, flags=flags, time_kernels=1, **extra)
     # coupled configs (C5): the displacement is solved after EVERY step, as the reference's monolithic solve does; the
     # unknown count is then (d + 1) per node.  (The simulation classes solve it lazily)
     coupled = bool(w.mechanics)
@@ -174,12 +197,13 @@ def main():
         h.set_dirichlet_u(dofs, np.zeros(len(dofs)))
     h.setup(with_mechanics=coupled)
     h.set_state(c0)
+    if coupled:
+        h.solve_mechanics()    # builds the multigrid hierarchy of K_el (one-off set-up, reported in config) before any timed step
     st0 = h.stats()
     if rank == 0:
         log("[bench] setup %.1f s; rows/rank %d, nnz %d (padded %d, +%.1f%%), corners %d" %
             (time.perf_counter() - t0, st0['n_rows'], st0['nnz'], st0['nnz_padded'],
              100.0 * (st0['nnz_padded'] / st0['nnz'] - 1.0), st0['n_corners']))
-    w.mesh = None   # free host memory
 
     def barrier():
         if world > 1:
@@ -210,15 +234,26 @@ def main():
         elapsed = float(tt.item())
     st = h.stats()
     steps_done = int(st['steps'] - steps_before)      # < K only if the solver gave up (status != 0)
+    # the other two hot kernels (assembly sweep, PCG vector update): event pairs around every launch of theirs cost
+    # ~0.1 ms per step at 1 M rows, so they are timed in a short pass of their own right after the timed region
+    st_k = None
+    if world == 1 and status == GLIMS_OK and not coupled:
+        k_steps = max(2, min(5, args.steps))
+        h.set_options(time_kernels=2)
+        h.reset_stats()
+        if h.step(k_steps) == GLIMS_OK:
+            st_k = h.stats()
+            st_k['_steps'] = k_steps
+        h.set_options(time_kernels=1)
     if status != GLIMS_OK:
         log("[bench] WARNING: solver status %d after %d of %d steps; throughput counts completed steps only" %
             (status, steps_done, args.steps))
 
     # ---- roofline of the dominant kernel: SELL-64 SpMV with the RD Jacobian A(c) ------------------------
     # algorithmic bytes per launch = 12*nnz + 20*rows of THIS rank's operator;
-    # duration = HIP events on the library's own stream around `reps` back-to-back launches (glims_apply).
-    # (a) inside the timed region: HIP events around every Krylov SpMV launch of the steps (GLIMS_TIME_SPMV, single
-    #     GPU); (b) after it: `spmv_reps` back-to-back launches of the same operator without the fused dot product.
+    # duration (a) inside the timed region: HIP events on the library's stream around every Krylov SpMV launch of the
+    # steps (glims_options.time_kernels), (b) after it: `spmv_reps` back-to-back launches of the same operator
+    # without the fused dot product (glims_apply).  The same event pairs time the other two hot kernels of a step.
     x = np.random.default_rng(0).standard_normal(h.n_nodes)
     h.apply(0, x, reps=5)
     _, ms = h.apply(0, x, reps=args.spmv_reps)
@@ -230,24 +265,78 @@ def main():
         t_spmv = st['ms_spmv_steps'] * 1e-3 / st['n_spmv_steps']
     achieved = b_alg / t_spmv / 1e9
     # HBM-side bytes per launch from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate rocprofv3 runs,
-    # calibrated on kernels with exactly known byte counts): profiles/r01_pmc_c4.json.  Only reported when this
-    # run's operator is the one those passes measured.
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(HERE, "profiles", "r01_pmc_c4.json")))
-        if world == 1 and pmc["n_rows"] == st['n_rows'] and pmc["nnz"] == st['nnz']:
-            key = [k for k in pmc["kernels"] if k.startswith("k_spmv<1" if in_step else "k_spmv<0")][0]
-            traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
-    except Exception:
-        traffic = None
+    # calibrated on kernels with exactly known byte counts).  A LOOKUP into the committed summary of those passes, not
+    # a measurement of this run: only reported when this run's operator is the one the passes measured, and
+    # `traffic_source` names the file.
+    pmc, pmc_file = None, None
+    for cand in ("r02_pmc_c4.json", "r01_pmc_c4.json"):
+        try:
+            q = json.load(open(os.path.join(HERE, "profiles", cand)))
+            if world == 1 and q["n_rows"] == st['n_rows'] and q["nnz"] == st['nnz']:
+                pmc, pmc_file = q, "profiles/" + cand
+                break
+        except Exception:   # noqa: BLE001
+            continue
+
+    def pmc_bytes(prefix):
+        if pmc is None:
+            return None
+        keys = [k for k in pmc["kernels"] if k.startswith(prefix)]
+        return pmc["kernels"][keys[0]]["hbm_bytes_per_launch"] if keys else None
+
+    traffic = pmc_bytes("k_spmv<1" if in_step else "k_spmv<0")
+    steps_n = max(1, steps_done)
+    ms_step = 1e3 * elapsed / steps_n
+    kernels = []
+
+    def kernel_entry(name, what, alg_bytes, sum_ms, count, median_us, pmc_prefix, n_steps, step_ms, where):
+        if count <= 0:
+            return
+        mean_us = 1e3 * sum_ms / count
+        tb = pmc_bytes(pmc_prefix)
+        kernels.append({"name": name, "does": what, "algorithmic_bytes_per_launch": alg_bytes,
+                        "median_us": median_us, "mean_us": mean_us, "launches_per_step": count / float(n_steps),
+                        "achieved_GBps": alg_bytes / (mean_us * 1e-6) / 1e9,
+                        "frac": alg_bytes / (mean_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                        "share_of_step": sum_ms / (step_ms * n_steps),
+                        "traffic_bytes_per_launch": tb,
+                        "achieved_real_GBps": None if tb is None else tb / (mean_us * 1e-6) / 1e9,
+                        "timed": where})
+
+    if world == 1 and in_step:
+        kernel_entry("k_spmv<1, 4, 1, 1, double, 1>", "y = A(c) x, SELL-64 with 16-bit column codes, fused w.u partials "
+                     "(algorithmic bytes: CSR with 4-byte columns, 12 nnz + 20 rows)", b_alg,
+                     st['ms_spmv_steps'], st['n_spmv_steps'], st['us_spmv_median'], "k_spmv<1", steps_n, ms_step,
+                     "HIP events inside the %d timed steps" % steps_n)
+    if st_k is not None:
+        ks, kms = st_k['_steps'], st_k['ms_steps'] / st_k['_steps']
+        where = "HIP events in a separate pass of %d steps right after the timed region" % ks
+        kernel_entry("k_rd_assemble<4, 0, 24, 1, double, 1>", "Jacobian + Newton residual(s) in one sweep over the "
+                     "(row, cell) incidences (algorithmic bytes: 12 per incidence + 20 per stored entry [S read, A write, "
+                     "4-byte column] + 32 per row)", 12 * st['n_corners'] + 20 * st['nnz_padded'] + 32 * st['n_rows'],
+                     st_k['ms_sweep_steps'], st_k['n_sweep_steps'], st_k['us_sweep_median'], "k_rd_assemble", ks, kms,
+                     where)
+        kernel_entry("k_cg_update<1>", "PCG recurrence scalars + p, s, x, r, u update + next (r.u, r.r) partials "
+                     "(algorithmic bytes: 12 vector passes x 8 B per row)", 96 * st['n_rows'],
+                     st_k['ms_update_steps'], st_k['n_update_steps'], st_k['us_update_median'], "k_cg_update<1>", ks, kms,
+                     where)
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": ("k_spmv<1, 4, 1, 1>" if in_step else "k_spmv<0, 4, 1, 1>") + " (SELL-64, fp64 values, "
-                "columns streamed as 16-bit window codes; algorithmic bytes still count 4-byte CSR columns)",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": None if traffic is None else
+                "lookup, not measured in this run: %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same "
+                "operator, tools/pmc_summary.py)" % pmc_file,
+                "achieved_real": None if traffic is None else traffic / t_spmv / 1e9,
+                "frac_real": None if traffic is None else traffic / t_spmv / 1e9 / HBM_PEAK_GBS,
+                "kernel": ("k_spmv<1, 4, 1, 1, double, 1>" if in_step else "k_spmv<0, 4, 1, 1, double, 1>") +
+                " (SELL-64, fp64 values, columns streamed as 16-bit window codes; algorithmic bytes still count 4-byte "
+                "CSR columns)",
                 "algorithmic_bytes_per_launch": b_alg, "avg_launch_us": t_spmv * 1e6,
+                "median_launch_us": st['us_spmv_median'] if in_step else None,
                 "launches_timed": int(st['n_spmv_steps']) if in_step else args.spmv_reps,
                 "timed": "inside the timed steps (k_spmv<1,..>, fused dot product)" if in_step
                          else "back-to-back launches after the timed steps (k_spmv<0,..>)",
-                "isolated_launch_us": t_isolated * 1e6}
+                "isolated_launch_us": t_isolated * 1e6,
+                "kernels": kernels}
 
     # practical HBM ceiling of THIS device next to the nominal peak: streaming scale kernel y = 2 x over
     # 1 GiB, read + write bytes over the HIP-event time of the fastest of 10 launches (torch is only the allocator / launcher here;
@@ -286,8 +375,16 @@ def main():
             "vs_baseline": None,
             "dtype": "f64" if not args.fp32_jacobian else "f64 (Jacobian stored f32 inside the Krylov solves)",
             "data": "synthetic",
+            "steps_requested": args.steps,
+            "steps_completed": steps_done,
+            "solver_status": int(status),
             "config": {"workload": w.name, "dofs": n_global * (dim + 1 if coupled else 1), "dt": w.dt,
                        "mech_cg_its_per_step": st['mech_cg_its'] / max(1, steps_done) if coupled else None,
+                       "mech_preconditioner": (("multigrid V-cycle, %d levels, operator complexity %.2f, set-up %.0f ms "
+                                                "(outside the timed steps)" % (st['mg_levels'], st['mg_complexity'],
+                                                                               st['ms_mg_setup']))
+                                               if st['mg_levels'] else "block-Jacobi") if coupled else None,
+                       "mech_ms_per_step": st['ms_mech'] / max(1, steps_done) if coupled else None,
                        "partition": "morton-node x%d" % world if world > 1 else "single GPU",
                        "newton_its_per_step": st['newton_its'] / max(1, steps_done),
                        "cg_its_per_step": st['cg_its'] / max(1, steps_done),
@@ -298,7 +395,7 @@ def main():
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(None if coupled else w)
         print(json.dumps(out), flush=True)
     h.close()
     if world > 1:

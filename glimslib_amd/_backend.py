@@ -21,6 +21,7 @@ FLAG_EXTRAPOLATE_GUESS = 1
 FLAG_WARM_START = 2
 FLAG_FP32_JACOBIAN = 4
 FLAG_MG_FP32_SMOOTHER = 8
+FLAG_INT32_COLUMNS = 16
 PRECOND_BLOCK_JACOBI, PRECOND_MULTIGRID = 0, 1
 ABI_VERSION = 2
 
@@ -37,7 +38,8 @@ class Options(C.Structure):
                 ("cg_maxit", C.c_int), ("mech_rtol", C.c_double), ("mech_atol", C.c_double),
                 ("mech_maxit", C.c_int), ("check_every", C.c_int), ("flags", C.c_int),
                 ("mech_precond", C.c_int), ("mech_mixed", C.c_int), ("mech_history", C.c_int),
-                ("mg_smooth", C.c_int), ("mg_coarse_nodes", C.c_int), ("mg_h_factor", C.c_double)]
+                ("mg_smooth", C.c_int), ("mg_coarse_nodes", C.c_int), ("mg_h_factor", C.c_double),
+                ("time_kernels", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -48,7 +50,10 @@ class Stats(C.Structure):
                 ("nnz_padded", C.c_int64), ("n_corners", C.c_int64), ("nnz_idx16", C.c_int64),
                 ("ms_spmv_steps", C.c_double), ("n_spmv_steps", C.c_int64),
                 ("failed_steps", C.c_int64), ("mg_levels", C.c_int64), ("mg_cycles", C.c_int64),
-                ("mg_complexity", C.c_double), ("ms_mg_setup", C.c_double), ("ms_mech", C.c_double)]
+                ("mg_complexity", C.c_double), ("ms_mg_setup", C.c_double), ("ms_mech", C.c_double),
+                ("ms_sweep_steps", C.c_double), ("n_sweep_steps", C.c_int64), ("ms_update_steps", C.c_double),
+                ("n_update_steps", C.c_int64), ("us_spmv_median", C.c_double), ("us_sweep_median", C.c_double),
+                ("us_update_median", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -15,29 +15,7 @@
 
 static void mailbox_close(glims_ctx* h);
 
-void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* slice_list, const double* vals,
-                    const double* x, double* y, const uint8_t* fixed, const double* addv, const double* r,
-                    double* partials, int partial_off, const int* done, const float* vals32 = nullptr);
-
 namespace {
-
-void read_tuning(glims_ctx* h) {
-  if (const char* e = getenv("GLIMS_SPMV_UNROLL")) h->tune_spmv_unroll = atoi(e);
-  if (const char* e = getenv("GLIMS_XCD_REMAP")) h->tune_xcd_remap = atoi(e);
-  if (const char* e = getenv("GLIMS_SPMV_NT")) h->tune_spmv_nt = atoi(e);
-  if (const char* e = getenv("GLIMS_RD_NT")) h->tune_rd_nt = atoi(e);
-  if (const char* e = getenv("GLIMS_RD_REMAP")) h->tune_rd_remap = atoi(e);
-  if (const char* e = getenv("GLIMS_RD_UNROLL")) h->tune_rd_unroll = atoi(e);
-  if (const char* e = getenv("GLIMS_IDX16")) h->tune_idx16 = atoi(e);
-  if (const char* e = getenv("GLIMS_TIME_SPMV")) h->time_spmv = atoi(e) != 0;
-  if (const char* e = getenv("GLIMS_PAIR_A")) h->tune_pair_A = atoi(e);
-  if (const char* e = getenv("GLIMS_FUSED_PACK")) h->tune_fused_pack = atoi(e);
-  if (const char* e = getenv("GLIMS_UPD_NT")) h->tune_upd_nt = atoi(e);
-  if (const char* e = getenv("GLIMS_BLK_VARIANT")) h->tune_blk_variant = atoi(e);
-  if (const char* e = getenv("GLIMS_LIN_MARGIN")) h->tune_lin_margin = atof(e);
-  if (const char* e = getenv("GLIMS_DEFER")) h->tune_defer = atoi(e);
-  if (const char* e = getenv("GLIMS_DEFER_EXTRA")) h->tune_defer_extra = std::max(1, atoi(e));
-}
 
 std::mutex g_err_mu;
 std::string g_create_err;
@@ -121,6 +99,7 @@ int glims_options_default(glims_options* o) {
   o->mg_smooth = 2;
   o->mg_coarse_nodes = 216;
   o->mg_h_factor = 2.0;
+  o->time_kernels = 0;
   return GLIMS_OK;
 }
 
@@ -154,7 +133,6 @@ int glims_create(glims_ctx** out, int dim, int64_t n_nodes, int64_t n_own, int64
     h->n_cells = n_cells;
     glims_options_default(&h->opt);
     std::memset(&h->stats, 0, sizeof(h->stats));
-    read_tuning(h);
     GL_HIP(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
     GL_HIP(hipStreamCreateWithFlags(&h->st_comm, hipStreamNonBlocking));
     GL_HIP(hipEventCreate(&h->ev_a));
@@ -252,7 +230,7 @@ int glims_create(glims_ctx** out, int dim, int64_t n_nodes, int64_t n_own, int64
     h->mat.alloc_zero(5 * GL_MAX_LABELS, h->st);
     h->partials.alloc_zero((size_t)p.n_slices * 3 + 4096, h->st);
     h->partials2.alloc_zero((size_t)(p.n_slices * 3 + 4096) / 1024 * 3 + 64, h->st);
-    h->partials_v.alloc_zero(2 * 4096 + 64, h->st);
+    h->partials_v.alloc_zero(2 * 4096 + 64, h->st);   // block pairs of the vector kernels (grid_for caps at 4096 blocks)
     h->red.alloc_zero(4, h->st);
     h->scal.alloc_zero(2 * SC_COUNT + 8, h->st);
     h->done.alloc_zero(1, h->st);
@@ -263,7 +241,8 @@ int glims_create(glims_ctx** out, int dim, int64_t n_nodes, int64_t n_own, int64
     h->stats.nnz_padded = p.total_entries;
     h->stats.n_corners = hp.n_corners;
     for (int32_t sl = 0; sl < hp.n_slices; ++sl)
-      if (hp.win_ok[sl] && h->tune_idx16) h->stats.nnz_idx16 += hp.slice_ptr[sl + 1] - hp.slice_ptr[sl];
+      if (hp.win_ok[sl]) h->nnz_idx16_avail += hp.slice_ptr[sl + 1] - hp.slice_ptr[sl];
+    h->stats.nnz_idx16 = h->nnz_idx16_avail;
     *out = h;
     return GLIMS_OK;
   } catch (const glims_error& e) {
@@ -350,7 +329,7 @@ int glims_set_options(glims_ctx* h, const glims_options* opt) {
         opt->mg_h_factor != h->opt.mg_h_factor)
       h->mg.ready = false;
     if (opt->dt != h->opt.dt) h->is_setup = false;
-    if ((opt->flags ^ h->opt.flags) & GLIMS_FLAG_FP32_JACOBIAN) h->is_setup = false;
+    if ((opt->flags ^ h->opt.flags) & (GLIMS_FLAG_FP32_JACOBIAN | GLIMS_FLAG_INT32_COLUMNS)) h->is_setup = false;
     if ((opt->flags ^ h->opt.flags) & GLIMS_FLAG_MG_FP32_SMOOTHER) h->mg.ready = false;
     h->opt = *opt;
     h->pending = false;
@@ -461,7 +440,9 @@ int glims_setup(glims_ctx* h, int with_mechanics) {
     }
     h->pending = false;
     h->jac32 = (h->opt.flags & GLIMS_FLAG_FP32_JACOBIAN) != 0;
-    h->pair_A = h->tune_pair_A != 0 && h->tune_idx16 != 0 && h->stats.nnz_idx16 == h->stats.nnz_padded;
+    h->use_idx16 = (h->opt.flags & GLIMS_FLAG_INT32_COLUMNS) == 0;
+    h->stats.nnz_idx16 = h->use_idx16 ? h->nnz_idx16_avail : 0;
+    h->pair_A = h->use_idx16 && h->stats.nnz_idx16 == h->stats.nnz_padded;
     gl_assemble_static(h, with_mechanics);
     GL_HIP(hipStreamSynchronize(h->st));
     h->is_setup = true;
@@ -538,10 +519,7 @@ int glims_apply(glims_ctx* h, int which, const double* x, double* y, int reps, d
   return guarded(h, [&]() {
     GL_REQUIRE(h->is_setup, "glims_apply before glims_setup");
     GL_REQUIRE(x && y && reps >= 1, "bad arguments");
-    GL_REQUIRE(which >= 0 && which <= 6, "unknown operator");
-    if (which == 6) GL_REQUIRE(h->tune_idx16 && h->stats.nnz_idx16 == h->stats.nnz_padded && !h->pair_A,
-                               "the slot-pair study needs 16-bit codes on every slice and GLIMS_PAIR_A=0");
-    read_tuning(h);
+    GL_REQUIRE(which >= 0 && which <= 5, "unknown operator");
     const int d = h->dim;
     const bool blk_in = which == 3, blk_out = which == 3 || which == 4;
     if (blk_out) GL_REQUIRE(h->have_mech, "mechanics operators not assembled");
@@ -551,12 +529,9 @@ int glims_apply(glims_ctx* h, int which, const double* x, double* y, int reps, d
     to_device_perm(h, x, xin.p, blk_in ? d : 1);
     const bool saved_mload = h->have_mload;
     h->have_mload = false;
-    if (which == 6) gl_spmv_pairs_study(h, h->vA.p, xin.p, yout.p);   // converts the layout (not timed)
     GL_HIP(hipEventRecord(h->ev_a, h->st));
     for (int r = 0; r < reps; ++r) {
-      if (which == 6)
-        gl_spmv_pairs_study_run(h, xin.p, yout.p);
-      else if (which == 5)   // A x with the fused dot product of the Krylov iteration (timing studies)
+      if (which == 5)   // A x with the fused dot product of the Krylov iteration (timing studies)
         gl_launch_spmv(h, h->st, h->pat.n_slices, nullptr, h->vA.p, xin.p, yout.p, nullptr, nullptr, xin.p,
                        h->partials.p, 0, nullptr, h->jac32 ? h->vA32.p : nullptr);
       else if (which <= 2)
@@ -590,7 +565,6 @@ int glims_rd_residual(glims_ctx* h, const double* c, const double* c_prev, doubl
     gl_launch_spmv(h, h->st, h->pat.n_slices, nullptr, h->vM.p, dcp.p, h->b.p, nullptr,
                    h->have_load_rd ? h->load_rd.p : nullptr, nullptr, nullptr, 0, nullptr);
     h->pending = false;
-    read_tuning(h);
     gl_rd_assemble(h, dc.p, h->b.p, nullptr, h->cg_r.p, h->cg_r2.p, h->partials.p);
     GL_HIP(hipStreamSynchronize(h->st));
     if (R) {

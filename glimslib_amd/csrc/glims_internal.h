@@ -18,6 +18,10 @@
 // streams 2 B instead of 4 B of index per entry.  Slices that need more windows fall back to the 32-bit stream.
 #define GL_WIN_BITS 11
 #define GL_N_WIN 32
+// Blocks are dealt to the 8 XCDs in chunks of this many consecutive logical blocks: neighbouring slices (overlapping x
+// gathers) share one L2 while the XCDs together still walk the matrix front to back (measured: time of the plain
+// mapping, fabric reads 2.21 -> 1.97 GB per SpMV at 10 M rows; contiguous eighths are 1-5 % slower).
+#define GL_XCD_CHUNK 64
 
 struct glims_error : std::runtime_error {
   int code;
@@ -191,6 +195,53 @@ struct MeshMetrics {
   std::vector<double> xyz;                 // owned nodes, internal numbering [n_own][dim]
 };
 
+#ifdef __HIPCC__
+// Node-local all-reduce of red[0..nq) (see NodeMail): called by every thread of the (single) final reduction block.
+// Sums in rank order on every rank -> the same bits everywhere, hence identical decisions.
+static __device__ __forceinline__ void node_allreduce(double* __restrict__ red, int nq, const NodeMail nm) {
+  __syncthreads();   // red[] written by threads < nq
+  if (threadIdx.x >= GL_WAVE) return;
+  const int lane = threadIdx.x;
+  unsigned long long seq = 0;
+  if (lane == 0) {
+    seq = *nm.seq + 1ull;
+    *nm.seq = seq;
+  }
+  seq = __shfl(seq, 0, GL_WAVE);
+  double* bank = nm.slots + (size_t)(seq & 1ull) * nm.world * 8;
+  if (lane == 0) {
+    double* mine = bank + (size_t)nm.rank * 8;
+    for (int q = 0; q < nq; ++q) __hip_atomic_store(mine + 1 + q, red[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(mine), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  bool ok = true;
+  if (lane < nm.world) {
+    const unsigned long long* f = reinterpret_cast<const unsigned long long*>(bank + (size_t)lane * 8);
+    const long long t0 = wall_clock64();   // 100 MHz
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+      __builtin_amdgcn_s_sleep(4);
+      if (wall_clock64() - t0 > nm.timeout_ticks) {   // default: a peer that is a minute late is not coming
+        ok = false;
+        break;
+      }
+    }
+  }
+  ok = __all(ok);
+  __threadfence_system();
+  if (lane < nq) {
+    double t = 0.0;
+    if (ok)
+      for (int r = 0; r < nm.world; ++r)
+        t += __hip_atomic_load(bank + (size_t)r * 8 + 1 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else
+      t = __builtin_nan("");
+    red[lane] = t;
+  }
+  if (!ok && lane == 0) *nm.err = 1;
+}
+
+#endif
+
 // scalar slots of the Krylov recurrence (device array `scal`)
 enum { SC_ALPHA = 0, SC_BETA, SC_GAMMA, SC_IT, SC_COUNT = 8 };
 
@@ -212,36 +263,27 @@ struct glims_ctx {
 
   glims_options opt;
   glims_stats stats;
-  // Tuning knobs, defaults = the measured best; environment overrides are read at glims_create
-  // and again by glims_apply (so that tools/ab_*.py can interleave variants in one process):
-  //   GLIMS_SPMV_UNROLL 4|8        entries in flight per lane in the scalar SpMV
-  //   GLIMS_XCD_REMAP   0|1|G      block -> XCD mapping: plain | contiguous eighths | chunks of G blocks (64)
-  //   GLIMS_SPMV_NT     0|1|2      non-temporal loads: none | values + columns | values only
-  //   GLIMS_IDX16       0|1        columns as int32 | as 16-bit (window, offset) codes where a slice allows it
-  //   GLIMS_RD_NT / GLIMS_RD_REMAP / GLIMS_RD_UNROLL (4|8|12|24)   the same for the assembly sweep
-  //   GLIMS_PAIR_A      0|1        Newton Jacobian + its column codes in the slot-pair layout (16-B value loads)
-  //   GLIMS_FUSED_PACK  0|1        partitioned run: halo payload packed by the vector-update kernel (1) or by k_pack
-  //   GLIMS_MECH_MIXED  0|1|2      elasticity: fp32 copy of K_el in the inner PCG under fp64 iterative refinement:
-  //                                off | when K_el exceeds the Infinity Cache (default) | always
-  //   GLIMS_MHIST       0..8       depth of the elasticity solve history used for the initial guess (6)
-  //   GLIMS_UPD_NT      0|1        non-temporal streams in the PCG vector update (everything but u)
-  //   GLIMS_BLK_VARIANT 0|1|2      block SpMV: first version | pipelined, 2 | 4 block entries per batch
-  //   GLIMS_DEFER 0|1, GLIMS_DEFER_EXTRA n   read the linear solve's outcome with the next Newton sweep (1) after
-  //                                enqueuing hint + n iterations, or poll after every batch (0)
-  // setup_host.cpp reads GLIMS_SIGMA (row-sort window) and GLIMS_WIN_LIMIT (max windows per slice, tests).
-  int tune_spmv_unroll = 4, tune_xcd_remap = 64, tune_rd_remap = 64, tune_spmv_nt = 1, tune_rd_nt = 0,
-      tune_rd_unroll = 24, tune_idx16 = 1, tune_defer = 1, tune_defer_extra = 2, tune_blk_variant = 1, tune_upd_nt = 0;
-  double tune_lin_margin = 0.5;   // GLIMS_LIN_MARGIN: the last linear solve of a step stops at margin * Newton target
+  bool use_idx16 = true;                   // columns as 16-bit (window, offset) codes where a slice has them
+                                           // (off with GLIMS_FLAG_INT32_COLUMNS: the int32 stream everywhere)
   int64_t stats_defer_miss = 0;
-  // GLIMS_TIME_SPMV=1: event pairs around the Krylov SpMV launches of glims_step (bench.py's in-step roofline figure)
-  bool time_spmv = false;
+  int64_t nnz_idx16_avail = 0;             // stored entries of slices that have 16-bit codes
+  // glims_options.time_kernels: event pairs around the hot kernels of glims_step (bench.py's in-step roofline figures)
+  enum { TK_SPMV = 0, TK_SWEEP = 1, TK_UPDATE = 2 };
   std::vector<hipEvent_t> tev;
+  std::vector<uint8_t> tev_cat;             // category of pair q = events 2q, 2q+1
   size_t tev_used = 0;
+  // time_kernels = 1: the Krylov SpMV only (two event records per launch cost ~2 us each -- too much for the other two
+  // kernels inside a timed region at 1 M rows); 2: all three categories
+  bool timing(int cat) const {
+    return (opt.time_kernels >= 2 || (opt.time_kernels == 1 && cat == TK_SPMV)) && tev_used + 2 <= tev.size();
+  }
+  void tick(int cat) {                      // first call opens a pair of category `cat`, the second closes it
+    if ((tev_used & 1) == 0) tev_cat[tev_used / 2] = (uint8_t)cat;
+    (void)hipEventRecord(tev[tev_used++], st);
+  }
 
   // scalar operator planes (SELL-64 layout) and block planes
   dvec<double> vM, vS, vA, vKel, vG;
-  dvec<double> study_pvals;                // slot-pair layout study (glims_apply which = 6)
-  dvec<uint16_t> study_pc16;
   dvec<float> vA32;                        // Newton Jacobian in single precision (GLIMS_FLAG_FP32_JACOBIAN only)
   bool jac32 = false;
   bool pair_A = false;                     // vA / vA32 and cols16p use the slot-pair layout (GLIMS_PAIR_A, needs 16-bit codes everywhere)
@@ -291,7 +333,6 @@ struct glims_ctx {
   // row -> send slots (the vector-update kernel packs the halo payload itself): send_ref[row] = -1 or r with the
   // slots send_slot[send_slot_ptr[r] .. send_slot_ptr[r+1])
   dvec<int32_t> send_ref, send_slot_ptr, send_slot;
-  int tune_fused_pack = 1;                  // GLIMS_FUSED_PACK
   dvec<double> sendbuf;
   int64_t n_send = 0;
   NodeMail nm;                              // active when nm.slots != nullptr
@@ -317,8 +358,12 @@ void gl_rd_assemble(glims_ctx* h, const double* c, const double* b, const double
 void gl_spmv_scalar(glims_ctx* h, const double* vals, const double* x, double* y, bool masked);
 void gl_apply_G(glims_ctx* h, const double* c, double* y);
 void gl_spmv_block(glims_ctx* h, const double* x, double* y, bool masked);
-void gl_spmv_pairs_study(glims_ctx* h, const double* vals, const double* x, double* y);
-void gl_spmv_pairs_study_run(glims_ctx* h, const double* x, double* y);
+void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* slice_list, const double* vals,
+                    const double* x, double* y, const uint8_t* fixed, const double* addv, const double* r,
+                    double* partials, int partial_off, const int* done, const float* vals32 = nullptr);
+void gl_launch_spmv_block(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* slice_list, const double* x,
+                          double* y, const uint8_t* fixed, const double* r, double* partials, int partial_off,
+                          const int* done, bool single_precision_operator = false);
 
 // solver.hip ----------------------------------------------------------------------------------------
 int gl_step(glims_ctx* h, int n_steps);

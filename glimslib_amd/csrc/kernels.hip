@@ -13,13 +13,6 @@
 
 namespace {
 
-__device__ __forceinline__ int xcd_remap(int b, int nb) {
-  // Blocks are dealt round-robin over the 8 XCDs; give each XCD one contiguous range of logical blocks so that
-  // neighbouring slices (which gather overlapping x entries) share one L2.  Bijective for any nb.
-  const int xcd = b & 7, q = nb >> 3, r = nb & 7;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-}
-
 __device__ __forceinline__ int xcd_chunk_remap(int b, int nb, int G) {
   // Hardware deals block b to XCD b % 8.  Give every XCD chunks of G consecutive logical blocks, chunk after chunk
   // round-robin over the XCDs: neighbouring slices (overlapping x gathers) share one L2, while the eight XCDs
@@ -35,6 +28,21 @@ __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
   return v;
+}
+
+// Epilogue of the dot-fused SpMV kernels (256-thread blocks): one partial per BLOCK, added over its 4 waves in a
+// fixed order (a partial per wave meant 4x as many values for the reduction kernel that follows, and a first
+// reduction stage at 10 M rows).
+// (A "last block done" reduction fused into this epilogue was built and measured in round 2: with the partials in
+//  uncached memory and two-level ticket counters the SpMV went from 36 to 62 us at 1 M rows -- more than the separate
+//  reduction kernel and its dispatch gap cost together, 7 + 6 us; with device-scope fences it was 15x slower still.)
+__device__ __forceinline__ void spmv_dot_partial(double pd, int b, double* __restrict__ partials, int partial_off) {
+  __shared__ double smd[4];
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  pd = wave_sum(pd);
+  if (lane == 0) smd[wid] = pd;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[partial_off + b] = (smd[0] + smd[1]) + (smd[2] + smd[3]);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -526,8 +534,7 @@ __global__ __launch_bounds__(256) void k_spmv(int n_launch, int chunk, const int
                                                int partial_off, const int* __restrict__ done, int remap) {
   if (done && *done) return;
   // block b owns the contiguous slice range [b*chunk, (b+1)*chunk); its 4 waves interleave inside that range
-  const int b = remap == 1 ? xcd_remap(blockIdx.x, gridDim.x)
-                : remap > 1 ? xcd_chunk_remap(blockIdx.x, gridDim.x, remap) : blockIdx.x;
+  const int b = remap > 1 ? xcd_chunk_remap(blockIdx.x, gridDim.x, remap) : blockIdx.x;
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int s_end = min(n_launch, (b + 1) * chunk);
   double pd = 0.0;
@@ -555,32 +562,7 @@ __global__ __launch_bounds__(256) void k_spmv(int n_launch, int chunk, const int
       if (DOTS) pd += acc * xd;   // xd = x[row], picked up from the gather of the diagonal entry
     }
   }
-  if (DOTS) {
-    // one partial per WAVE (4 slots per block): no LDS, no block barrier at the end of the kernel
-    pd = wave_sum(pd);
-    if (lane == 0) partials[(size_t)(partial_off + b) * 4 + wid] = pd;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// STUDY (glims_apply which = 6, not used by the solver): "slot-pair" SELL -- two consecutive slots of a row are adjacent
-// in memory, so a lane reads its values 16 B and its column codes 4 B at a time (1024-B / 256-B wave loads, half the
-// load instructions); an odd last slot stays a single 8-B / 2-B load.  Layout per slice with len slots:
-//   pairs q = 0 .. len/2 - 1 at pbase + (q*64 + lane)*2 + {0,1},  odd tail at pbase + (len/2)*128 + lane.
-// ---------------------------------------------------------------------------------------------------
-__global__ void k_to_pairs(int n_slices, const int64_t* __restrict__ slice_ptr, const double* __restrict__ vals,
-                           const uint16_t* __restrict__ c16, double* __restrict__ pvals, uint16_t* __restrict__ pc16) {
-  const int s = blockIdx.x, lane = threadIdx.x;
-  const int64_t base = slice_ptr[s];
-  const int len = (int)((slice_ptr[s + 1] - base) >> 6);
-  for (int k = 0; k < len; ++k) {
-    const int64_t src = base + (int64_t)k * GL_WAVE + lane;
-    int64_t d;
-    if ((len & 1) && k == len - 1) d = base + (int64_t)(len / 2) * 2 * GL_WAVE + lane;
-    else d = base + ((int64_t)(k >> 1) * GL_WAVE + lane) * 2 + (k & 1);
-    pvals[d] = vals[src];
-    pc16[d] = c16[src];
-  }
+  if (DOTS) spmv_dot_partial(pd, b, partials, partial_off);
 }
 
 // slot-major -> slot-pair copy of one per-entry array
@@ -591,111 +573,6 @@ __global__ void k_plane_to_pairs(int n_slices, const int64_t* __restrict__ slice
   const int64_t base = slice_ptr[s];
   const int len = (int)((slice_ptr[s + 1] - base) >> 6);
   for (int k = 0; k < len; ++k) out[base + pair_off(k, len, lane)] = (TO)in[base + (int64_t)k * GL_WAVE + lane];
-}
-
-template <int DOTS>
-__global__ __launch_bounds__(256) void k_spmv_pairs(int n_launch, int chunk, int64_t n_own,
-                                                     const int64_t* __restrict__ slice_ptr,
-                                                     const uint16_t* __restrict__ pc16,
-                                                     const int32_t* __restrict__ win_base,
-                                                     const double* __restrict__ pvals, const double* __restrict__ x,
-                                                     double* __restrict__ y, int remap) {
-  const int b = remap > 1 ? xcd_chunk_remap(blockIdx.x, gridDim.x, remap) : blockIdx.x;
-  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int s_end = min(n_launch, (b + 1) * chunk);
-  for (int s = b * chunk + wid; s < s_end; s += 4) {
-    const int64_t row = (int64_t)s * GL_WAVE + lane;
-    const int64_t base = slice_ptr[s];
-    const int len = (int)((slice_ptr[s + 1] - base) >> 6);
-    const int32_t wb = win_base[(int64_t)s * GL_N_WIN + (lane & (GL_N_WIN - 1))];
-    const double2* v2 = reinterpret_cast<const double2*>(pvals + base) + lane;
-    const uint32_t* c2 = reinterpret_cast<const uint32_t*>(pc16 + base) + lane;
-    const int np = len >> 1;
-    double acc = 0.0;
-    int q = 0;
-    for (; q + 2 <= np; q += 2) {   // 2 pairs = 4 entries per batch
-      uint32_t cc[2];
-      double2 vv[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) cc[j] = __builtin_nontemporal_load(c2 + (int64_t)(q + j) * GL_WAVE);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        vv[j].x = __builtin_nontemporal_load(&v2[(int64_t)(q + j) * GL_WAVE].x);
-        vv[j].y = __builtin_nontemporal_load(&v2[(int64_t)(q + j) * GL_WAVE].y);
-      }
-      double xg[4];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        xg[2 * j] = x[decode_col(cc[j] & 0xffffu, wb)];
-        xg[2 * j + 1] = x[decode_col(cc[j] >> 16, wb)];
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc += vv[j].x * xg[2 * j] + vv[j].y * xg[2 * j + 1];
-    }
-    for (; q < np; ++q) {
-      const uint32_t c = __builtin_nontemporal_load(c2 + (int64_t)q * GL_WAVE);
-      const double2 v = v2[(int64_t)q * GL_WAVE];
-      acc += v.x * x[decode_col(c & 0xffffu, wb)] + v.y * x[decode_col(c >> 16, wb)];
-    }
-    if (len & 1) {
-      const int64_t t = base + (int64_t)np * 2 * GL_WAVE + lane;
-      acc += pvals[t] * x[decode_col(pc16[t], wb)];
-    }
-    if (row < n_own) y[row] = acc;
-  }
-}
-
-// block version (mechanics): BS x BS blocks stored as BS*BS slot-major planes per slice entry
-template <int BS, int DOTS>
-__global__ __launch_bounds__(256) void k_spmv_block(int n_launch, int chunk,
-                                                     const int32_t* __restrict__ slice_list, int64_t n_own, const int64_t* __restrict__ slice_ptr,
-                                                     const int32_t* __restrict__ cols,
-                                                     const double* __restrict__ vals, const double* __restrict__ x,
-                                                     double* __restrict__ y, const uint8_t* __restrict__ fixed,
-                                                     const double* __restrict__ r, double* __restrict__ partials,
-                                                     int partial_off, const int* __restrict__ done, int remap) {
-  if (done && *done) return;
-  constexpr int B2 = BS * BS;
-  const int b = remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
-  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int s_end = min(n_launch, (b + 1) * chunk);
-  double pd = 0.0;
-  for (int si = b * chunk + wid; si < s_end; si += 4) {
-    const int s = slice_list ? slice_list[si] : si;
-    const int64_t row = (int64_t)s * GL_WAVE + lane;
-    const int64_t base = slice_ptr[s];
-    const int len = (int)((slice_ptr[s + 1] - base) >> 6);
-    const int32_t* cc = cols + base + lane;
-    double acc[BS];
-#pragma unroll
-    for (int a = 0; a < BS; ++a) acc[a] = 0.0;
-#pragma unroll 2
-    for (int k = 0; k < len; ++k) {
-      const int64_t col = cc[(int64_t)k * GL_WAVE];
-      const double* v = vals + (base + (int64_t)k * GL_WAVE) * B2 + lane;
-      double xj[BS];
-#pragma unroll
-      for (int bb = 0; bb < BS; ++bb) xj[bb] = x[col * BS + bb];
-#pragma unroll
-      for (int a = 0; a < BS; ++a)
-#pragma unroll
-        for (int bb = 0; bb < BS; ++bb) acc[a] += v[(a * BS + bb) * GL_WAVE] * xj[bb];
-    }
-    if (row < n_own) {
-#pragma unroll
-      for (int a = 0; a < BS; ++a) {
-        double v = acc[a];
-        if (fixed && fixed[row * BS + a]) v = 0.0;
-        y[row * BS + a] = v;
-        if (DOTS) pd += v * x[row * BS + a];
-      }
-    }
-  }
-  if (DOTS) {
-    // one partial per WAVE (4 slots per block): no LDS, no block barrier at the end of the kernel
-    pd = wave_sum(pd);
-    if (lane == 0) partials[(size_t)(partial_off + b) * 4 + wid] = pd;
-  }
 }
 
 // Pipelined block SpMV: KB block entries per batch -- all column loads, then all KB*BS*BS value loads (non-temporal:
@@ -759,11 +636,7 @@ __global__ __launch_bounds__(256) void k_spmv_block2(int n_launch, int chunk, co
       }
     }
   }
-  if (DOTS) {
-    // one partial per WAVE (4 slots per block): no LDS, no block barrier at the end of the kernel
-    pd = wave_sum(pd);
-    if (lane == 0) partials[(size_t)(partial_off + b) * 4 + wid] = pd;
-  }
+  if (DOTS) spmv_dot_partial(pd, b, partials, partial_off);
 }
 
 // Level-0 pass of the elasticity multigrid (mg.hip): one sweep over the single-precision copy of K_el with the
@@ -1015,24 +888,25 @@ void gl_rd_assemble(glims_ctx* h, const double* c, const double* b, const double
                     double* partials, int part) {
   const DevPattern& p = h->pat;
   const uint8_t* fx = h->have_fixed_c ? h->fixed_c.p : nullptr;
-#define GL_RD3(NV, NT, CU, CIDX)                                                                                   \
+  // Kernel configuration (measured best): cached (not non-temporal) streams, 24 incidence records
+  // in flight per lane, one slice per block dealt to the XCDs in chunks.  AT / PAIR: the Newton Jacobian is written in
+  // fp64 or (GLIMS_FLAG_FP32_JACOBIAN) fp32, slot-major or -- when every slice has 16-bit column codes -- slot-pair.
+#define GL_RD(NV, CIDX, AT, PAIR, APTR)                                                                             \
   do {                                                                                                             \
-    set_lds(k_rd_assemble<NV, NT, CU, CIDX>, lds);                                                                 \
-    hipLaunchKernelGGL((k_rd_assemble<NV, NT, CU, CIDX>), dim3(grid), dim3(GL_WAVE), lds, h->st, list, h->n_own,    \
-                       p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, p.win_ok.p, p.cslice_ptr.p, p.cslots.p,   \
-                       p.cw.p, p.diag_k.p, h->vS.p, h->vA.p, c, b, b2, r_out, r2_out, h->dinv.p, fx,                 \
-                       2.0 * h->opt.dt, partials, cap, h->tune_rd_remap);                                          \
+    set_lds(k_rd_assemble<NV, 0, 24, CIDX, AT, PAIR>, lds);                                                        \
+    hipLaunchKernelGGL((k_rd_assemble<NV, 0, 24, CIDX, AT, PAIR>), dim3(grid), dim3(GL_WAVE), lds, h->st, list,     \
+                       h->n_own, p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, p.win_ok.p, p.cslice_ptr.p,     \
+                       p.cslots.p, p.cw.p, p.diag_k.p, h->vS.p, APTR, c, b, b2, r_out, r2_out, h->dinv.p, fx,        \
+                       2.0 * h->opt.dt, partials, cap, GL_XCD_CHUNK);                                              \
   } while (0)
-#define GL_RD2(NV, NT, CU)                                                                                         \
+#define GL_RDV(NV)                                                                                                  \
   do {                                                                                                             \
-    if (h->tune_idx16) GL_RD3(NV, NT, CU, 1); else GL_RD3(NV, NT, CU, 0);                                         \
-  } while (0)
-#define GL_RD(NV, NT)                                                                                              \
-  do {                                                                                                             \
-    if (h->tune_rd_unroll == 12) { GL_RD2(NV, NT, 12); }                                                           \
-    else if (h->tune_rd_unroll == 8) { GL_RD2(NV, NT, 8); }                                                        \
-    else if (h->tune_rd_unroll == 4) { GL_RD2(NV, NT, 4); }                                                        \
-    else { GL_RD2(NV, NT, 24); }                                                                                   \
+    if (h->pair_A && h->jac32) GL_RD(NV, 1, float, 1, h->vA32.p);                                                  \
+    else if (h->pair_A) GL_RD(NV, 1, double, 1, h->vA.p);                                                          \
+    else if (h->jac32 && h->use_idx16) GL_RD(NV, 1, float, 0, h->vA32.p);                                          \
+    else if (h->jac32) GL_RD(NV, 0, float, 0, h->vA32.p);                                                          \
+    else if (h->use_idx16) GL_RD(NV, 1, double, 0, h->vA.p);                                                       \
+    else GL_RD(NV, 0, double, 0, h->vA.p);                                                                         \
   } while (0)
   // one launch per row-length class: the LDS footprint (2 * cap * 512 B per wave) decides the occupancy, so the
   // (few) long rows of an unstructured mesh must not size it for everybody
@@ -1043,58 +917,23 @@ void gl_rd_assemble(glims_ctx* h, const double* c, const double* b, const double
                      : part == GL_PART_INTERIOR ? n_int : p.bucket_count[bk] - n_int;
     if (grid <= 0) continue;
     const int32_t* list = p.bucket_slices[bk]->p + (part == GL_PART_BOUNDARY ? n_int : 0);
-    if (h->pair_A) {   // Jacobian in the slot-pair layout (fp64 or, with the option, fp32): default configuration only
-      const size_t ldsp = (size_t)2 * cap * GL_WAVE * sizeof(double);
-#define GL_RDP(NV, AT, APTR)                                                                                        \
-  do {                                                                                                             \
-    set_lds(k_rd_assemble<NV, 0, 24, 1, AT, 1>, ldsp);                                                             \
-    hipLaunchKernelGGL((k_rd_assemble<NV, 0, 24, 1, AT, 1>), dim3(grid), dim3(GL_WAVE), ldsp, h->st, list,          \
-                       h->n_own, p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, p.win_ok.p, p.cslice_ptr.p,     \
-                       p.cslots.p, p.cw.p, p.diag_k.p, h->vS.p, APTR, c, b, b2, r_out, r2_out, h->dinv.p, fx,        \
-                       2.0 * h->opt.dt, partials, cap, h->tune_rd_remap);                                          \
-  } while (0)
-      if (h->jac32) {
-        if (h->nv == 3) GL_RDP(3, float, h->vA32.p); else GL_RDP(4, float, h->vA32.p);
-      } else {
-        if (h->nv == 3) GL_RDP(3, double, h->vA.p); else GL_RDP(4, double, h->vA.p);
-      }
-#undef GL_RDP
-      continue;
-    }
-    if (h->jac32) {   // Jacobian stored in single precision (option): default kernel configuration only
-      const size_t lds32 = (size_t)2 * cap * GL_WAVE * sizeof(double);
-#define GL_RD32(NV)                                                                                                 \
-  do {                                                                                                             \
-    set_lds(k_rd_assemble<NV, 0, 24, 1, float>, lds32);                                                            \
-    hipLaunchKernelGGL((k_rd_assemble<NV, 0, 24, 1, float>), dim3(grid), dim3(GL_WAVE), lds32, h->st, list,         \
-                       h->n_own, p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, p.win_ok.p, p.cslice_ptr.p,     \
-                       p.cslots.p, p.cw.p, p.diag_k.p, h->vS.p, h->vA32.p, c, b, b2, r_out, r2_out, h->dinv.p, fx,   \
-                       2.0 * h->opt.dt, partials, cap, h->tune_rd_remap);                                          \
-  } while (0)
-      if (h->nv == 3) GL_RD32(3); else GL_RD32(4);
-#undef GL_RD32
-      continue;
-    }
     const size_t lds = (size_t)2 * cap * GL_WAVE * sizeof(double);
-    if (h->nv == 3) {
-      if (h->tune_rd_nt) GL_RD(3, 1); else GL_RD(3, 0);
-    } else {
-      if (h->tune_rd_nt) GL_RD(4, 1); else GL_RD(4, 0);
-    }
+    if (h->nv == 3) GL_RDV(3); else GL_RDV(4);
   }
+#undef GL_RDV
 #undef GL_RD
-#undef GL_RD2
-#undef GL_RD3
   GL_HIP(hipGetLastError());
 }
 
-// Blocks per SpMV launch: every block owns a contiguous chunk of slices; with fused dots each of its 4 waves emits
-// one partial sum, i.e. a launch fills 4 * gl_spmv_grid() slots.
+// Blocks per SpMV launch: every block owns a contiguous chunk of slices; with fused dots each block emits one
+// partial sum, i.e. a launch fills gl_spmv_grid() slots.
 // (one slice per wave: ~16x more blocks than fit on the chip, so the dispatcher balances the tail; equal-length
 // persistent blocks measured 25 % slower because 2048 blocks do not fit a residency of 7 blocks/CU in one round)
 int gl_spmv_grid(int n_launch) { return std::max(1, (n_launch + 3) / 4); }
 
-// Generic entry used by the solver: slice subset + fused dots.
+// Generic entry used by the solver: slice subset + fused dot product (r != nullptr).
+// Kernel configuration (measured best): 4 entries in flight per lane, non-temporal value / column
+// streams, blocks dealt to the XCDs in chunks of 64, 16-bit column codes wherever a slice has them.
 void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* slice_list, const double* vals,
                     const double* x, double* y, const uint8_t* fixed, const double* addv, const double* r,
                     double* partials, int partial_off, const int* done, const float* vals32) {
@@ -1102,56 +941,26 @@ void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* s
   const DevPattern& p = h->pat;
   const int grid = gl_spmv_grid(n_launch);
   const int chunk = (n_launch + grid - 1) / grid;
-  const int remap = slice_list ? 0 : h->tune_xcd_remap;   // 0 plain, 1 contiguous eighths, G > 1 chunks of G blocks
-  if (h->pair_A && (vals == h->vA.p || (vals32 && vals32 == h->vA32.p))) {
-    // Newton Jacobian in the slot-pair layout (default kernel configuration only; tuning knobs do not apply)
-#define GL_SPMV_PAIR(DOTS, VT, VPTR)                                                                                  \
-  hipLaunchKernelGGL((k_spmv<DOTS, 4, 1, 1, VT, 1>), dim3(grid), dim3(256), 0, st, n_launch, chunk, slice_list,        \
-                     h->n_own, p.slice_ptr.p, p.cols.p, p.cols16p.p, p.win_base.p, p.win_ok.p, p.diag_k.p, VPTR, x, y, \
-                     fixed, addv, r, partials, partial_off, done, remap)
-    if (vals32) {
-      if (r) GL_SPMV_PAIR(1, float, vals32); else GL_SPMV_PAIR(0, float, vals32);
-    } else {
-      if (r) GL_SPMV_PAIR(1, double, vals); else GL_SPMV_PAIR(0, double, vals);
-    }
-#undef GL_SPMV_PAIR
-    GL_HIP(hipGetLastError());
-    return;
-  }
-  if (vals32) {   // single-precision operator copy: only the default kernel configuration is built for it
-    if (r)
-      hipLaunchKernelGGL((k_spmv<1, 4, 1, 1, float>), dim3(grid), dim3(256), 0, st, n_launch, chunk, slice_list,
-                         h->n_own, p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, p.win_ok.p, p.diag_k.p, vals32,
-                         x, y, fixed, addv, r, partials, partial_off, done, remap);
-    else
-      hipLaunchKernelGGL((k_spmv<0, 4, 1, 1, float>), dim3(grid), dim3(256), 0, st, n_launch, chunk, slice_list,
-                         h->n_own, p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, p.win_ok.p, p.diag_k.p, vals32,
-                         x, y, fixed, addv, r, partials, partial_off, done, remap);
-    GL_HIP(hipGetLastError());
-    return;
-  }
-#define GL_SPMV3(DOTS, UNR, NT, CIDX)                                                                              \
-  hipLaunchKernelGGL((k_spmv<DOTS, UNR, NT, CIDX>), dim3(grid), dim3(256), 0, st, n_launch, chunk, slice_list,      \
-                     h->n_own, p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, p.win_ok.p, p.diag_k.p, vals, x, y, \
-                     fixed,                                                                                         \
+  const int remap = slice_list ? 0 : GL_XCD_CHUNK;
+  const bool pair = h->pair_A && (vals == h->vA.p || (vals32 && vals32 == h->vA32.p));
+#define GL_SPMV4(DOTS, CIDX, VT, PAIR, VPTR, C16)                                                                    \
+  hipLaunchKernelGGL((k_spmv<DOTS, 4, 1, CIDX, VT, PAIR>), dim3(grid), dim3(256), 0, st, n_launch, chunk, slice_list,  \
+                     h->n_own, p.slice_ptr.p, p.cols.p, C16, p.win_base.p, p.win_ok.p, p.diag_k.p, VPTR, x, y, fixed, \
                      addv, r, partials, partial_off, done, remap)
-#define GL_SPMV(DOTS, UNR, NT)                                                       \
-  do {                                                                               \
-    if (h->tune_idx16) GL_SPMV3(DOTS, UNR, NT, 1); else GL_SPMV3(DOTS, UNR, NT, 0); \
+#define GL_SPMV3(DOTS, CIDX)                                                                                         \
+  do {                                                                                                               \
+    if (pair && vals32) GL_SPMV4(DOTS, 1, float, 1, vals32, p.cols16p.p);                                            \
+    else if (pair) GL_SPMV4(DOTS, 1, double, 1, vals, p.cols16p.p);                                                  \
+    else if (vals32) GL_SPMV4(DOTS, CIDX, float, 0, vals32, p.cols16.p);                                             \
+    else GL_SPMV4(DOTS, CIDX, double, 0, vals, p.cols16.p);                                                          \
   } while (0)
-  const int unr = h->tune_spmv_unroll;
-  if (h->tune_spmv_nt == 2) {
-    if (r) { if (unr == 8) GL_SPMV(1, 8, 2); else GL_SPMV(1, 4, 2); }
-    else   { if (unr == 8) GL_SPMV(0, 8, 2); else GL_SPMV(0, 4, 2); }
-  } else if (h->tune_spmv_nt) {
-    if (r) { if (unr == 8) GL_SPMV(1, 8, 1); else GL_SPMV(1, 4, 1); }
-    else   { if (unr == 8) GL_SPMV(0, 8, 1); else GL_SPMV(0, 4, 1); }
+  if (r) {
+    if (h->use_idx16) GL_SPMV3(1, 1); else GL_SPMV3(1, 0);
   } else {
-    if (r) { if (unr == 8) GL_SPMV(1, 8, 0); else GL_SPMV(1, 4, 0); }
-    else   { if (unr == 8) GL_SPMV(0, 8, 0); else GL_SPMV(0, 4, 0); }
+    if (h->use_idx16) GL_SPMV3(0, 1); else GL_SPMV3(0, 0);
   }
-#undef GL_SPMV
 #undef GL_SPMV3
+#undef GL_SPMV4
   GL_HIP(hipGetLastError());
 }
 
@@ -1162,25 +971,17 @@ void gl_launch_spmv_block(glims_ctx* h, hipStream_t st, int n_launch, const int3
   const DevPattern& p = h->pat;
   const int grid = gl_spmv_grid(n_launch);
   const int chunk = (n_launch + grid - 1) / grid;
-  const int remap = slice_list ? 0 : 1;
+  const int remap = slice_list ? 0 : GL_XCD_CHUNK;
 #define GL_BLK(BS, DOTS)                                                                                         \
   do {                                                                                                           \
     if (single_precision_operator)                                                                               \
       hipLaunchKernelGGL((k_spmv_block2<BS, DOTS, 2, float>), dim3(grid), dim3(256), 0, st, n_launch, chunk,      \
                          slice_list, h->n_own, p.slice_ptr.p, p.cols.p, h->vKel32.p, x, y, fixed, r, partials,    \
-                         partial_off, done, slice_list ? 0 : h->tune_xcd_remap);                                 \
-    else if (h->tune_blk_variant == 1)                                                                           \
+                         partial_off, done, remap);                                                          \
+    else                                                                                                         \
       hipLaunchKernelGGL((k_spmv_block2<BS, DOTS, 2, double>), dim3(grid), dim3(256), 0, st, n_launch, chunk,     \
                          slice_list, h->n_own, p.slice_ptr.p, p.cols.p, h->vKel.p, x, y, fixed, r, partials,      \
-                         partial_off, done, slice_list ? 0 : h->tune_xcd_remap);                                 \
-    else if (h->tune_blk_variant == 2)                                                                           \
-      hipLaunchKernelGGL((k_spmv_block2<BS, DOTS, 4, double>), dim3(grid), dim3(256), 0, st, n_launch, chunk,     \
-                         slice_list, h->n_own, p.slice_ptr.p, p.cols.p, h->vKel.p, x, y, fixed, r, partials,      \
-                         partial_off, done, slice_list ? 0 : h->tune_xcd_remap);                                 \
-    else                                                                                                         \
-      hipLaunchKernelGGL((k_spmv_block<BS, DOTS>), dim3(grid), dim3(256), 0, st, n_launch, chunk, slice_list,     \
-                         h->n_own, p.slice_ptr.p, p.cols.p, h->vKel.p, x, y, fixed, r, partials, partial_off,     \
-                         done, remap);                                                                           \
+                         partial_off, done, remap);                                                          \
   } while (0)
   if (h->dim == 2) {
     if (r) GL_BLK(2, 1); else GL_BLK(2, 0);
@@ -1195,30 +996,6 @@ void gl_spmv_scalar(glims_ctx* h, const double* vals, const double* x, double* y
   gl_launch_spmv(h, h->st, h->pat.n_slices, nullptr, vals, x, y,
                  masked && h->have_fixed_c ? h->fixed_c.p : nullptr, nullptr, nullptr, nullptr, 0, nullptr,
                  vals == h->vA.p && h->jac32 ? h->vA32.p : nullptr);
-}
-
-void gl_spmv_pairs_study(glims_ctx* h, const double* vals, const double* x, double* y) {
-  const DevPattern& p = h->pat;
-  if (h->study_pvals.n != (size_t)p.total_entries) {
-    h->study_pvals.alloc((size_t)p.total_entries);
-    h->study_pc16.alloc((size_t)p.total_entries);
-  }
-  hipLaunchKernelGGL(k_to_pairs, dim3(p.n_slices), dim3(GL_WAVE), 0, h->st, p.n_slices, p.slice_ptr.p, vals, p.cols16.p,
-                     h->study_pvals.p, h->study_pc16.p);
-  const int grid = gl_spmv_grid(p.n_slices);
-  const int chunk = (p.n_slices + grid - 1) / grid;
-  hipLaunchKernelGGL(k_spmv_pairs<0>, dim3(grid), dim3(256), 0, h->st, p.n_slices, chunk, h->n_own, p.slice_ptr.p,
-                     h->study_pc16.p, p.win_base.p, h->study_pvals.p, x, y, h->tune_xcd_remap);
-  GL_HIP(hipGetLastError());
-}
-
-void gl_spmv_pairs_study_run(glims_ctx* h, const double* x, double* y) {   // layout already converted
-  const DevPattern& p = h->pat;
-  const int grid = gl_spmv_grid(p.n_slices);
-  const int chunk = (p.n_slices + grid - 1) / grid;
-  hipLaunchKernelGGL(k_spmv_pairs<0>, dim3(grid), dim3(256), 0, h->st, p.n_slices, chunk, h->n_own, p.slice_ptr.p,
-                     h->study_pc16.p, p.win_base.p, h->study_pvals.p, x, y, h->tune_xcd_remap);
-  GL_HIP(hipGetLastError());
 }
 
 void gl_spmv_block(glims_ctx* h, const double* x, double* y, bool masked) {
@@ -1246,11 +1023,11 @@ void gl_launch_mg_fine(glims_ctx* h, int mode, const double* xin, const double* 
   const int chunk = (p.n_slices + grid - 1) / grid;
   const uint8_t* fx = h->have_fixed_u ? h->fixed_u.p : nullptr;
   const bool half = h->vKel16.n != 0 && h->mg.half_smoother;
-  const bool c16 = h->tune_idx16 != 0 && h->stats.nnz_idx16 == h->stats.nnz_padded;   // every slice has 16-bit codes
+  const bool c16 = h->use_idx16 && h->stats.nnz_idx16 == h->stats.nnz_padded;   // every slice has 16-bit codes
 #define GL_MGF3(BS, MODE, VT, VPTR, SC, CIDX)                                                                        \
   hipLaunchKernelGGL((k_mg_fine<BS, MODE, 2, VT, CIDX>), dim3(grid), dim3(256), 0, h->st, p.n_slices, chunk,          \
                      h->n_own, p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, VPTR, SC, h->m_dinv.p, fx, xin, r, \
-                     d, xout, c1, c2, h->tune_xcd_remap, done)
+                     d, xout, c1, c2, GL_XCD_CHUNK, done)
 #define GL_MGF2(BS, MODE, CIDX)                                                                                      \
   do {                                                                                                               \
     if (half) GL_MGF3(BS, MODE, _Float16, (const _Float16*)h->vKel16.p, h->mg.half_unscale, CIDX);                    \

@@ -21,16 +21,10 @@
 
 #include <omp.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstring>
-
-void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* slice_list, const double* vals,
-                    const double* x, double* y, const uint8_t* fixed, const double* addv, const double* r,
-                    double* partials, int partial_off, const int* done, const float* vals32 = nullptr);
-void gl_launch_spmv_block(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* slice_list, const double* x,
-                          double* y, const uint8_t* fixed, const double* r, double* partials, int partial_off,
-                          const int* done, bool single_precision_operator = false);
 
 namespace {
 
@@ -279,50 +273,6 @@ __global__ __launch_bounds__(256) void k_cg_update(int64_t n_own, const double* 
   block_sum2(pg, pr, pv);
 }
 
-// Node-local all-reduce of red[0..nq) (see NodeMail): called by every thread of the (single) final reduction block.
-// Sums in rank order on every rank -> the same bits everywhere, hence identical decisions.
-__device__ __forceinline__ void node_allreduce(double* __restrict__ red, int nq, const NodeMail nm) {
-  __syncthreads();   // red[] written by threads < nq
-  if (threadIdx.x >= GL_WAVE) return;
-  const int lane = threadIdx.x;
-  unsigned long long seq = 0;
-  if (lane == 0) {
-    seq = *nm.seq + 1ull;
-    *nm.seq = seq;
-  }
-  seq = __shfl(seq, 0, GL_WAVE);
-  double* bank = nm.slots + (size_t)(seq & 1ull) * nm.world * 8;
-  if (lane == 0) {
-    double* mine = bank + (size_t)nm.rank * 8;
-    for (int q = 0; q < nq; ++q) __hip_atomic_store(mine + 1 + q, red[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(mine), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  bool ok = true;
-  if (lane < nm.world) {
-    const unsigned long long* f = reinterpret_cast<const unsigned long long*>(bank + (size_t)lane * 8);
-    const long long t0 = wall_clock64();   // 100 MHz
-    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
-      __builtin_amdgcn_s_sleep(4);
-      if (wall_clock64() - t0 > nm.timeout_ticks) {   // default: a peer that is a minute late is not coming
-        ok = false;
-        break;
-      }
-    }
-  }
-  ok = __all(ok);
-  __threadfence_system();
-  if (lane < nq) {
-    double t = 0.0;
-    if (ok)
-      for (int r = 0; r < nm.world; ++r)
-        t += __hip_atomic_load(bank + (size_t)r * 8 + 1 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    else
-      t = __builtin_nan("");
-    red[lane] = t;
-  }
-  if (!ok && lane == 0) *nm.err = 1;
-}
-
 // red[q] = sum_b partials[b*nq + q] in a fixed order -> bitwise reproducible.  Two stages: `nb1` blocks each sum a
 // contiguous range into tmp[blk*nq + q], then one block sums tmp (a single block over ~1e5 partials took 98 us).
 __global__ __launch_bounds__(256) void k_reduce_stage1(int n, int nq, int per_block,
@@ -386,14 +336,28 @@ __global__ __launch_bounds__(1024) void k_reduce(int n, int nq, const double* __
   if (nm.slots) node_allreduce(red, nq, nm);
 }
 
-// PCG reduction: red = ( sum pv[.][0] , sum ps[.] , sum pv[.][1] ) = (gamma, delta, rr), fixed order
+// PCG reduction: red = ( sum pv[.][0] , sum ps[.] , sum pv[.][1] ) = (gamma, delta, rr), fixed order.
+//   ps: one delta partial per SpMV block (up to ~40 k at 10 M rows: four independent chains per thread, the loop is
+//   latency-bound), pv: one (gamma, rr) pair per block of the vector kernel.  In a partitioned run the same block
+//   performs the node-local all-reduce (NodeMail).
 __global__ __launch_bounds__(1024) void k_reduce_cg(int ns, const double* __restrict__ ps, int nv,
                                                      const double* __restrict__ pv, double* __restrict__ red,
                                                      const int* __restrict__ done, const NodeMail nm) {
   if (done && *done) return;
   __shared__ double sm[16][3];
   double v[3] = {0.0, 0.0, 0.0};
-  for (int i = threadIdx.x; i < ns; i += 1024) v[1] += ps[i];
+  {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int i = threadIdx.x;
+    for (; i + 3072 < ns; i += 4096) {
+      a0 += ps[i];
+      a1 += ps[i + 1024];
+      a2 += ps[i + 2048];
+      a3 += ps[i + 3072];
+    }
+    for (; i < ns; i += 1024) a0 += ps[i];
+    v[1] = (a0 + a1) + (a2 + a3);
+  }
   for (int i = threadIdx.x; i < nv; i += 1024) {
     v[0] += pv[(size_t)i * 2];
     v[2] += pv[(size_t)i * 2 + 1];
@@ -773,22 +737,24 @@ struct CgVecs {
   bool mg = false;          // u = V-cycle(r) (elasticity multigrid) instead of the (block-)Jacobi scaling
 };
 
+// w = A u with the fused dot product: one delta partial per SpMV block, interior launch first (slots [0, nbi)), then the
+// boundary launch (slots [nbi, nbi + nbb))
 static void apply_with_halo(glims_ctx* h, const CgVecs& v) {
   const DevPattern& p = h->pat;
   const bool split = h->world > 1 && h->n_peers > 0;
   if (!split) {
     if (v.vals) {
-      const bool timed = h->time_spmv && h->tev_used + 2 <= h->tev.size();
-      if (timed) GL_HIP(hipEventRecord(h->tev[h->tev_used++], h->st));
+      const bool timed = h->timing(glims_ctx::TK_SPMV);
+      if (timed) h->tick(glims_ctx::TK_SPMV);
       gl_launch_spmv(h, h->st, p.n_slices, nullptr, v.vals, v.u, v.w, v.fixed, nullptr, v.r, h->partials.p, 0,
                      h->done.p, v.vals32);
-      if (timed) GL_HIP(hipEventRecord(h->tev[h->tev_used++], h->st));
+      if (timed) h->tick(glims_ctx::TK_SPMV);
     } else
       gl_launch_spmv_block(h, h->st, p.n_slices, nullptr, v.u, v.w, v.fixed, v.r, h->partials.p, 0, h->done.p, v.k32);
     return;
   }
   // interior slices overlap with the xGMI transfer; boundary slices run once the ghosts have landed
-  halo_start(h, v.u, v.bs, /*prepacked=*/h->tune_fused_pack != 0 && !v.mg);
+  halo_start(h, v.u, v.bs, /*prepacked=*/!v.mg);
   const int nbi = p.n_interior > 0 ? gl_spmv_grid(p.n_interior) : 0;   // partial-sum slots of the interior launch
   if (v.vals)
     gl_launch_spmv(h, h->st, p.n_interior, p.interior_slices.p, v.vals, v.u, v.w, v.fixed, nullptr, v.r,
@@ -815,10 +781,10 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
                     double* res_out, bool defer = false) {
   const DevPattern& p = h->pat;
   const bool split = h->world > 1 && h->n_peers > 0;
-  // delta partials: one per wave of the SpMV launch(es)
-  const int nblocks = 4 * (split ? (p.n_interior > 0 ? gl_spmv_grid(p.n_interior) : 0) +
-                                       (p.n_boundary > 0 ? gl_spmv_grid(p.n_boundary) : 0)
-                                 : gl_spmv_grid(p.n_slices));
+  // delta partials: one per block of the SpMV launch(es)
+  const int nblocks = split ? (p.n_interior > 0 ? gl_spmv_grid(p.n_interior) : 0) +
+                                  (p.n_boundary > 0 ? gl_spmv_grid(p.n_boundary) : 0)
+                            : gl_spmv_grid(p.n_slices);
   const int64_t n = h->n_own;
   // scal = [ping | pong | info{its, rr}]
   const unsigned g = grid_for(n);
@@ -831,7 +797,7 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
     GL_HIP(hipGetLastError());                                                          \
   } while (0)
   PackMap pm;
-  if (split && h->tune_fused_pack && h->n_send > 0) {
+  if (split && h->n_send > 0) {
     pm.ref = h->send_ref.p;
     pm.ptr = h->send_slot_ptr.p;
     pm.slot = h->send_slot.p;
@@ -854,28 +820,21 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
   double* info_dev = h->scal.p + 2 * SC_COUNT;
   while (enq < maxit + 1) {
     int want = batch;
-    if (hint > 0) want = enq == 0 ? hint + (defer ? h->tune_defer_extra : 1) : std::max(2, std::min(batch, hint / 4 + 1));
+    if (hint > 0) want = enq == 0 ? hint + (defer ? 2 : 1) : std::max(2, std::min(batch, hint / 4 + 1));
     const int nb = std::min(want, maxit + 1 - enq);
     for (int j = 0; j < nb; ++j) {
       const double* prev = h->scal.p + ((enq + j) & 1) * SC_COUNT;
       double* cur = h->scal.p + ((enq + j + 1) & 1) * SC_COUNT;
       apply_with_halo(h, v);
-      // delta partials: one per SpMV wave (a first reduction stage only above 64 k of them); gamma / rr partials: one
-      // pair per block of the previous vector kernel
-      const double* ps = h->partials.p;
-      int ns = nblocks;
-      if (nblocks > 65536) {
-        const int per_block = 1024;
-        ns = (nblocks + per_block - 1) / per_block;
-        hipLaunchKernelGGL(k_reduce_stage1, dim3(ns), dim3(256), 0, h->st, nblocks, 1, per_block, h->partials.p,
-                           h->partials2.p, h->done.p);
-        ps = h->partials2.p;
-      }
-      hipLaunchKernelGGL(k_reduce_cg, dim3(1), dim3(1024), 0, h->st, ns, ps, (int)g, h->partials_v.p, h->red.p,
-                         h->done.p, h->nm);
+      // gamma / rr partials: one pair per block of the previous vector kernel; delta: one per SpMV block
+      hipLaunchKernelGGL(k_reduce_cg, dim3(1), dim3(1024), 0, h->st, nblocks, h->partials.p, (int)g, h->partials_v.p,
+                         h->red.p, h->done.p, h->nm);
       allreduce_sum(h, h->red.p, 3);
+      const bool timed_upd = v.vals && h->timing(glims_ctx::TK_UPDATE);
+      if (timed_upd) h->tick(glims_ctx::TK_UPDATE);
       GL_VEC(k_cg_update, n, h->red.p, prev, cur, info_dev, h->done.p, tol2, v.p, v.s, v.x, v.r, v.u, v.w, v.dinv,
-             h->partials_v.p, h->tune_upd_nt, pm, ext);
+             h->partials_v.p, /*nt=*/0, pm, ext);
+      if (timed_upd) h->tick(glims_ctx::TK_UPDATE);
       precondition();
     }
     enq += nb;
@@ -914,7 +873,10 @@ static void rd_sweep(glims_ctx* h, const double* b2, double* norms /*[2]*/, Mail
     if (mass_for_b2)
       gl_launch_spmv(h, h->st, p.n_slices, nullptr, h->vM.p, h->c.p, h->b2.p, nullptr, load, nullptr, nullptr, 0,
                      nullptr);
+    const bool timed = h->timing(glims_ctx::TK_SWEEP);
+    if (timed) h->tick(glims_ctx::TK_SWEEP);
     gl_rd_assemble(h, h->c.p, h->b.p, b2, h->cg_r.p, h->cg_r2.p, h->partials.p);
+    if (timed) h->tick(glims_ctx::TK_SWEEP);
   } else {
     halo_start(h, h->c.p, 1);
     if (mass_for_b2)
@@ -945,8 +907,9 @@ int gl_step(glims_ctx* h, int n_steps) {
   const bool extrapolate = (o.flags & GLIMS_FLAG_EXTRAPOLATE_GUESS) != 0;
   const double* load = h->have_load_rd ? h->load_rd.p : nullptr;
   int status = GLIMS_OK;
-  if (h->time_spmv && h->tev.empty()) {
-    h->tev.resize(8192);
+  if (h->opt.time_kernels && h->tev.empty()) {
+    h->tev.resize(16384);
+    h->tev_cat.assign(h->tev.size() / 2, 0);
     for (hipEvent_t& e : h->tev) GL_HIP(hipEventCreate(&e));
   }
   h->tev_used = 0;
@@ -986,7 +949,7 @@ int gl_step(glims_ctx* h, int n_steps) {
         break;
       }
       // A(c_k) delta = -R(c_k);  the update is accumulated straight into c (x0 = 0  <=>  x = c_k)
-      const double tol_lin = std::max(std::max(o.cg_atol, h->tune_lin_margin * target), o.cg_rtol * nr);
+      const double tol_lin = std::max(std::max(o.cg_atol, 0.5 * target), o.cg_rtol * nr);
       if (it == 0 && (o.flags & GLIMS_FLAG_WARM_START) && !extrapolate) {   // both options own the c_old buffer
         // initial guess of the first linear solve = the previous step's total increment: same linear system, same
         // solution, the Krylov iteration just starts closer.  One SpMV with the already assembled A(c^n).
@@ -1007,7 +970,7 @@ int gl_step(glims_ctx* h, int n_steps) {
       int64_t its = 0;
       double res = 0.0;
       const int slot = std::min(it, 7);
-      const int cs = cg_solve(h, v, tol_lin, o.cg_maxit, h->cg_hint[slot], &its, &res, /*defer=*/h->tune_defer != 0);
+      const int cs = cg_solve(h, v, tol_lin, o.cg_maxit, h->cg_hint[slot], &its, &res, /*defer=*/true);
       const bool deferred = its < 0;
       if (!deferred) {
         h->cg_hint[slot] = (int)its;
@@ -1059,18 +1022,31 @@ int gl_step(glims_ctx* h, int n_steps) {
   GL_HIP(hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
   h->stats.ms_steps += ms;
   if (h->tev_used >= 2) {
-    // launches that the decision word turned into no-ops last a few microseconds: leave them out of the average
-    std::vector<float> d(h->tev_used / 2);
-    float dmax = 0.f;
-    for (size_t q = 0; q < d.size(); ++q) {
-      GL_HIP(hipEventElapsedTime(&d[q], h->tev[2 * q], h->tev[2 * q + 1]));
-      dmax = std::max(dmax, d[q]);
+    // launches that the decision word turned into no-ops last a few microseconds: leave them out of sums and medians
+    std::vector<float> d[3];
+    for (size_t q = 0; q < h->tev_used / 2; ++q) {
+      float t = 0.f;
+      GL_HIP(hipEventElapsedTime(&t, h->tev[2 * q], h->tev[2 * q + 1]));
+      d[std::min<int>(2, h->tev_cat[q])].push_back(t);
     }
-    for (float t : d)
-      if (t > 0.2f * dmax) {
-        h->stats.ms_spmv_steps += t;
-        h->stats.n_spmv_steps++;
+    double* sums[3] = {&h->stats.ms_spmv_steps, &h->stats.ms_sweep_steps, &h->stats.ms_update_steps};
+    int64_t* cnts[3] = {&h->stats.n_spmv_steps, &h->stats.n_sweep_steps, &h->stats.n_update_steps};
+    double* meds[3] = {&h->stats.us_spmv_median, &h->stats.us_sweep_median, &h->stats.us_update_median};
+    for (int c = 0; c < 3; ++c) {
+      float dmax = 0.f;
+      for (float t : d[c]) dmax = std::max(dmax, t);
+      std::vector<float> real;
+      for (float t : d[c])
+        if (t > 0.2f * dmax) real.push_back(t);
+      for (float t : real) {
+        *sums[c] += t;
+        ++*cnts[c];
       }
+      if (!real.empty()) {
+        std::nth_element(real.begin(), real.begin() + real.size() / 2, real.end());
+        *meds[c] = 1e3 * real[real.size() / 2];
+      }
+    }
     h->tev_used = 0;
   }
   return status;

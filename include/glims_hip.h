@@ -19,6 +19,14 @@
  *   - displacement dofs are node-major interleaved: dof = node*dim + component
  *     (the reference's mixed space W = [P1^dim, P1], simulation_tumor_growth.py:67-72);
  *   - all floating point is IEEE fp64.
+ *
+ * Environment variables read by the library (everything else is a glims_options field):
+ *   GLIMS_VERBOSE        any value: timing lines of the set-up phases on stderr
+ *   GLIMS_HOST_THREADS   OpenMP team of the host-side symbolic phase (default: the CPUs this process may use,
+ *                        divided by the ranks on the host)
+ *   GLIMS_WIN_LIMIT      TEST HOOK: at most this many (<= 32) column windows per 64-row slice before a slice falls back
+ *                        to 4-byte column indices -- lets tests/ exercise the mixed 16-bit / 32-bit index path on
+ *                        meshes whose slices would all be compressible
  */
 #ifndef GLIMS_HIP_H
 #define GLIMS_HIP_H
@@ -76,6 +84,9 @@ typedef struct glims_options {
                              inverse computed once on the host                                      default 216   */
   double mg_h_factor;     /* spacing of the first auxiliary Cartesian grid in units of the mesh width
                              (lattice meshes: of the lattice constant per axis)                    default 2.0   */
+  int    time_kernels;    /* HIP-event pairs on the handle's stream around hot kernels of glims_step: 1 = the Krylov
+                             SpMV, 2 = also the assembly sweep and the PCG vector update; results in
+                             glims_stats.*_steps / us_*_median (bench.py's in-step roofline figures)  default 0     */
 } glims_options;
 
 #define GLIMS_PRECOND_BLOCK_JACOBI 0
@@ -88,6 +99,8 @@ typedef struct glims_options {
                                            the same fixed point); takes effect at glims_setup */
 #define GLIMS_FLAG_MG_FP32_SMOOTHER 8     /* OFF by default.  The level-0 smoother of the elasticity multigrid streams a
                                            single-precision copy of K_el instead of the (scaled) half-precision one */
+#define GLIMS_FLAG_INT32_COLUMNS 16       /* OFF by default.  Stream the 4-byte column indices everywhere instead of the 16-bit
+                                           (window, offset) codes (same bits in every result; takes effect at glims_setup) */
 #define GLIMS_FLAG_WARM_START 2         /* first linear solve of a step starts from the previous step's increment
                                            (ignored when GLIMS_FLAG_EXTRAPOLATE_GUESS is set) */
 
@@ -108,7 +121,7 @@ typedef struct glims_stats {
   int64_t nnz_padded;       /* stored SELL-64 entries */
   int64_t n_corners;        /* (row, cell) incidences */
   int64_t nnz_idx16;        /* stored entries whose column is streamed as a 16-bit (window, offset) code */
-  double  ms_spmv_steps;    /* GLIMS_TIME_SPMV=1 only: HIP-event time of the Krylov SpMV launches inside glims_step */
+  double  ms_spmv_steps;    /* time_kernels = 1 only: HIP-event time of the Krylov SpMV launches inside glims_step */
   int64_t n_spmv_steps;     /*   ... and how many of them really ran (launches skipped behind the decision word excluded) */
   /* ---- ABI 2 */
   int64_t failed_steps;     /* time steps whose Newton / Krylov solve gave up (not counted in `steps`) */
@@ -118,6 +131,14 @@ typedef struct glims_stats {
   double  ms_mg_setup;      /* wall time of the last hierarchy set-up (transfer lists, Galerkin products, eigenvalue
                                estimates, coarse inverse) */
   double  ms_mech;          /* wall time spent in elasticity solves */
+  /* time_kernels = 1 only; launches skipped behind the decision word (a few microseconds) are left out */
+  double  ms_sweep_steps;   /* assembly sweeps (k_rd_assemble) inside glims_step */
+  int64_t n_sweep_steps;
+  double  ms_update_steps;  /* PCG vector updates (k_cg_update) of the RD solves inside glims_step */
+  int64_t n_update_steps;
+  double  us_spmv_median;   /* medians over the last glims_step call */
+  double  us_sweep_median;
+  double  us_update_median;
 } glims_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------------------- */
@@ -192,8 +213,7 @@ int glims_reset_stats(glims_ctx* h);
 /* y = Op x, repeated `reps` times on the handle's stream and timed with HIP events (ms_total out, may be NULL).
  * which: 0 = current RD Jacobian A(c), 1 = S, 2 = M (scalar, [n_nodes]);  3 = K_el, ([n_nodes*dim], unconstrained);
  *        4 = G (x [n_nodes] -> y [n_nodes*dim]);  5 = A(c) through the kernel variant with the Krylov iteration's
- *        fused dot product, 6 = A(c) through a study kernel on a slot-pair copy of the layout (timing studies).
- *        Ghost rows of y are returned as 0. */
+ *        fused dot product.  Ghost rows of y are returned as 0. */
 int glims_apply(glims_ctx* h, int which, const double* x, double* y, int reps, double* ms_total);
 
 /* Assembles A(c) and the Newton residual R(c; c_prev) for host vectors (ghost rows 0):

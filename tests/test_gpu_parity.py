@@ -440,8 +440,9 @@ def test_baseline_configs_complete_runs_match_the_c_oracle(backend, name):
 def test_column_index_streams_are_bitwise_equivalent(backend, monkeypatch):
     """
     The SpMV and the assembly sweep read the columns either as int32 or as 16-bit (window, offset) codes; slices that
-    need more windows than the table holds use int32.  All three situations (all codes / none / mixed, forced through
-    GLIMS_WIN_LIMIT) must produce the same bits, on a mesh with several thousand slices and on a tiny one.
+    need more windows than the table holds use int32.  All three situations (all codes / none [GLIMS_FLAG_INT32_COLUMNS]
+    / mixed, forced through the test hook GLIMS_WIN_LIMIT) must produce the same bits, on a mesh with several thousand
+    slices and on a tiny one.
     """
     rng = np.random.default_rng(5)
     for mesh in (BoxMesh((0, 0, 0), (1.0, 1.3, 0.8), 30, 28, 26), _case(3, ragged=True)[0], _case(2)[0]):
@@ -450,12 +451,12 @@ def test_column_index_streams_are_bitwise_equivalent(backend, monkeypatch):
         x = rng.standard_normal(n)
         c0 = np.exp(-4 * ((mesh.points - mesh.points.mean(0)) ** 2).sum(1))
         outs = []
-        for env in (dict(GLIMS_IDX16="1"), dict(GLIMS_IDX16="0"), dict(GLIMS_IDX16="1", GLIMS_WIN_LIMIT="2"),
-                    dict(GLIMS_IDX16="1", GLIMS_WIN_LIMIT="0")):
+        for int32, env in ((False, {}), (True, {}), (False, dict(GLIMS_WIN_LIMIT="2")), (False, dict(GLIMS_WIN_LIMIT="0"))):
             monkeypatch.delenv("GLIMS_WIN_LIMIT", raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
-            h = _handle(backend, mesh, lab, 1.0, mechanics=False)
+            h = _handle(backend, mesh, lab, 1.0, mechanics=False,
+                        flags=backend.FLAG_WARM_START | (backend.FLAG_INT32_COLUMNS if int32 else 0))
             st = h.stats()
             y = h.apply(1, x)[0]
             r = h.rd_residual(c0 + 0.1 * x, c0)
@@ -521,10 +522,9 @@ def test_elasticity_history_guess_changes_only_the_iteration_count(backend, monk
     c0 = np.exp(-0.2 * ((mesh.points - np.array([5.0, 4.5, 4.0])) ** 2).sum(1))
     o = _oracle(mesh, lab, 1.0, dirichlet_u=(dofs, vals))
     out = {}
-    monkeypatch.setenv("GLIMS_MECH_MIXED", "2")                    # fp32 inner operator + fp64 refinement, also on this small mesh
     for depth in ("0", "6"):
-        monkeypatch.setenv("GLIMS_MHIST", depth)
-        h = _handle(backend, mesh, lab, 1.0)
+        # mech_mixed = 2: fp32 inner operator + fp64 refinement, also on this small mesh
+        h = _handle(backend, mesh, lab, 1.0, mech_mixed=2, mech_history=int(depth))
         h.set_dirichlet_u(dofs, vals)
         h.set_state(c0)
         us = []
