@@ -4,7 +4,8 @@ Node-based mesh partition for the single-node multi-GPU path (one process per GP
 The reference's only parallel mode is DOLFIN's MPI domain decomposition (README.md:142-183; glimslib contributes
 nothing but ``mesh.mpi_comm()`` handles).  This module produces the same kind of decomposition as plain arrays:
 
-  * nodes are ordered along a Morton curve and cut into ``n_parts`` contiguous, equally sized ranges (owner map);
+  * nodes are ordered along a Morton curve and cut into ``n_parts`` contiguous ranges of equal work (cumulative
+    cells-per-node, i.e. equal nnz / equal (row, cell) incidences; owner map);
   * rank r keeps every cell that touches one of its nodes; the cells' foreign vertices are its ghosts;
   * local numbering = [owned (ascending global id) | ghosts grouped by owner rank, ascending global id];
   * the send list to peer p is "my owned nodes that share a cell with a node owned by p", ascending global id --
@@ -49,14 +50,41 @@ def morton_keys(points):
     return key
 
 
-def node_owners(points, n_parts):
-    """owner[node] in [0, n_parts): contiguous equal-count ranges of the Morton order."""
+def node_weights(n_nodes, cells):
+    """
+    Work per matrix row, up to a factor: the number of cells at the node (= its (row, cell) incidences, what the
+    assembly sweep streams) + 1.  On simplex meshes the row length is an affine function of it (interior node of a
+    tetrahedral mesh: neighbours = cells / 2 + 2), so equal sums of this weight are equal nnz AND equal incidences
+    to within a few per cent (tests/test_partition_balance.py) -- without building the adjacency on the host.
+    """
+    w = np.bincount(np.asarray(cells).reshape(-1), minlength=n_nodes).astype(np.float64)
+    return w + 1.0
+
+
+def node_owners(points, n_parts, cells=None):
+    """
+    owner[node] in [0, n_parts): contiguous ranges of the Morton order.  With ``cells`` the ranges carry equal WORK
+    (cumulative node_weights, SURVEY section 8e "equal-nnz ranges"); without, equal node counts.
+    DOLFIN/ParMETIS balance vertices too, under mpirun (README.md:142-158); on the structured BASELINE meshes the two
+    rules coincide, on an unstructured mesh (rows 6..46 long) equal counts leave ~5-10 % more nnz on some rank.
+    """
     n = len(points)
     if n_parts == 1:
         return np.zeros(n, dtype=np.int32)
     order = np.argsort(morton_keys(points), kind='stable')
     owner = np.empty(n, dtype=np.int32)
-    bounds = (np.arange(n_parts + 1, dtype=np.int64) * n) // n_parts
+    if cells is None:
+        bounds = (np.arange(n_parts + 1, dtype=np.int64) * n) // n_parts
+    else:
+        cum = np.cumsum(node_weights(n, cells)[order])
+        targets = cum[-1] * np.arange(1, n_parts, dtype=np.float64) / n_parts
+        inner = np.searchsorted(cum, targets, side='left') + 1
+        bounds = np.concatenate([[0], inner, [n]]).astype(np.int64)
+        bounds = np.maximum.accumulate(bounds)
+        for r in range(1, n_parts):                       # every rank owns at least one node
+            bounds[r] = max(bounds[r], bounds[r - 1] + 1)
+        bounds = np.minimum(bounds, n - (n_parts - np.arange(n_parts + 1)))
+        bounds[0], bounds[-1] = 0, n
     for r in range(n_parts):
         owner[order[bounds[r]:bounds[r + 1]]] = r
     return owner
@@ -124,9 +152,10 @@ def build_local_part(points, cells, owner, rank, n_parts):
                      recv_count.astype(np.int64))
 
 
-def partition_mesh(points, cells, n_parts, rank=None):
-    """Returns the LocalPart of ``rank`` (or the list of all parts when rank is None)."""
-    owner = node_owners(points, n_parts)
+def partition_mesh(points, cells, n_parts, rank=None, balance='work'):
+    """Returns the LocalPart of ``rank`` (or the list of all parts when rank is None).  ``balance``: 'work' (equal
+    cumulative row work per rank, the default) or 'nodes' (equal node counts)."""
+    owner = node_owners(points, n_parts, cells if balance == 'work' else None)
     if rank is not None:
         return build_local_part(points, cells, owner, rank, n_parts)
     return [build_local_part(points, cells, owner, r, n_parts) for r in range(n_parts)]

@@ -1,0 +1,94 @@
+"""
+Method of manufactured solutions on the HIP path: the discrete forms against the CONTINUOUS equations that the
+reference's UFL states (simulation_tumor_growth.py:110-120), not against this repository's own restatement.
+
+  RD block   -div(D grad c) - rho c (1 - c) = s            (steady state of F_rd, reached by implicit steps)
+  mechanics  -div sigma(u) + grad(gamma (2 mu + d lambda) c) = f,   sigma = 2 mu eps(u) + lambda tr eps(u) I
+             (F_m: int sigma(u):eps(v) - int sigma(v):(c gamma I) - int f.v, integrated by parts)
+
+A smooth solution is chosen, the source that makes it exact is derived symbolically (sympy), the loads enter through
+glims_set_rd_load / glims_set_mech_load as M * (nodal source) (the mass operator hook), Dirichlet data are the exact
+solution on the boundary.  P1 elements: the L2 error must fall with order 2 under uniform refinement (three levels).
+A wrong factor, sign or missing term in any form shows up as an error that does not converge at all.
+"""
+import numpy as np
+import pytest
+import sympy as sp
+
+from glimslib_amd.mesh import BoxMesh, RectangleMesh
+
+pytestmark = pytest.mark.gpu
+
+D_, RHO, GAMMA, E_, NU = 0.7, 1.3, 0.2, 2.5, 0.3
+MU = E_ / (2 * (1 + NU))
+LAM = E_ * NU / ((1 + NU) * (1 - 2 * NU))
+
+
+def _symbols(dim):
+    return sp.symbols('x y z')[:dim]
+
+
+def _manufactured(dim):
+    X = _symbols(dim)
+    pi = sp.pi
+    c = sp.Rational(3, 10) + sp.Rational(1, 5) * sp.prod([sp.sin(pi * x) for x in X]) + sp.Rational(1, 10) * X[0] * X[-1]
+    u = [sp.sin(pi * X[0]) * sp.cos(pi * X[1] / 2) * (1 + (X[-1] if dim == 3 else 0)) / 10,
+         X[0] * (1 - X[1]) * sp.exp(X[0] / 2) / 8]
+    if dim == 3:
+        u.append(sp.sin(pi * X[2] / 2) * (X[0] + X[1] ** 2) / 12)
+    lap = lambda f: sum(sp.diff(f, x, 2) for x in X)
+    s = -D_ * lap(c) - RHO * c * (1 - c)
+    div_u = sum(sp.diff(u[a], X[a]) for a in range(dim))
+    kappa = GAMMA * (2 * MU + dim * LAM)
+    f = [-(MU * lap(u[a]) + (LAM + MU) * sp.diff(div_u, X[a])) + kappa * sp.diff(c, X[a]) for a in range(dim)]
+    fn = lambda e: sp.lambdify(X, e, 'numpy')
+    return fn(c), fn(s), [fn(e) for e in u], [fn(e) for e in f]
+
+
+def _solve(backend, dim, n):
+    mesh = RectangleMesh((0, 0), (1, 1), n, n) if dim == 2 else BoxMesh((0, 0, 0), (1, 1, 1), n, n, n)
+    P = mesh.points
+    cols = [P[:, a] for a in range(dim)]
+    c_f, s_f, u_f, f_f = _manufactured(dim)
+    bc = lambda v: np.broadcast_to(np.asarray(v, dtype=np.float64), (len(P),)).copy()
+    c_ex, s_n = bc(c_f(*cols)), bc(s_f(*cols))
+    u_ex = np.stack([bc(g(*cols)) for g in u_f], axis=1)
+    f_n = np.stack([bc(g(*cols)) for g in f_f], axis=1)
+    fac = mesh.facets()
+    bn = np.unique(fac['vertices'][fac['exterior']])
+    dofs = (bn[:, None] * dim + np.arange(dim)).ravel()
+    dt = 20.0
+    h = backend.Handle(P, mesh.cells, np.ones(mesh.num_cells(), np.int32))
+    h.set_materials([0, D_], [0, RHO], [0, GAMMA], [1, E_], [0.3, NU])
+    h.set_options(dt=dt, mech_rtol=1e-12)
+    h.setup(True)
+    h.set_rd_load(dt * h.apply(2, s_n)[0])                        # dt * int s phi_i  with s interpolated
+    h.set_mech_load(np.stack([h.apply(2, f_n[:, a])[0] for a in range(dim)], axis=1))
+    h.set_dirichlet_c(bn, c_ex[bn])
+    h.set_dirichlet_u(dofs, u_ex.reshape(-1)[dofs])
+    h.set_state(c_ex)
+    assert h.step(12) == 0                                         # backward Euler into the discrete steady state
+    c1 = h.get_state(want_u=False)[0]
+    assert h.step(1) == 0
+    c2 = h.get_state(want_u=False)[0]
+    assert np.abs(c2 - c1).max() < 1e-11                           # steady
+    # mechanics with the EXACT concentration, so that the two error sources stay separate
+    h.set_state(c_ex)
+    assert h.solve_mechanics() == 0
+    u = h.get_state()[1].reshape(-1, dim)
+    l2 = lambda e: np.sqrt(max(e @ h.apply(2, e)[0], 0.0))
+    ec = l2(c2 - c_ex)
+    eu = np.sqrt(sum(l2(u[:, a] - u_ex[:, a]) ** 2 for a in range(dim)))
+    h.close()
+    return ec, eu
+
+
+@pytest.mark.parametrize("dim,levels", [(2, (16, 32, 64)), (3, (12, 24, 48))])   # n = 8 in 3-D is pre-asymptotic (1.90)
+def test_manufactured_solutions_converge_with_order_two(backend, dim, levels):
+    errs = [_solve(backend, dim, n) for n in levels]
+    ec, eu = np.array([e[0] for e in errs]), np.array([e[1] for e in errs])
+    oc, ou = np.log2(ec[:-1] / ec[1:]), np.log2(eu[:-1] / eu[1:])
+    print("dim %d: L2 errors c %s (orders %s), u %s (orders %s)" %
+          (dim, ["%.2e" % e for e in ec], ["%.2f" % o for o in oc], ["%.2e" % e for e in eu], ["%.2f" % o for o in ou]))
+    assert oc.min() > 1.9 and ou.min() > 1.9
+    assert ec[-1] < 2e-3 and eu[-1] < 2e-3
