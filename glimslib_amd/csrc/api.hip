@@ -519,7 +519,8 @@ int glims_apply(glims_ctx* h, int which, const double* x, double* y, int reps, d
   return guarded(h, [&]() {
     GL_REQUIRE(h->is_setup, "glims_apply before glims_setup");
     GL_REQUIRE(x && y && reps >= 1, "bad arguments");
-    GL_REQUIRE(which >= 0 && which <= 5, "unknown operator");
+    GL_REQUIRE(which >= 0 && which <= 7 && which != 6, "unknown operator");
+    if (which == 7) GL_REQUIRE(h->have_state, "the matrix-free product needs the state c (glims_set_state)");
     const int d = h->dim;
     const bool blk_in = which == 3, blk_out = which == 3 || which == 4;
     if (blk_out) GL_REQUIRE(h->have_mech, "mechanics operators not assembled");
@@ -531,7 +532,9 @@ int glims_apply(glims_ctx* h, int which, const double* x, double* y, int reps, d
     h->have_mload = false;
     GL_HIP(hipEventRecord(h->ev_a, h->st));
     for (int r = 0; r < reps; ++r) {
-      if (which == 5)   // A x with the fused dot product of the Krylov iteration (timing studies)
+      if (which == 7)   // matrix-free A(c) x from the incidence lists (measurement only)
+        gl_rd_matfree(h, h->c.p, xin.p, yout.p);
+      else if (which == 5)   // A x with the fused dot product of the Krylov iteration (timing studies)
         gl_launch_spmv(h, h->st, h->pat.n_slices, nullptr, h->vA.p, xin.p, yout.p, nullptr, nullptr, xin.p,
                        h->partials.p, 0, nullptr, h->jac32 ? h->vA32.p : nullptr);
       else if (which <= 2)

@@ -357,6 +357,7 @@ void gl_rd_assemble(glims_ctx* h, const double* c, const double* b, const double
                     double* partials /*[gl_rd_grid][2]*/, int part = GL_PART_ALL);
 void gl_spmv_scalar(glims_ctx* h, const double* vals, const double* x, double* y, bool masked);
 void gl_apply_G(glims_ctx* h, const double* c, double* y);
+void gl_rd_matfree(glims_ctx* h, const double* c, const double* x, double* y);
 void gl_spmv_block(glims_ctx* h, const double* x, double* y, bool masked);
 void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* slice_list, const double* vals,
                     const double* x, double* y, const uint8_t* fixed, const double* addv, const double* r,

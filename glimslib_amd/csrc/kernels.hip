@@ -387,6 +387,86 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
 }
 
 // ---------------------------------------------------------------------------------------------------
+// MATRIX-FREE variant of y = A(c) x, for the A/B that SURVEY 7.1 step 5 asks for (glims_apply which = 7; the solver
+// does not use it): A(c) = S + 2 dt N(c) is never stored, N(c)'s row is rebuilt from the (row, cell) incidence lists
+// -- exactly the sweep's phase 2 -- and applied to the gathered x on the fly.  Per row it streams the incidence
+// records (12 B each, 23.7 per row on tetrahedra), S (8 B per entry) and the column codes, i.e. ~3x the bytes of the
+// assembled product; measured (profiles/r02_matfree_ab.txt): 1.38 ms and 5.15 GB against 0.33 ms and 1.77 GB at 10 M rows.
+// ---------------------------------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(GL_WAVE) void k_rd_matfree(
+    const int32_t* __restrict__ slice_list, int64_t n_own, const int64_t* __restrict__ slice_ptr,
+    const int32_t* __restrict__ cols, const int64_t* __restrict__ cslice_ptr, const uint32_t* __restrict__ cslots,
+    const double* __restrict__ cw, const uint8_t* __restrict__ diag_k, const double* __restrict__ vS,
+    const double* __restrict__ c, const double* __restrict__ x, double* __restrict__ y, double two_dt, int max_len) {
+  extern __shared__ double lds[];
+  double* acc = lds;
+  double* cn = lds + (size_t)max_len * GL_WAVE;
+  double* xn = lds + (size_t)2 * max_len * GL_WAVE;
+  const int lane = threadIdx.x;
+  const int s = slice_list[xcd_chunk_remap(blockIdx.x, gridDim.x, 4 * GL_XCD_CHUNK)];
+  const int64_t row = (int64_t)s * GL_WAVE + lane;
+  const int64_t base = slice_ptr[s], cbase = cslice_ptr[s];
+  const int len = (int)((slice_ptr[s + 1] - base) >> 6), clen = (int)((cslice_ptr[s + 1] - cbase) >> 6);
+  const int32_t* cc = cols + base + lane;
+  for (int k = 0; k < len; k += 8) {
+    int32_t ci8[8];
+    double c8[8], x8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ci8[j] = cc[(int64_t)min(k + j, len - 1) * GL_WAVE];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      c8[j] = c[ci8[j]];
+      x8[j] = x[ci8[j]];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (k + j < len) {
+        cn[(k + j) * GL_WAVE + lane] = c8[j];
+        xn[(k + j) * GL_WAVE + lane] = x8[j];
+        acc[(k + j) * GL_WAVE + lane] = 0.0;
+      }
+  }
+  const int dk = diag_k[row];
+  const double ci = cn[dk * GL_WAVE + lane];
+  const uint32_t* sl = cslots + cbase + lane;
+  const double* wp = cw + cbase + lane;
+  auto corner = [&](double w, uint32_t slots) {
+    if (w == 0.0) return;
+    int k[NV];
+    double cv[NV], av[NV], st = 0.0;
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+      k[m] = (int)((slots >> (8 * m)) & 255u);
+      cv[m] = cn[k[m] * GL_WAVE + lane];
+      av[m] = acc[k[m] * GL_WAVE + lane];
+    }
+#pragma unroll
+    for (int m = 0; m < NV; ++m) st += cv[m];
+#pragma unroll
+    for (int m = 0; m < NV; ++m)
+      acc[k[m] * GL_WAVE + lane] = av[m] + ((k[m] == dk) ? w * (4.0 * ci + 2.0 * st) : w * (ci + cv[m] + st));
+  };
+  {
+    int q = 0;
+    for (; q + 24 <= clen; q += 24) corner_batch<24, 0>(wp, sl, q, corner);
+    for (; q + 4 <= clen; q += 4) corner_batch<4, 0>(wp, sl, q, corner);
+    for (; q < clen; ++q) corner_batch<1, 0>(wp, sl, q, corner);
+  }
+  const double* sv = vS + base + lane;
+  double r = 0.0;
+  for (int k = 0; k < len; k += 8) {
+    double S8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) S8[j] = sv[(int64_t)min(k + j, len - 1) * GL_WAVE];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (k + j < len) r += (S8[j] + two_dt * acc[(k + j) * GL_WAVE + lane]) * xn[(k + j) * GL_WAVE + lane];
+  }
+  if (row < n_own) y[row] = r;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // hot: SELL-64 SpMV  y = A x  (+ addv), optional Dirichlet row mask, optional fused dot products
 //   DOTS: partials[b] = y.x over the rows of logical block b (the PCG's delta = w.u; r.u and r.r come from the
 //   vector-update kernel, which has r and u in registers anyway, so this kernel never reads r)
@@ -1068,4 +1148,27 @@ void gl_make_half_copy(glims_ctx* h) {
                      (_Float16*)h->vKel16.p, 1.0 / mx);
   GL_HIP(hipGetLastError());
   h->mg.half_unscale = mx;
+}
+
+// y = (S + 2 dt N(c)) x without the assembled Jacobian (measurement only, see k_rd_matfree)
+void gl_rd_matfree(glims_ctx* h, const double* c, const double* x, double* y) {
+  const DevPattern& p = h->pat;
+  for (size_t bk = 0; bk < p.bucket_cap.size(); ++bk) {
+    const int cap = p.bucket_cap[bk];
+    const int grid = p.bucket_count[bk];
+    if (grid <= 0) continue;
+    const size_t lds = (size_t)3 * cap * GL_WAVE * sizeof(double);
+    if (h->nv == 3) {
+      set_lds(k_rd_matfree<3>, lds);
+      hipLaunchKernelGGL(k_rd_matfree<3>, dim3(grid), dim3(GL_WAVE), lds, h->st, p.bucket_slices[bk]->p, h->n_own,
+                         p.slice_ptr.p, p.cols.p, p.cslice_ptr.p, p.cslots.p, p.cw.p, p.diag_k.p, h->vS.p, c, x, y,
+                         2.0 * h->opt.dt, cap);
+    } else {
+      set_lds(k_rd_matfree<4>, lds);
+      hipLaunchKernelGGL(k_rd_matfree<4>, dim3(grid), dim3(GL_WAVE), lds, h->st, p.bucket_slices[bk]->p, h->n_own,
+                         p.slice_ptr.p, p.cols.p, p.cslice_ptr.p, p.cslots.p, p.cw.p, p.diag_k.p, h->vS.p, c, x, y,
+                         2.0 * h->opt.dt, cap);
+    }
+  }
+  GL_HIP(hipGetLastError());
 }

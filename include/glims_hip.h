@@ -213,7 +213,11 @@ int glims_reset_stats(glims_ctx* h);
 /* y = Op x, repeated `reps` times on the handle's stream and timed with HIP events (ms_total out, may be NULL).
  * which: 0 = current RD Jacobian A(c), 1 = S, 2 = M (scalar, [n_nodes]);  3 = K_el, ([n_nodes*dim], unconstrained);
  *        4 = G (x [n_nodes] -> y [n_nodes*dim]);  5 = A(c) through the kernel variant with the Krylov iteration's
- *        fused dot product.  Ghost rows of y are returned as 0. */
+ *        fused dot product;  7 = the MATRIX-FREE product (S + 2 dt N(c)) x rebuilt from the (row, cell) incidence lists
+ *        for the current state c (equals which = 0 once A(c) has been assembled for that state; not used by the solver:
+ *        measured 4.2x slower than the assembled product at 10 M rows -- 1.38 ms and 5.15 GB against 0.33 ms and 1.77 GB --
+ *        profiles/r02_matfree_ab.txt).
+ *        Ghost rows of y are returned as 0. */
 int glims_apply(glims_ctx* h, int which, const double* x, double* y, int reps, double* ms_total);
 
 /* Assembles A(c) and the Newton residual R(c; c_prev) for host vectors (ghost rows 0):

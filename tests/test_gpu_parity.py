@@ -673,3 +673,24 @@ def test_long_run_breakdown_is_the_schemes_and_happens_at_the_same_step_as_in_th
     assert st['steps'] == fail_dev - 1 and st['failed_steps'] == 1
     h.close()
     co.close()
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_matrix_free_product_equals_the_assembled_one(backend, dim):
+    """glims_apply(which = 7) rebuilds (S + 2 dt N(c)) x from the incidence lists for the current state; it must equal
+    the assembled Jacobian's product for the same state and the oracle's (the operator the A/B of
+    tools/ab_matfree.py times)."""
+    mesh, lab = _case(dim)
+    n = mesh.num_vertices()
+    rng = np.random.default_rng(40 + dim)
+    dt = 0.7
+    h = _handle(backend, mesh, lab, dt, mechanics=False)
+    o = _oracle(mesh, lab, dt)
+    c = rng.random(n)
+    x = rng.standard_normal(n)
+    h.set_state(c)
+    h.rd_residual(c, c)
+    ya, ym = h.apply(0, x)[0], h.apply(7, x)[0]
+    ref = o.rd_jacobian(c) @ x
+    assert rel_l2(ym, ref) < 1e-14 and rel_l2(ya, ref) < 1e-14
+    h.close()
