@@ -108,6 +108,7 @@ struct HostPattern {
   int64_t nnz = 0, n_corners = 0;
 };
 
+int gl_host_threads();   // OpenMP team the host phases may use (affinity mask, cgroup quota, ranks per host)
 void build_host_pattern(HostPattern& hp, int dim, int64_t n_nodes, int64_t n_own, int64_t n_cells,
                         const double* xyz, const int32_t* cells);
 

@@ -707,7 +707,9 @@ void gl_mesh_metrics(glims_ctx* h, const HostPattern& hp, const double* xyz_old)
   const int d = h->dim;
   const int64_t n = h->n_own;
   mm.xyz.resize((size_t)n * d);
-#pragma omp parallel for schedule(static)
+  const int nth = gl_host_threads();   // not the runtime's default team (one thread per visible hardware thread)
+  (void)nth;                           // (the device pass of the compiler does not see the OpenMP clauses)
+#pragma omp parallel for schedule(static) num_threads(nth)
   for (int64_t i = 0; i < n; ++i)
     for (int a = 0; a < d; ++a) mm.xyz[i * d + a] = xyz_old[(int64_t)hp.new2old[i] * d + a];
   for (int a = 0; a < 3; ++a) {
@@ -725,7 +727,7 @@ void gl_mesh_metrics(glims_ctx* h, const HostPattern& hp, const double* xyz_old)
   int64_t ecnt = 0;
   double ext[3];
   for (int a = 0; a < 3; ++a) ext[a] = std::max(mm.hi[a] - mm.lo[a], 1e-300);
-#pragma omp parallel
+#pragma omp parallel num_threads(nth)
   {
     double hm[3] = {1e300, 1e300, 1e300}, es = 0.0;
     int64_t ec = 0;
@@ -766,7 +768,7 @@ void gl_mesh_metrics(glims_ctx* h, const HostPattern& hp, const double* xyz_old)
       break;
     }
     int bad = 0;
-#pragma omp parallel for schedule(static) reduction(+ : bad)
+#pragma omp parallel for schedule(static) reduction(+ : bad) num_threads(nth)
     for (int64_t i = 0; i < n; ++i) {
       const double t = (mm.xyz[i * d + a] - mm.lo[a]) / hmin[a];
       if (std::fabs(t - std::round(t)) > 1e-6) ++bad;
@@ -820,15 +822,18 @@ bool dense_spd_inverse(std::vector<double>& A, int n, double shift_rel) {
     if (!(s > 0.0)) return false;
     const double ljj = std::sqrt(s);
     L[(size_t)j * n + j] = ljj;
-#pragma omp parallel for schedule(static) if (n - j > 256)
     for (int i = j + 1; i < n; ++i) {
       double t = L[(size_t)i * n + j];
       for (int k = 0; k < j; ++k) t -= L[(size_t)i * n + k] * L[(size_t)j * n + k];
       L[(size_t)i * n + j] = t / ljj;
     }
   }
-  // inverse column by column: L y = e_c, L^T x = y
-#pragma omp parallel for schedule(dynamic, 8)
+  // inverse column by column: L y = e_c, L^T x = y.  The team is sized by the CPUs this process may really use: the
+  // OpenMP default of one thread per visible hardware thread (256 on a GPU box that grants 16 cores) made this loop
+  // take 0.5 s for a 375 x 375 matrix.
+  const int nth = std::max(1, std::min(gl_host_threads(), 16));
+  (void)nth;
+#pragma omp parallel for schedule(dynamic, 8) num_threads(nth)
   for (int c = 0; c < n; ++c) {
     std::vector<double> y(n, 0.0);
     for (int i = c; i < n; ++i) {
@@ -854,6 +859,15 @@ void mg_setup_t(glims_ctx* h) {
   const DevPattern& p = h->pat;
   const int64_t n = h->n_own;
   const double t_start = omp_get_wtime();
+  const bool verbose = getenv("GLIMS_VERBOSE") != nullptr;
+  double t_last = t_start;
+  auto lap = [&](const char* what) {
+    if (!verbose) return;
+    GL_HIP(hipStreamSynchronize(h->st));
+    const double t = omp_get_wtime();
+    fprintf(stderr, "glims multigrid set-up: %-42s %8.1f ms\n", what, 1e3 * (t - t_last));
+    t_last = t;
+  };
   mg.clear();
   GL_REQUIRE(h->vKel32.n != 0 && h->vKel.n != 0, "multigrid set-up before the elasticity operator was assembled");
   GL_REQUIRE(!mm.xyz.empty(), "mesh metrics missing");
@@ -878,7 +892,7 @@ void mg_setup_t(glims_ctx* h) {
       mg.H[a] = H[a];
     }
     GL_REQUIRE(g1.nn < (int64_t(1) << 31), "auxiliary grid too large");
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(gl_host_threads())
     for (int64_t i = 0; i < n; ++i) {
       int64_t lin = 0, stride = 1;
       for (int a = 0; a < D; ++a) {
@@ -913,6 +927,7 @@ void mg_setup_t(glims_ctx* h) {
                             "(strongly graded mesh); use GLIMS_PRECOND_BLOCK_JACOBI");
     for (int a = 0; a < D; ++a) H[a] *= 0.5 * (rc + 1);   // edges then span at most two cells
   }
+  lap("grid choice, node -> cell map, reach");
   mg.S = 1;
   for (int a = 0; a < D; ++a) mg.S *= 2 * mg.R + 1;
   {   // children lists: counting sort of the mesh nodes by cell
@@ -925,6 +940,7 @@ void mg_setup_t(glims_ctx* h) {
     mg.cell_nodes.upload(nodes, h->st);
     GL_HIP(hipStreamSynchronize(h->st));
   }
+  lap("children lists (counting sort, upload)");
   const size_t nd0 = (size_t)h->n_nodes * BS;
   mg.x.alloc_zero(nd0, h->st);
   mg.x2.alloc_zero(nd0, h->st);
@@ -977,6 +993,7 @@ void mg_setup_t(glims_ctx* h) {
     GL_HIP(hipGetLastError());
   }
 
+  lap("Galerkin products, diagonal inverses");
   // ---- lambda_max(Dinv A) per smoothed level: power iteration -----------------------------------------------------
   gl_block_dinv(h);
   mg.half_smoother = (h->opt.flags & GLIMS_FLAG_MG_FP32_SMOOTHER) == 0;
@@ -1012,6 +1029,7 @@ void mg_setup_t(glims_ctx* h) {
     L.lam = (std::isfinite(lam) && lam > 0.0) ? lam : 2.0;
   }
 
+  lap("half copy, eigenvalue estimates");
   // ---- coarsest level: dense inverse on the host ------------------------------------------------------------------
   {
     MgLevel& L = *mg.lv.back();
@@ -1059,6 +1077,7 @@ void mg_setup_t(glims_ctx* h) {
     mg.coarse_inv.upload(M, h->st);
     GL_HIP(hipStreamSynchronize(h->st));
   }
+  lap("coarsest level: dense inverse");
   mg.ready = true;
   h->stats.mg_levels = (int64_t)mg.lv.size() + 1;
   h->stats.mg_complexity = 1.0 + (double)mg.entries / ((double)p.total_entries * B2);

@@ -58,7 +58,7 @@ struct KeyIdx {
 // OpenMP team for the symbolic phase: the hardware threads the process may really use.  A container often reports all
 // threads of the host while its CPU quota is a fraction of them; oversubscribed teams are slower, not faster (C4 on a
 // 16-core share of a 128-thread host: 3.4 s with 128 threads, 2.3 s with 16).  GLIMS_HOST_THREADS overrides.
-static int host_threads() {
+int gl_host_threads() {
   if (const char* e = getenv("GLIMS_HOST_THREADS")) return std::max(1, atoi(e));
   long n = omp_get_num_procs();
   cpu_set_t set;
@@ -86,7 +86,7 @@ void build_host_pattern(HostPattern& hp, int dim, int64_t n_nodes, int64_t n_own
                         const double* xyz, const int32_t* cells) {
   const bool verbose = getenv("GLIMS_VERBOSE") != nullptr;
   const int saved_threads = omp_get_max_threads();
-  omp_set_num_threads(host_threads());
+  omp_set_num_threads(gl_host_threads());
   struct Restore {
     int n;
     ~Restore() { omp_set_num_threads(n); }
