@@ -282,6 +282,11 @@ struct glims_ctx {
     if ((tev_used & 1) == 0) tev_cat[tev_used / 2] = (uint8_t)cat;
     (void)hipEventRecord(tev[tev_used++], st);
   }
+  hipEvent_t* pair(int cat) {               // a pair to be attached to one dispatch (hipExtLaunchKernelGGL)
+    tev_cat[tev_used / 2] = (uint8_t)cat;
+    tev_used += 2;
+    return &tev[tev_used - 2];
+  }
 
   // scalar operator planes (SELL-64 layout) and block planes
   dvec<double> vM, vS, vA, vKel, vG;
@@ -362,7 +367,8 @@ void gl_rd_matfree(glims_ctx* h, const double* c, const double* x, double* y);
 void gl_spmv_block(glims_ctx* h, const double* x, double* y, bool masked);
 void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* slice_list, const double* vals,
                     const double* x, double* y, const uint8_t* fixed, const double* addv, const double* r,
-                    double* partials, int partial_off, const int* done, const float* vals32 = nullptr);
+                    double* partials, int partial_off, const int* done, const float* vals32 = nullptr,
+                    hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 void gl_launch_spmv_block(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* slice_list, const double* x,
                           double* y, const uint8_t* fixed, const double* r, double* partials, int partial_off,
                           const int* done, bool single_precision_operator = false);

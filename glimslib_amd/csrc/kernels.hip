@@ -7,6 +7,7 @@
 // private LDS column acc[slot*64 + lane] (bank = lane -> conflict-free for any slot), so the segmented scatter-add
 // of FEM assembly needs neither atomics nor colouring and is bitwise reproducible.
 #include "glims_internal.h"
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -1016,17 +1017,21 @@ int gl_spmv_grid(int n_launch) { return std::max(1, (n_launch + 3) / 4); }
 // streams, blocks dealt to the XCDs in chunks of 64, 16-bit column codes wherever a slice has them.
 void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* slice_list, const double* vals,
                     const double* x, double* y, const uint8_t* fixed, const double* addv, const double* r,
-                    double* partials, int partial_off, const int* done, const float* vals32) {
+                    double* partials, int partial_off, const int* done, const float* vals32, hipEvent_t ev0,
+                    hipEvent_t ev1) {
   if (n_launch <= 0) return;
   const DevPattern& p = h->pat;
   const int grid = gl_spmv_grid(n_launch);
   const int chunk = (n_launch + grid - 1) / grid;
   const int remap = slice_list ? 0 : GL_XCD_CHUNK;
   const bool pair = h->pair_A && (vals == h->vA.p || (vals32 && vals32 == h->vA32.p));
+  // ev0 / ev1 (glims_options.time_kernels): start / stop events attached to THIS dispatch (hipExtLaunchKernelGGL) --
+  // the kernel's own timestamps, no extra packets in the queue.  hipEventRecord before and after the launch put a
+  // 5-6 us idle gap on either side of every SpMV (profiles/r02_c3_timeline.txt), 14 % of the step at 1 M rows.
 #define GL_SPMV4(DOTS, CIDX, VT, PAIR, VPTR, C16)                                                                    \
-  hipLaunchKernelGGL((k_spmv<DOTS, 4, 1, CIDX, VT, PAIR>), dim3(grid), dim3(256), 0, st, n_launch, chunk, slice_list,  \
-                     h->n_own, p.slice_ptr.p, p.cols.p, C16, p.win_base.p, p.win_ok.p, p.diag_k.p, VPTR, x, y, fixed, \
-                     addv, r, partials, partial_off, done, remap)
+  hipExtLaunchKernelGGL((k_spmv<DOTS, 4, 1, CIDX, VT, PAIR>), dim3(grid), dim3(256), 0, st, ev0, ev1, 0, n_launch,    \
+                        chunk, slice_list, h->n_own, p.slice_ptr.p, p.cols.p, C16, p.win_base.p, p.win_ok.p,         \
+                        p.diag_k.p, VPTR, x, y, fixed, addv, r, partials, partial_off, done, remap)
 #define GL_SPMV3(DOTS, CIDX)                                                                                         \
   do {                                                                                                               \
     if (pair && vals32) GL_SPMV4(DOTS, 1, float, 1, vals32, p.cols16p.p);                                            \

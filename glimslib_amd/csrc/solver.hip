@@ -744,11 +744,9 @@ static void apply_with_halo(glims_ctx* h, const CgVecs& v) {
   const bool split = h->world > 1 && h->n_peers > 0;
   if (!split) {
     if (v.vals) {
-      const bool timed = h->timing(glims_ctx::TK_SPMV);
-      if (timed) h->tick(glims_ctx::TK_SPMV);
+      hipEvent_t* ev = h->timing(glims_ctx::TK_SPMV) ? h->pair(glims_ctx::TK_SPMV) : nullptr;
       gl_launch_spmv(h, h->st, p.n_slices, nullptr, v.vals, v.u, v.w, v.fixed, nullptr, v.r, h->partials.p, 0,
-                     h->done.p, v.vals32);
-      if (timed) h->tick(glims_ctx::TK_SPMV);
+                     h->done.p, v.vals32, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr);
     } else
       gl_launch_spmv_block(h, h->st, p.n_slices, nullptr, v.u, v.w, v.fixed, v.r, h->partials.p, 0, h->done.p, v.k32);
     return;
