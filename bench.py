@@ -106,6 +106,13 @@ def main():
     ap.add_argument("--warm-start", type=int, default=None, help="override GLIMS_FLAG_WARM_START (tuning runs only)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON result of rank 0.  Libraries below us write there too (gloo announces
+    # "[Gloo] Rank r is connected to n peer ranks" on stdout when a process group forms): everything written to fd 1
+    # from here on goes to stderr, the result line is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -396,7 +403,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(None if coupled else w)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     h.close()
     if world > 1:
         dist.barrier()

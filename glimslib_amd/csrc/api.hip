@@ -95,7 +95,7 @@ int glims_options_default(glims_options* o) {
   o->flags = GLIMS_FLAG_WARM_START;
   o->mech_precond = GLIMS_PRECOND_MULTIGRID;
   o->mech_mixed = 1;
-  o->mech_history = 6;
+  o->mech_history = 8;
   o->mg_smooth = 2;
   o->mg_coarse_nodes = 216;
   o->mg_h_factor = 2.0;

@@ -1245,7 +1245,10 @@ int gl_solve_mechanics(glims_ctx* h, const double* c_dev) {
       }
       int64_t in_its = 0;
       double in_res = 0.0;
-      const int ics = cg_solve(h, v, std::max(tol, 1e-3 * nr), (int)std::max<int64_t>(1, h->opt.mech_maxit - its), 0,
+      // inner reduction 1e-6 (round 1: 1e-3): the single-precision operator is good for that, and with the
+      // solve-history guess (initial residual ~1e-6 |rhs|) ONE inner solve then reaches the target -- the loop costs
+      // two fp64 operator passes (initial residual, verification) instead of four to five
+      const int ics = cg_solve(h, v, std::max(tol, 1e-6 * nr), (int)std::max<int64_t>(1, h->opt.mech_maxit - its), 0,
                                &in_its, &in_res);
       its += in_its;
       if (ics == GLIMS_NAN) {
