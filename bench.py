@@ -163,6 +163,7 @@ def main():
         else:
             h.comm_init(rank, world, broadcast_unique_id(dist, rank))
         h.set_halo(part.peer_rank, part.send_ptr, part.send_idx, part.recv_count)
+        h.set_mg_frame(w.mesh.points.min(axis=0), w.mesh.points.max(axis=0))
         from glimslib_amd.parallel import setup_node_mailbox
         mailbox = setup_node_mailbox(h, dist, rank)
         if rank == 0:

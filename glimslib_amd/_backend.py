@@ -97,6 +97,7 @@ SIGNATURES = {
     "glims_comm_mailbox": (C.c_int, [_h, C.c_char_p]),
     "glims_comm_mailbox_selftest": (C.c_int, [_h]),
     "glims_set_halo": (C.c_int, [_h, C.c_int, _i32p, _i64p, _i32p, _i64p]),
+    "glims_set_mg_frame": (C.c_int, [_h, _dp, _dp]),
     "glims_set_transport": (C.c_int, [_h, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
@@ -317,6 +318,12 @@ class Handle:
         self._transport_refs = (halo_cb, allreduce_cb)
         self._check(self.lib.glims_set_transport(self._h, int(rank), int(world), C.cast(halo_cb, C.c_void_p),
                                                  C.cast(allreduce_cb, C.c_void_p), None))
+
+    def set_mg_frame(self, lo, hi):
+        """Bounding box of the WHOLE (global) mesh: the elasticity multigrid of a partitioned run gets replicated coarse
+        levels on one global grid frame (see glims_set_mg_frame)."""
+        lo, hi = _f64(lo, (self.dim,)), _f64(hi, (self.dim,))
+        self._check(self.lib.glims_set_mg_frame(self._h, _ptr(lo, _dp), _ptr(hi, _dp)))
 
     def set_halo(self, peer_rank, send_ptr, send_idx, recv_count):
         pr = np.ascontiguousarray(peer_rank, dtype=np.int32)

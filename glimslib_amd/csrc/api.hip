@@ -746,6 +746,23 @@ int glims_set_transport(glims_ctx* h, int rank, int world, glims_halo_fn halo, g
   });
 }
 
+int glims_set_mg_frame(glims_ctx* h, const double* lo, const double* hi) {
+  return guarded(h, [&]() {
+    h->mg.ready = false;
+    if (!lo || !hi) {
+      h->mg_frame_set = false;
+      return GLIMS_OK;
+    }
+    for (int a = 0; a < h->dim; ++a) {
+      GL_REQUIRE(std::isfinite(lo[a]) && std::isfinite(hi[a]) && hi[a] >= lo[a], "bad bounding box");
+      h->mg_frame_lo[a] = lo[a];
+      h->mg_frame_hi[a] = hi[a];
+    }
+    h->mg_frame_set = true;
+    return GLIMS_OK;
+  });
+}
+
 int glims_set_halo(glims_ctx* h, int n_peers, const int32_t* peer_rank, const int64_t* send_ptr,
                    const int32_t* send_idx, const int64_t* recv_count) {
   return guarded(h, [&]() {

@@ -18,6 +18,10 @@
 // streams 2 B instead of 4 B of index per entry.  Slices that need more windows fall back to the 32-bit stream.
 #define GL_WIN_BITS 11
 #define GL_N_WIN 32
+// elasticity multigrid, partitioned runs with glims_set_mg_frame: the auxiliary grids are replicated on every rank; the
+// first one may have at most this many nodes (operator 27 x 9 x 4 B per node = 4 GB, residual all-reduce 100 MB per
+// cycle at the limit) -- beyond it the grid spacing is widened until it fits
+#define GL_MG_GLOBAL_NODES (4ll << 20)
 // Blocks are dealt to the 8 XCDs in chunks of this many consecutive logical blocks: neighbouring slices (overlapping x
 // gathers) share one L2 while the XCDs together still walk the matrix front to back (measured: time of the plain
 // mapping, fabric reads 2.21 -> 1.97 GB per SpMV at 10 M rows; contiguous eighths are 1-5 % slower).
@@ -161,6 +165,9 @@ struct MgGrid {
 struct MgLevel {                           // one Cartesian level
   MgGrid g;
   int f[3] = {1, 1, 1};                    // coarsening factor per axis towards the next level (1 | 2)
+  int o[3] = {0, 0, 0};                    // global index of this box's node 0 (partitioned runs; 0 otherwise)
+  int ng[3] = {1, 1, 1};                   // nodes per axis of the level's GLOBAL grid
+  bool global = false;                     // replicated on every rank (box = whole grid), residual all-reduced per cycle
   dvec<float> A;                           // [S][bs*bs][nn] stencil-major planes
   dvec<double> dinv;                       // [bs*bs][nn] inverse diagonal blocks
   dvec<double> x, x2, r, d, res;           // [bs][nn] (component-major)
@@ -176,6 +183,7 @@ struct MgHierarchy {
   dvec<double> x, x2, d, res;              // level-0 work vectors [n_nodes*bs] (ghost slots stay zero)
   double lam0 = 1.0;
   bool half_smoother = true;               // level-0 smoother streams the half-precision copy of K_el
+  bool exact_level0 = false;               // partitioned run with a global frame: level-0 passes see the ghosts (halo exchange)
   double half_unscale = 1.0;               // K_el = half_unscale * (half copy)
   std::vector<MgLevel*> lv;                // owned
   dvec<double> coarse_inv;                 // dense inverse of the coarsest operator [nc][nc], nc = lv.back()->g.nn * bs
@@ -193,7 +201,7 @@ struct MeshMetrics {
   double h_lattice[3] = {0, 0, 0};         // lattice constant per axis if the nodes form a lattice
   bool lattice = false;
   double mean_edge = 0.0;
-  std::vector<double> xyz;                 // owned nodes, internal numbering [n_own][dim]
+  std::vector<double> xyz;                 // all local nodes (owned, then ghosts), internal numbering [n_nodes][dim]
 };
 
 #ifdef __HIPCC__
@@ -314,6 +322,8 @@ struct glims_ctx {
   dvec<uint8_t> fixed_c, fixed_u;
   bool have_fixed_c = false, have_fixed_u = false, have_load_rd = false, have_mload = false;
   MgHierarchy mg;
+  bool mg_frame_set = false;               // glims_set_mg_frame: global bounding box of a partitioned mesh
+  double mg_frame_lo[3] = {0, 0, 0}, mg_frame_hi[3] = {0, 0, 0};
   MeshMetrics mm;
   dvec<double> fixed_c_val;                 // Dirichlet values of the concentration [n_nodes] (internal numbering)
   bool dirichlet_c_dirty = false;           // values not yet written into the iterate (done by the next step)
@@ -382,6 +392,7 @@ int gl_comm_selftest(glims_ctx* h);
 int gl_mailbox_selftest(glims_ctx* h);
 int gl_project(glims_ctx* h, double* rhs_dev /*[n_nodes], overwritten*/, double* x_dev /*[n_nodes]*/, double rtol);
 double gl_dot(glims_ctx* h, const double* a, const double* b, int64_t n, bool global = true);   // deterministic; host value
+void gl_allreduce_bulk(glims_ctx* h, double* dev, size_t n);   // in-place sum over ranks of a device vector (RCCL / transport)
 void gl_apply_dirichlet_c(glims_ctx* h);                                     // c[fixed] = stored values (+ halo)
 void gl_block_dinv(glims_ctx* h);                                            // m_dinv of the constrained K_el
 

@@ -67,7 +67,7 @@ __device__ __forceinline__ int v2off(const int* o, int R) {
 // how far the Galerkin product mesh -> grid reaches: max over mesh edges (i, j) of the index distance between a parent
 // of i and a parent of j (parents with non-zero weight only)
 template <int D>
-__global__ void k_mg_reach(int64_t n_own, GridDev g1, const int64_t* __restrict__ slice_ptr,
+__global__ void k_mg_reach(int64_t n_own, int64_t n_col, GridDev g1, const int64_t* __restrict__ slice_ptr,
                            const int32_t* __restrict__ cols, const int32_t* __restrict__ cell0,
                            const double* __restrict__ wgt, int* __restrict__ reach) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -78,7 +78,7 @@ __global__ void k_mg_reach(int64_t n_own, GridDev g1, const int64_t* __restrict_
   lin2v(cell0[i], g1, ci);
   for (int k = 0; k < len; ++k) {
     const int64_t j = cols[base + (int64_t)k * GL_WAVE + (i & 63)];
-    if (j >= n_own) continue;
+    if (j >= n_col) continue;
     int cj[3];
     lin2v(cell0[j], g1, cj);
 #pragma unroll
@@ -95,7 +95,8 @@ __global__ void k_mg_reach(int64_t n_own, GridDev g1, const int64_t* __restrict_
 // A1[I, off] = sum_{i child of I} sum_{j in row i, I + off parent of j} w_iI w_j(I+off) F_i K_ij F_j
 // one thread per (grid node, stencil offset): a gather in a fixed order
 template <int D>
-__global__ void k_mg_rap0(GridDev g1, int R, int S, int64_t n_own, const int32_t* __restrict__ cell_ptr,
+__global__ void k_mg_rap0(GridDev g1, int R, int S, int64_t n_own, int64_t n_col,
+                          const int32_t* __restrict__ cell_ptr,
                           const int32_t* __restrict__ cell_nodes, const int32_t* __restrict__ cell0,
                           const double* __restrict__ wgt, const int64_t* __restrict__ slice_ptr,
                           const int32_t* __restrict__ cols, const double* __restrict__ vK,
@@ -142,7 +143,7 @@ __global__ void k_mg_rap0(GridDev g1, int R, int S, int64_t n_own, const int32_t
         const int len = (int)((slice_ptr[(i >> 6) + 1] - base) >> 6);
         for (int k = 0; k < len; ++k) {
           const int64_t j = cols[base + (int64_t)k * GL_WAVE + lane];
-          if (j >= n_own) continue;   // ghost column: outside this rank's preconditioner
+          if (j >= n_col) continue;   // ghost column: dropped unless the hierarchy has a replicated (global) level
           int cj[3];
           lin2v(cell0[j], g1, cj);
           double wj = 1.0;
@@ -169,9 +170,19 @@ __global__ void k_mg_rap0(GridDev g1, int R, int S, int64_t n_own, const int32_t
   for (int e = 0; e < B2; ++e) A1[((long long)off * B2 + e) * g1.nn + I] = (float)acc[e];
 }
 
+// Transfer between two Cartesian levels.  Levels are boxes of ONE global index frame per level (partitioned runs:
+// each rank stores the box its nodes touch; the levels below the first replicated one are such local boxes):
+// global index = local index + offset, and the 2:1 relation (coarse J <-> fine 2J - 1, 2J, 2J + 1) holds between
+// GLOBAL indices.  Single GPU: all offsets are 0.
 struct Fac {
-  int f[3];
+  int f[3];    // coarsening factor per axis (1 | 2)
+  int of[3];   // global index of the fine box's node 0
+  int oc[3];   // global index of the coarse box's node 0
 };
+// local fine index of the child d (-1, 0, 1) of local coarse index I along axis a
+__device__ __forceinline__ int child_index(const Fac& fc, int a, int I, int d) {
+  return (fc.f[a] == 2 ? 2 * (I + fc.oc[a]) + d : I + fc.oc[a]) - fc.of[a];
+}
 // 1-D interpolation weight of fine index j with respect to coarse index J (factor f)
 __device__ __forceinline__ double w1d(int f, int j, int J) {
   if (f == 1) return j == J ? 1.0 : 0.0;
@@ -211,20 +222,19 @@ __global__ void k_mg_rap(GridDev gf, GridDev gc, Fac fc, int R, int S, const flo
       for (int a = 0; a < D; ++a) {
         if (fc.f[a] == 1) {
           if (dv[a] != 0) ok = false;
-          iv[a] = Iv[a];
         } else {
-          iv[a] = 2 * Iv[a] + dv[a];
           wi *= dv[a] == 0 ? 1.0 : 0.5;
         }
+        iv[a] = child_index(fc, a, Iv[a], dv[a]);
         ok = ok && iv[a] >= 0 && iv[a] < gn(gf, a);
       }
       if (!ok) continue;
       const long long i = v2lin(iv, gf);
-      // fine stencil offsets that land on a child of J: |iv + of - f J| <= f - 1
+      // fine stencil offsets that land on a child of J: |(iv + of) - f J| <= f - 1 in global indices
       int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
 #pragma unroll
       for (int a = 0; a < D; ++a) {
-        const int ctr = fc.f[a] * Jv[a] - iv[a];
+        const int ctr = fc.f[a] * (Jv[a] + fc.oc[a]) - (iv[a] + fc.of[a]);
         lo[a] = max(-R, ctr - (fc.f[a] - 1));
         hi[a] = min(R, ctr + (fc.f[a] - 1));
       }
@@ -238,7 +248,7 @@ __global__ void k_mg_rap(GridDev gf, GridDev gc, Fac fc, int R, int S, const flo
             for (int a = 0; a < D; ++a) {
               const int jv = iv[a] + of[a];
               in = in && jv >= 0 && jv < gn(gf, a);
-              wj *= w1d(fc.f[a], jv, Jv[a]);
+              wj *= w1d(fc.f[a], jv + fc.of[a], Jv[a] + fc.oc[a]);
             }
             if (!in || wj == 0.0) continue;
             const int oi = v2off<D>(of, R);
@@ -582,11 +592,10 @@ __global__ __launch_bounds__(256) void k_mg_restrict(GridDev gf, GridDev gc, Fac
     for (int a = 0; a < D; ++a) {
       if (fc.f[a] == 1) {
         if (dv[a] != 0) ok = false;
-        iv[a] = Iv[a];
       } else {
-        iv[a] = 2 * Iv[a] + dv[a];
         wi *= dv[a] == 0 ? 1.0 : 0.5;
       }
+      iv[a] = child_index(fc, a, Iv[a], dv[a]);
       ok = ok && iv[a] >= 0 && iv[a] < gn(gf, a);
     }
     if (ok) {
@@ -624,16 +633,18 @@ __global__ void k_mg_prolong(GridDev gf, GridDev gc, Fac fc, const double* __res
 #pragma unroll
     for (int a = 0; a < D; ++a) {
       const int up = (corner >> a) & 1;
+      const int gfi = iv[a] + fc.of[a];   // global fine index
       if (fc.f[a] == 1) {
         if (up) ok = false;
-        pv[a] = iv[a];
-      } else if ((iv[a] & 1) == 0) {
+        pv[a] = gfi - fc.oc[a];
+      } else if ((gfi & 1) == 0) {
         if (up) ok = false;
-        pv[a] = iv[a] >> 1;
+        pv[a] = (gfi >> 1) - fc.oc[a];
       } else {
-        pv[a] = (iv[a] >> 1) + up;
+        pv[a] = (gfi >> 1) + up - fc.oc[a];
         w *= 0.5;
       }
+      ok = ok && pv[a] >= 0 && pv[a] < gn(gc, a);
     }
     if (!ok) continue;
     const long long J = v2lin(pv, gc);
@@ -654,6 +665,23 @@ __global__ __launch_bounds__(256) void k_mg_dense(int n, const double* __restric
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
   if (lane == 0) x[row] = v;
+}
+
+__global__ void k_mg_f2d(int64_t n, const float* __restrict__ a, double* __restrict__ b) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) b[i] = (double)a[i];
+}
+__global__ void k_mg_d2f(int64_t n, const double* __restrict__ a, float* __restrict__ b) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) b[i] = (float)a[i];
+}
+__global__ void k_mg_mask_to_double(int64_t n, const uint8_t* __restrict__ m, double* __restrict__ d) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) d[i] = m[i] ? 1.0 : 0.0;
+}
+__global__ void k_mg_double_to_mask(int64_t n, const double* __restrict__ d, uint8_t* __restrict__ m) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) m[i] = d[i] != 0.0 ? 1 : 0;
 }
 
 __global__ void k_mg_fill(int64_t n, double* __restrict__ x, const uint8_t* __restrict__ fixed) {
@@ -706,11 +734,11 @@ void gl_mesh_metrics(glims_ctx* h, const HostPattern& hp, const double* xyz_old)
   MeshMetrics& mm = h->mm;
   const int d = h->dim;
   const int64_t n = h->n_own;
-  mm.xyz.resize((size_t)n * d);
+  mm.xyz.resize((size_t)h->n_nodes * d);
   const int nth = gl_host_threads();   // not the runtime's default team (one thread per visible hardware thread)
   (void)nth;                           // (the device pass of the compiler does not see the OpenMP clauses)
 #pragma omp parallel for schedule(static) num_threads(nth)
-  for (int64_t i = 0; i < n; ++i)
+  for (int64_t i = 0; i < h->n_nodes; ++i)   // ghosts keep their place in the numbering (new2old = identity there)
     for (int a = 0; a < d; ++a) mm.xyz[i * d + a] = xyz_old[(int64_t)hp.new2old[i] * d + a];
   for (int a = 0; a < 3; ++a) {
     mm.lo[a] = 1e300;
@@ -875,36 +903,106 @@ void mg_setup_t(glims_ctx* h) {
   const double hf = h->opt.mg_h_factor > 0.5 ? h->opt.mg_h_factor : 2.0;
   const int coarse_max = std::max(8, h->opt.mg_coarse_nodes);
 
+  // ---- partitioned runs: one global index frame for the auxiliary grids -------------------------------------------
+  // With glims_set_mg_frame (the global bounding box) every rank lays the SAME Cartesian grids over the mesh and all
+  // Cartesian levels are REPLICATED: each rank computes its part of the first grid's Galerkin operator (rows of its
+  // owned mesh nodes, ghost columns included -- the product is additive over the rows), the parts are summed once by
+  // an all-reduce, the coarser operators follow locally (identical on every rank); in every cycle the restricted
+  // residual is all-reduced on the first grid, and the level-0 passes see the ghost values through a halo exchange.
+  // The cycle is then the single-GPU cycle, evaluated in a distributed way: the iteration count does not depend on the
+  // number of ranks (rank-local hierarchies: 31 -> 65+ iterations at 2 ranks).  The price is redundant work on the
+  // Cartesian levels (1/8 of the mesh nodes on the first one) and 24 B per first-grid node of all-reduce per cycle;
+  // intermediate rank-local boxes of the same frame were tried and rejected: their operators are partial row sums, and
+  // smoothing with them next to an exact coarse operator made the iteration count WORSE (65 against 31 at 2 ranks).
+  const bool multi = h->world > 1;
+  const bool framed = multi && h->mg_frame_set;
+  const int64_t n_all = framed ? h->n_nodes : n;        // nodes with grid coordinates (ghosts only in framed runs)
+  bool lattice = mm.lattice;
+  double h_lat[3] = {mm.h_lattice[0], mm.h_lattice[1], mm.h_lattice[2]}, mean_edge = mm.mean_edge;
+  dvec<double> sc;                                       // scratch for the collective decisions of the set-up
+  sc.alloc_zero(8, h->st);
+  auto agree = [&](double* v, int m) {                   // sum over ranks (identity on one rank)
+    if (!multi) return;
+    GL_HIP(hipMemcpyAsync(sc.p, v, m * sizeof(double), hipMemcpyHostToDevice, h->st));
+    gl_allreduce_bulk(h, sc.p, (size_t)m);
+    GL_HIP(hipMemcpyAsync(v, sc.p, m * sizeof(double), hipMemcpyDeviceToHost, h->st));
+    GL_HIP(hipStreamSynchronize(h->st));
+  };
+  if (framed) {   // every rank must take the same decisions: lattice only if all agree, spacings averaged
+    double v[5] = {lattice ? 1.0 : 0.0, h_lat[0], h_lat[1], h_lat[2], mean_edge};
+    agree(v, 5);
+    lattice = v[0] == (double)h->world;
+    for (int a = 0; a < 3; ++a) h_lat[a] = v[1 + a] / h->world;
+    mean_edge = v[4] / h->world;
+  }
+  double flo[3], fhi[3];
+  for (int a = 0; a < 3; ++a) {
+    flo[a] = framed ? h->mg_frame_lo[a] : mm.lo[a];
+    fhi[a] = framed ? h->mg_frame_hi[a] : mm.hi[a];
+  }
+
   // ---- level 1 grid: spacing, origin, node -> cell map (host), children lists ------------------------------------
   double H[3] = {1, 1, 1};
-  for (int a = 0; a < D; ++a) H[a] = mm.lattice ? hf * mm.h_lattice[a] : hf * mm.mean_edge / 1.2;
+  for (int a = 0; a < D; ++a) H[a] = lattice ? hf * h_lat[a] : hf * mean_edge / 1.2;
   MgGrid g1;
-  std::vector<int32_t> cell0(n);
-  std::vector<double> wgt((size_t)n * D);
+  int ng1[3] = {1, 1, 1}, o1[3] = {0, 0, 0};             // global dims of level 1, offset of this rank's box
+  std::vector<int32_t> cell0(n_all);
+  std::vector<int32_t> cgl((size_t)n_all * D);           // global cell index per node and axis
+  std::vector<double> wgt((size_t)n_all * D);
   for (int attempt = 0;; ++attempt) {
+    for (int a = 0; a < D; ++a) {
+      const int cells = std::max(1, (int)std::ceil((fhi[a] - flo[a]) / H[a] - 1e-9));
+      ng1[a] = cells + 1;
+      mg.lo[a] = flo[a];
+      mg.H[a] = H[a];
+    }
+    if (framed) {   // replicated grids must fit: widen the spacing (the same decision on every rank: global numbers only)
+      double nng = 1.0;
+      for (int a = 0; a < D; ++a) nng *= ng1[a];
+      if (nng > (double)GL_MG_GLOBAL_NODES && attempt < 6) {
+        const double fac = 1.02 * std::pow(nng / (double)GL_MG_GLOBAL_NODES, 1.0 / D);
+        for (int a = 0; a < D; ++a) H[a] *= fac;
+        continue;
+      }
+    }
+    int cmin[3] = {1 << 30, 1 << 30, 1 << 30}, cmax[3] = {0, 0, 0};
+#pragma omp parallel num_threads(gl_host_threads())
+    {
+      int lmin[3] = {1 << 30, 1 << 30, 1 << 30}, lmax[3] = {0, 0, 0};
+#pragma omp for schedule(static) nowait
+      for (int64_t i = 0; i < n_all; ++i)
+        for (int a = 0; a < D; ++a) {
+          const double t = (mm.xyz[i * D + a] - flo[a]) / H[a];
+          int c = (int)std::floor(t);
+          c = std::max(0, std::min(ng1[a] - 2, c));
+          double w = t - c;
+          if (std::fabs(w) < 1e-6) w = 0.0;            // lattice-aligned nodes: exact weights, compact stencils
+          if (std::fabs(w - 1.0) < 1e-6) w = 1.0;
+          w = std::max(0.0, std::min(1.0, w));
+          wgt[i * D + a] = w;
+          cgl[i * D + a] = c;
+          lmin[a] = std::min(lmin[a], c);
+          lmax[a] = std::max(lmax[a], c);
+        }
+#pragma omp critical
+      for (int a = 0; a < D; ++a) {
+        cmin[a] = std::min(cmin[a], lmin[a]);
+        cmax[a] = std::max(cmax[a], lmax[a]);
+      }
+    }
     g1 = MgGrid();
     g1.nn = 1;
     for (int a = 0; a < D; ++a) {
-      const int cells = std::max(1, (int)std::ceil((mm.hi[a] - mm.lo[a]) / H[a] - 1e-9));
-      g1.n[a] = cells + 1;
+      o1[a] = 0;                                         // (offsets: see Fac; every level is the whole grid)
+      g1.n[a] = ng1[a];
       g1.nn *= g1.n[a];
-      mg.lo[a] = mm.lo[a];
-      mg.H[a] = H[a];
     }
     GL_REQUIRE(g1.nn < (int64_t(1) << 31), "auxiliary grid too large");
 #pragma omp parallel for schedule(static) num_threads(gl_host_threads())
-    for (int64_t i = 0; i < n; ++i) {
+    for (int64_t i = 0; i < n_all; ++i) {
       int64_t lin = 0, stride = 1;
       for (int a = 0; a < D; ++a) {
-        const double t = (mm.xyz[i * D + a] - mm.lo[a]) / H[a];
-        int c = (int)std::floor(t);
-        c = std::max(0, std::min(g1.n[a] - 2, c));
-        double w = t - c;
-        if (std::fabs(w) < 1e-6) w = 0.0;            // lattice-aligned nodes: exact weights, compact stencils
-        if (std::fabs(w - 1.0) < 1e-6) w = 1.0;
-        w = std::max(0.0, std::min(1.0, w));
-        wgt[i * D + a] = w;
-        lin += (int64_t)c * stride;
+        lin += (int64_t)(cgl[i * D + a] - o1[a]) * stride;
         stride *= g1.n[a];
       }
       cell0[i] = (int32_t)lin;
@@ -913,24 +1011,26 @@ void mg_setup_t(glims_ctx* h) {
     mg.wgt.upload(wgt, h->st);
     dvec<int> reach;
     reach.alloc_zero(1, h->st);
-    hipLaunchKernelGGL(k_mg_reach<D>, dim3(gridn(n)), dim3(256), 0, h->st, n, gdev(g1), p.slice_ptr.p, p.cols.p,
+    hipLaunchKernelGGL(k_mg_reach<D>, dim3(gridn(n)), dim3(256), 0, h->st, n, n_all, gdev(g1), p.slice_ptr.p, p.cols.p,
                        mg.cell0.p, mg.wgt.p, reach.p);
     GL_HIP(hipGetLastError());
     int rc = 0;
     GL_HIP(hipMemcpyAsync(&rc, reach.p, sizeof(int), hipMemcpyDeviceToHost, h->st));
     GL_HIP(hipStreamSynchronize(h->st));
-    if (rc <= 2) {
-      mg.R = std::max(1, rc);
+    double fl[2] = {rc > 1 ? 1.0 : 0.0, rc > 2 ? 1.0 : 0.0};
+    if (framed) agree(fl, 2);                            // the stencil radius is a property of the whole hierarchy
+    if (fl[1] == 0.0) {
+      mg.R = fl[0] > 0.0 ? 2 : 1;
       break;
     }
     GL_REQUIRE(attempt < 6, "multigrid: mesh edges span more than two cells of every auxiliary grid tried "
                             "(strongly graded mesh); use GLIMS_PRECOND_BLOCK_JACOBI");
-    for (int a = 0; a < D; ++a) H[a] *= 0.5 * (rc + 1);   // edges then span at most two cells
+    for (int a = 0; a < D; ++a) H[a] *= framed ? 1.5 : 0.5 * (rc + 1);   // edges then span at most two cells
   }
   lap("grid choice, node -> cell map, reach");
   mg.S = 1;
   for (int a = 0; a < D; ++a) mg.S *= 2 * mg.R + 1;
-  {   // children lists: counting sort of the mesh nodes by cell
+  {   // children lists: counting sort of the OWNED mesh nodes by cell
     std::vector<int32_t> ptr((size_t)g1.nn + 1, 0), nodes((size_t)n);
     for (int64_t i = 0; i < n; ++i) ptr[(size_t)cell0[i] + 1]++;
     for (int64_t c = 0; c < g1.nn; ++c) ptr[c + 1] += ptr[c];
@@ -946,46 +1046,99 @@ void mg_setup_t(glims_ctx* h) {
   mg.x2.alloc_zero(nd0, h->st);
   mg.d.alloc_zero(nd0, h->st);
   mg.res.alloc_zero(nd0, h->st);
+  // constrained-dof mask including the ghosts (their owners know): columns of constrained ghost dofs are eliminated
+  // from this rank's part of the Galerkin products like every other constrained column
+  dvec<uint8_t> fx_all;
+  const uint8_t* fxr = fx;
+  if (framed && fx) {
+    dvec<double> fd;
+    fd.alloc_zero(nd0, h->st);
+    hipLaunchKernelGGL(k_mg_mask_to_double, dim3(gridn(n * BS)), dim3(256), 0, h->st, n * BS, fx, fd.p);
+    gl_halo_exchange(h, fd.p, BS);
+    fx_all.alloc(nd0);
+    hipLaunchKernelGGL(k_mg_double_to_mask, dim3(gridn((long long)nd0)), dim3(256), 0, h->st, (int64_t)nd0, fd.p, fx_all.p);
+    GL_HIP(hipGetLastError());
+    GL_HIP(hipStreamSynchronize(h->st));
+    fxr = fx_all.p;
+  }
 
   // ---- Galerkin products ------------------------------------------------------------------------------------------
-  auto new_level = [&](const MgGrid& g) {
+  auto new_level = [&](const MgGrid& g, const int* off, const int* ng, bool global) {
     MgLevel* L = new MgLevel();
     L->g = g;
+    for (int a = 0; a < 3; ++a) {
+      L->o[a] = off[a];
+      L->ng[a] = ng[a];
+    }
+    L->global = global;
     L->A.alloc((size_t)mg.S * B2 * g.nn);
     L->dinv.alloc((size_t)B2 * g.nn);
     for (dvec<double>* v : {&L->x, &L->x2, &L->r, &L->d, &L->res}) v->alloc_zero((size_t)BS * g.nn, h->st);
     mg.lv.push_back(L);
     return L;
   };
-  MgLevel* L1 = new_level(g1);
+  auto nn_of = [&](const int* ng) {
+    int64_t v = 1;
+    for (int a = 0; a < D; ++a) v *= ng[a];
+    return v;
+  };
+  // replicate a level: sum of the ranks' partial operators (single precision planes summed in double)
+  auto allreduce_operator = [&](MgLevel* L) {
+    const size_t ne = (size_t)mg.S * B2 * L->g.nn;
+    dvec<double> tmp;
+    tmp.alloc(ne);
+    hipLaunchKernelGGL(k_mg_f2d, dim3(gridn((long long)ne)), dim3(256), 0, h->st, (int64_t)ne, L->A.p, tmp.p);
+    gl_allreduce_bulk(h, tmp.p, ne);
+    hipLaunchKernelGGL(k_mg_d2f, dim3(gridn((long long)ne)), dim3(256), 0, h->st, (int64_t)ne, tmp.p, L->A.p);
+    GL_HIP(hipGetLastError());
+    GL_HIP(hipStreamSynchronize(h->st));
+  };
+  const bool g1_global = framed;
+  MgLevel* L1 = new_level(g1, o1, ng1, g1_global);
   hipLaunchKernelGGL(k_mg_rap0<D>, dim3(gridn((long long)g1.nn * mg.S)), dim3(256), 0, h->st, gdev(g1), mg.R, mg.S, n,
-                     mg.cell_ptr.p, mg.cell_nodes.p, mg.cell0.p, mg.wgt.p, p.slice_ptr.p, p.cols.p, h->vKel.p, fx,
-                     L1->A.p);
+                     n_all, mg.cell_ptr.p, mg.cell_nodes.p, mg.cell0.p, mg.wgt.p, p.slice_ptr.p, p.cols.p, h->vKel.p,
+                     fxr, L1->A.p);
   GL_HIP(hipGetLastError());
+  if (g1_global) allreduce_operator(L1);
   mg.entries = (int64_t)mg.S * B2 * g1.nn;
-  while (mg.lv.back()->g.nn > coarse_max) {
+  // coarsen until the GLOBAL grid is small enough (the level count is then the same on every rank)
+  while (nn_of(mg.lv.back()->ng) > coarse_max) {
     MgLevel* Lf = mg.lv.back();
     MgGrid gc;
     gc.nn = 1;
+    int ngc[3] = {1, 1, 1}, oc[3] = {0, 0, 0};
     bool any = false;
     for (int a = 0; a < D; ++a) {
-      if (Lf->g.n[a] > 2) {
+      if (Lf->ng[a] > 2) {
         Lf->f[a] = 2;
-        gc.n[a] = Lf->g.n[a] / 2 + 1;
+        ngc[a] = Lf->ng[a] / 2 + 1;
         any = true;
       } else {
         Lf->f[a] = 1;
-        gc.n[a] = Lf->g.n[a];
+        ngc[a] = Lf->ng[a];
+      }
+    }
+    if (!any) break;
+    const bool glob = Lf->global;
+    for (int a = 0; a < D; ++a) {
+      if (glob) {
+        oc[a] = 0;
+        gc.n[a] = ngc[a];
+      } else {   // box of the parents of this rank's fine box [o, o + n - 1]
+        const int lo_g = Lf->o[a], hi_g = Lf->o[a] + Lf->g.n[a] - 1;
+        oc[a] = Lf->f[a] == 2 ? lo_g >> 1 : lo_g;
+        const int hc = Lf->f[a] == 2 ? (hi_g + 1) >> 1 : hi_g;
+        gc.n[a] = std::min(hc, ngc[a] - 1) - oc[a] + 1;
       }
       gc.nn *= gc.n[a];
     }
-    if (!any) break;
-    MgLevel* Lc = new_level(gc);
+    MgLevel* Lc = new_level(gc, oc, ngc, glob);
     Lf = mg.lv[mg.lv.size() - 2];
-    Fac fc{{Lf->f[0], Lf->f[1], Lf->f[2]}};
+    Fac fc{{Lf->f[0], Lf->f[1], Lf->f[2]}, {Lf->o[0], Lf->o[1], Lf->o[2]}, {oc[0], oc[1], oc[2]}};
     hipLaunchKernelGGL(k_mg_rap<D>, dim3(gridn((long long)gc.nn * mg.S)), dim3(256), 0, h->st, gdev(Lf->g), gdev(gc),
                        fc, mg.R, mg.S, Lf->A.p, Lc->A.p);
     GL_HIP(hipGetLastError());
+    if (glob && !Lf->global) allreduce_operator(Lc);   // first replicated level: sum of the ranks' parts
     mg.entries += (int64_t)mg.S * B2 * gc.nn;
   }
   for (MgLevel* L : mg.lv) {
@@ -996,6 +1149,7 @@ void mg_setup_t(glims_ctx* h) {
   lap("Galerkin products, diagonal inverses");
   // ---- lambda_max(Dinv A) per smoothed level: power iteration -----------------------------------------------------
   gl_block_dinv(h);
+  mg.exact_level0 = framed;
   mg.half_smoother = (h->opt.flags & GLIMS_FLAG_MG_FP32_SMOOTHER) == 0;
   if (mg.half_smoother) gl_make_half_copy(h);
   const int pit = 12;
@@ -1004,8 +1158,11 @@ void mg_setup_t(glims_ctx* h) {
     hipLaunchKernelGGL(k_mg_fill, dim3(gridn(nd)), dim3(256), 0, h->st, nd, mg.x.p, fx);
     double lam = 1.0;
     for (int it = 0; it < pit; ++it) {
+      if (mg.exact_level0) gl_halo_exchange(h, mg.x.p, BS);
       gl_launch_mg_fine(h, 2, mg.x.p, nullptr, nullptr, mg.x2.p, 0.0, 0.0);
-      lam = std::sqrt(gl_dot(h, mg.x2.p, mg.x2.p, nd, false));   // = |Dinv A x| / |x| once x is normalised (it > 0)
+      // = |Dinv A x| / |x| once x is normalised (it > 0); one global value in the distributed-exact mode, so that
+      // every rank smooths with the same polynomial
+      lam = std::sqrt(gl_dot(h, mg.x2.p, mg.x2.p, nd, mg.exact_level0));
       if (!(lam > 0.0) || !std::isfinite(lam)) break;
       hipLaunchKernelGGL(k_mg_scale, dim3(gridn(nd)), dim3(256), 0, h->st, nd, mg.x2.p, 1.0 / lam);
       std::swap(mg.x.p, mg.x2.p);
@@ -1086,7 +1243,8 @@ void mg_setup_t(glims_ctx* h) {
     fprintf(stderr, "glims multigrid: %s mesh, H = (%.4g, %.4g, %.4g), stencil radius %d, levels:", mm.lattice ? "lattice" : "general",
             mg.H[0], mg.H[1], D == 3 ? mg.H[2] : 0.0, mg.R);
     fprintf(stderr, " mesh(%lld nodes, lam %.2f)", (long long)n, mg.lam0);
-    for (MgLevel* L : mg.lv) fprintf(stderr, " %dx%dx%d(lam %.2f)", L->g.n[0], L->g.n[1], L->g.n[2], L->lam);
+    for (MgLevel* L : mg.lv)
+      fprintf(stderr, " %dx%dx%d%s(lam %.2f)", L->g.n[0], L->g.n[1], L->g.n[2], L->global ? "[replicated]" : "", L->lam);
     fprintf(stderr, "; operator complexity %.2f; set-up %.1f ms\n", h->stats.mg_complexity, h->stats.ms_mg_setup);
   }
 }
@@ -1117,9 +1275,11 @@ void mg_cycle_cart(glims_ctx* h, size_t l, const int* done) {
   }
   mg_apply_cart<D>(h, L, mg.R, 0, xa, L.r.p, nullptr, L.res.p, 0.0, 0.0, done);
   MgLevel& C = *mg.lv[l + 1];
-  const Fac fc{{L.f[0], L.f[1], L.f[2]}};
+  const Fac fc{{L.f[0], L.f[1], L.f[2]}, {L.o[0], L.o[1], L.o[2]}, {C.o[0], C.o[1], C.o[2]}};
   hipLaunchKernelGGL(k_mg_restrict<D>, dim3(gridn(C.g.nn, 4)), dim3(256), 0, h->st, g, gdev(C.g), fc, L.res.p, C.r.p);
   GL_HIP(hipGetLastError());
+  // first replicated level of a partitioned run: every rank has restricted the residual of its own rows -> sum
+  if (C.global && !L.global) gl_allreduce_bulk(h, C.r.p, (size_t)BS * C.g.nn);
   mg_cycle_cart<D>(h, l + 1, done);
   hipLaunchKernelGGL(k_mg_prolong<D>, dim3(gridn(g.nn)), dim3(256), 0, h->st, g, gdev(C.g), fc, C.x.p, xa, xb);
   GL_HIP(hipGetLastError());
@@ -1145,17 +1305,21 @@ void mg_apply_t(glims_ctx* h, const double* r, double* u, const int* done) {
   ch.next(0, &c1, &c2);
   hipLaunchKernelGGL(k_mg_first_fine<BS>, dim3(gridn(n)), dim3(256), 0, h->st, n, h->m_dinv.p, r, mg.d.p, mg.x.p, c2);
   double *xa = mg.x.p, *xb = mg.x2.p;
+  const bool ex = mg.exact_level0;   // the passes read ghost columns: bring them in (iterates are owned-row vectors)
   for (int m = 1; m < deg; ++m) {
     ch.next(m, &c1, &c2);
+    if (ex) gl_halo_exchange(h, xa, BS);
     gl_launch_mg_fine(h, 1, xa, r, mg.d.p, xb, c1, c2, done);
     std::swap(xa, xb);
   }
+  if (ex) gl_halo_exchange(h, xa, BS);
   gl_launch_mg_fine(h, 0, xa, r, nullptr, mg.res.p, 0.0, 0.0, done);
   MgLevel& L1 = *mg.lv[0];
   const GridDev g1 = gdev(L1.g);
   hipLaunchKernelGGL(k_mg_restrict0<D>, dim3(gridn(g1.nn, 4)), dim3(256), 0, h->st, g1, mg.cell_ptr.p, mg.cell_nodes.p,
                      mg.wgt.p, mg.res.p, L1.r.p);
   GL_HIP(hipGetLastError());
+  if (L1.global) gl_allreduce_bulk(h, L1.r.p, (size_t)BS * L1.g.nn);
   mg_cycle_cart<D>(h, 0, done);
   hipLaunchKernelGGL(k_mg_prolong0<D>, dim3(gridn(n)), dim3(256), 0, h->st, g1, n, mg.cell0.p, mg.wgt.p, fx, L1.x.p,
                      xa, xb);
@@ -1165,6 +1329,7 @@ void mg_apply_t(glims_ctx* h, const double* r, double* u, const int* done) {
   for (int m = 0; m < deg; ++m) {
     cp.next(m, &c1, &c2);
     double* out = m == deg - 1 ? u : xb;   // the last step writes the preconditioned residual where the solver wants it
+    if (ex) gl_halo_exchange(h, xa, BS);
     gl_launch_mg_fine(h, 1, xa, r, mg.d.p, out, c1, c2, done);
     std::swap(xa, xb);
   }

@@ -618,6 +618,18 @@ static void allreduce_sum(glims_ctx* h, double* dev, int n) {
   GL_REQUIRE(h->comm_red, "world > 1 but no communicator: call glims_comm_init or glims_set_transport");
   GL_NCCL(ncclAllReduce(dev, dev, (size_t)n, ncclDouble, ncclSum, h->comm_red, h->st));
 }
+// In-place sum over ranks of a device vector of any length (multigrid set-up and its per-cycle coarse residual):
+// always RCCL or the host transport -- the node mailbox carries a handful of scalars only.
+void gl_allreduce_bulk(glims_ctx* h, double* dev, size_t n) {
+  if (h->world <= 1 || n == 0) return;
+  if (h->tr_allreduce) {
+    const int rc = h->tr_allreduce(h->tr_user, dev, (int)n, (void*)h->st);
+    if (rc != 0) throw glims_error(GLIMS_E_RCCL, "transport allreduce callback failed (" + std::to_string(rc) + ")");
+    return;
+  }
+  GL_REQUIRE(h->comm_red, "world > 1 but no communicator: call glims_comm_init or glims_set_transport");
+  GL_NCCL(ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, h->comm_red, h->st));
+}
 void gl_comm_destroy(glims_ctx* h) {
   if (h->comm_halo) (void)ncclCommDestroy(h->comm_halo);
   if (h->comm_red) (void)ncclCommDestroy(h->comm_red);
@@ -925,7 +937,10 @@ int gl_step(glims_ctx* h, int n_steps) {
                      nullptr);
       // new Dirichlet data enter the ITERATE, after the old state went into b = M c^n: the reference's u_previous
       // keeps the previous step's boundary values while the DirichletBC constrains the unknown
-      if (h->dirichlet_c_dirty) gl_apply_dirichlet_c(h);
+      if (h->dirichlet_c_dirty) {
+        gl_apply_dirichlet_c(h);
+        gl_halo_exchange(h, h->c.p, 1);   // a rank lists its OWN constrained nodes; their ghost copies follow
+      }
       if (extrapolate) {
         hipLaunchKernelGGL(k_extrapolate, dim3(grid_exact(n)), dim3(256), 0, h->st, n, h->c.p, h->c_old.p,
                            h->have_fixed_c ? h->fixed_c.p : nullptr, h->stats.steps > 0 ? 1 : 0);

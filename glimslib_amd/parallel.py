@@ -183,6 +183,8 @@ class DistributedHandle:
         else:
             self.h.comm_init(rank, world, broadcast_unique_id(dist, rank))
         self.h.set_halo(p.peer_rank, p.send_ptr, p.send_idx, p.recv_count)
+        pts = np.asarray(points)
+        self.h.set_mg_frame(pts.min(axis=0), pts.max(axis=0))   # every rank holds the whole host mesh: global box
         self.node_mailbox = setup_node_mailbox(self.h, dist, rank)
         self.g2l_owned = np.full(self.n_global, -1, dtype=np.int64)
         self.g2l_owned[p.global_ids[:p.n_own]] = np.arange(p.n_own)

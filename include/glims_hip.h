@@ -278,6 +278,14 @@ int glims_comm_selftest(glims_ctx* h);
 int glims_set_halo(glims_ctx* h, int n_peers, const int32_t* peer_rank,
                    const int64_t* send_ptr, const int32_t* send_idx, const int64_t* recv_count);
 
+/* Partitioned runs with mechanics: the bounding box lo[dim], hi[dim] of the WHOLE mesh (the same numbers on every rank).
+ * The elasticity multigrid then lays one global frame of auxiliary grids over the partitioned mesh and replicates its
+ * coarse levels (their operators are summed over the ranks once, the restricted residual once per cycle), so that the
+ * low-frequency part of the error is corrected globally -- the counterpart of what a parallel AMG does inside PETSc
+ * under mpirun (simulation_tumor_growth_brain_quad.py:116-119, README.md:142-183).  Without this call each rank
+ * preconditions its own rows only (still correct, about three times the iterations at 2 ranks).  NULL clears. */
+int glims_set_mg_frame(glims_ctx* h, const double* lo, const double* hi);
+
 /* Optional host-provided transport instead of RCCL (e.g. the reference's own MPI communicator, which DOLFIN hands
  * around as mesh.mpi_comm(), helper_classes.py:1249-1267; also used by the 2-rank tests on a single GPU, where RCCL
  * refuses two ranks per device).  Both callbacks are invoked from the calling thread with device pointers and the
