@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """
 Random partitioned runs on ONE GPU (gloo-staged halos + node-mailbox reductions, like tests/test_gpu_multirank.py):
-random mesh size / dimension / world size (2-5) per seed; the gathered result must equal the single-rank device run.
+random mesh size / dimension / world size (2-5) per seed (every fifth case an unstructured Delaunay mesh; two of three
+cases with the global multigrid frame of glims_set_mg_frame); the gathered result must equal the single-rank device run.
 usage: tools/fuzz_multirank.py [n_cases=12]
 """
 import os, socket, sys, tempfile
@@ -18,7 +19,16 @@ def problem(seed):
     from glimslib_amd.mesh import BoxMesh, RectangleMesh
     rng = np.random.default_rng(5000 + seed)
     dim = 2 + seed % 2
-    if dim == 3:
+    if seed % 5 == 4:   # unstructured: Delaunay mesh of random points (125-point coarse stencils in the multigrid)
+        from scipy.spatial import Delaunay
+        from glimslib_amd.mesh import Mesh
+        dim = 3
+        pts = rng.random((int(rng.integers(600, 2500)), 3)) * np.array([10.0, 8.0, 6.0])
+        cells = Delaunay(pts).simplices.astype(np.int32)
+        X = pts[cells]
+        vol = np.abs(np.linalg.det(X[:, 1:] - X[:, :1])) / 6.0
+        mesh = Mesh(pts, cells[vol > 1e-6 * vol.mean()])
+    elif dim == 3:
         n = rng.integers(3, 13, size=3)
         mesh = BoxMesh((0, 0, 0), tuple(float(v) for v in n * rng.uniform(0.6, 1.5, size=3)), *[int(v) for v in n])
     else:
@@ -46,6 +56,8 @@ def worker(rank, world, port, out_dir, seed):
         tr = HostStagedTransport(dist)
         h.set_transport(rank, world, tr.halo_cb, tr.allreduce_cb)
         h.set_halo(part.peer_rank, part.send_ptr, part.send_idx, part.recv_count)
+        if seed % 3 != 0:   # two of three cases: global multigrid frame (replicated coarse levels), else rank-local hierarchies
+            h.set_mg_frame(mesh.points.min(axis=0), mesh.points.max(axis=0))
         assert setup_node_mailbox(h, dist, rank)
         h.set_materials(TABS['D'], TABS['rho'], TABS['gamma'], TABS['E'], TABS['nu'])
         h.set_options(dt=1.0)
