@@ -182,9 +182,13 @@ struct MgHierarchy {
   dvec<int32_t> cell_ptr, cell_nodes;      // mesh nodes sorted by level-1 cell (children lists of the grid nodes)
   dvec<double> x, x2, d, res;              // level-0 work vectors [n_nodes*bs] (ghost slots stay zero)
   double lam0 = 1.0;
+  double dropped_fraction = 0.0;           // mesh edges whose parents lie more than two grid cells apart (not in the coarse operators)
   bool half_smoother = true;               // level-0 smoother streams the half-precision copy of K_el
   bool exact_level0 = false;               // partitioned run with a global frame: level-0 passes see the ghosts (halo exchange)
-  double half_unscale = 1.0;               // K_el = half_unscale * (half copy)
+  dvec<double> sc;                         // level-0 scaling s = 1 / sqrt(diag K_el) per dof (1 on constrained dofs)
+  dvec<float> dinv0;                       // inverse diagonal blocks of the scaled operator S K S, single precision
+  dvec<float> vK32s;                       // single-precision scaled copy (GLIMS_FLAG_MG_FP32_SMOOTHER only)
+  dvec<double> rs;                         // scaled residual r~ = S r of the current cycle
   std::vector<MgLevel*> lv;                // owned
   dvec<double> coarse_inv;                 // dense inverse of the coarsest operator [nc][nc], nc = lv.back()->g.nn * bs
   int64_t entries = 0;                     // stored operator entries of the coarse levels (scalars)
@@ -303,7 +307,7 @@ struct glims_ctx {
   bool pair_A = false;                     // vA / vA32 and cols16p use the slot-pair layout (GLIMS_PAIR_A, needs 16-bit codes everywhere)
   int tune_pair_A = 1;
   dvec<float> vKel32;                      // single-precision copy of K_el (inner solves of the elasticity solver)
-  dvec<uint16_t> vKel16;                   // scaled half-precision copy (bit pattern of _Float16): level-0 multigrid smoother
+  dvec<uint16_t> vKel16;                   // half-precision copy of S K_el S (bit pattern of _Float16): level-0 multigrid smoother
   // vectors (internal numbering; length n_nodes unless noted)
   dvec<double> c, c_old, b, load_rd, dinv;
   dvec<double> cg_p, cg_s, cg_u, cg_w, cg_r, cg_r2, b2;     // scalar CG work vectors; r2/b2: speculative next step
@@ -311,7 +315,7 @@ struct glims_ctx {
   int mech_hint = 0;
   // history of solved elasticity problems (right-hand side, free-dof solution): the operator is linear and time
   // independent, so the least-squares fit of a new right-hand side by the stored ones gives the initial guess
-  static constexpr int MHIST = 8;   // GLIMS_MHIST <= 8 limits the depth actually used
+  static constexpr int MHIST = 16;  // upper bound of glims_options.mech_history
   dvec<double> mh_rhs[MHIST], mh_x[MHIST];
   int mh_count = 0, mh_next = 0;           // depth: glims_options.mech_history
   double mh_G[MHIST][MHIST] = {{0.0}};     // Gram matrix (rhs_k, rhs_l) of the stored right-hand sides (host copy)
@@ -399,8 +403,8 @@ void gl_block_dinv(glims_ctx* h);                                            // 
 // mg.hip --------------------------------------------------------------------------------------------
 void gl_mesh_metrics(glims_ctx* h, const HostPattern& hp, const double* xyz_old);
 void gl_mg_setup(glims_ctx* h);
-void gl_make_half_copy(glims_ctx* h);
+void gl_make_smoother_copy(glims_ctx* h, bool half, bool exchange_scale);
 void gl_mg_apply(glims_ctx* h, const double* r, double* u, const int* done = nullptr);   // u = V-cycle(r); r zero on constrained dofs
 // level-0 operator pass of the multigrid (kernels.hip): mode 0 out = r - A x, 1 Chebyshev step, 2 out = Dinv A x
 void gl_launch_mg_fine(glims_ctx* h, int mode, const double* xin, const double* r, double* d, double* xout, double c1,
-                       double c2, const int* done = nullptr);
+                       double c2, const int* done = nullptr, double* uout = nullptr);

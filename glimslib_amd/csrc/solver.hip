@@ -485,10 +485,10 @@ __global__ __launch_bounds__(256) void k_dot3(int64_t n, int nq, const Dot3 v, c
         sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
 }
 
-// y = sum_k a[k] x_k  (k < m <= 8)
+// y = sum_k a[k] x_k  (k < m <= 16)
 struct LinComb {
-  const double* x[8];
-  double a[8];
+  const double* x[16];
+  double a[16];
 };
 __global__ void k_lincomb(int64_t n, int m, const LinComb lc, double* __restrict__ y) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1208,7 +1208,7 @@ int gl_solve_mechanics(glims_ctx* h, const double* c_dev) {
         for (int k = 0; k < m; ++k) a[k] = e_last[k];
     }
     LinComb lc;
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 16; ++k) {
       lc.x[k] = h->mh_x[k < m ? k : 0].p;
       lc.a[k] = k < m ? a[k] : 0.0;
     }

@@ -77,7 +77,7 @@ typedef struct glims_options {
   int    mech_mixed;      /* inner PCG streams a single-precision copy of K_el under an fp64 iterative-refinement
                              loop: 0 off, 1 when K_el exceeds the Infinity Cache, 2 always          default 1     */
   int    mech_history;    /* right-hand sides / solutions of the last k solves kept for the least-squares initial
-                             guess (K_el is linear and time independent), 0..8                      default 8     */
+                             guess (K_el is linear and time independent), 0..16                     default 8     */
   int    mg_smooth;       /* Chebyshev degree of the pre- and of the post-smoother on every level
                              (1 = damped block-Jacobi)                                             default 2     */
   int    mg_coarse_nodes; /* coarsen until a grid has at most this many nodes; that level is solved with a dense

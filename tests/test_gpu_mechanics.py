@@ -252,3 +252,27 @@ def test_config_c5_full_size_properties(backend):
           (h4.stats()['mech_cg_its'], np.abs(uk - exact).max(), np.abs(exact).max()))
     assert np.abs(uk - exact).max() < 1e-6 * np.abs(exact).max()
     h4.close()
+
+
+def test_multigrid_on_a_larger_delaunay_mesh_with_slivers(backend):
+    """100 000 random points, Delaunay: cell volumes over three decades and hull slivers, i.e. stiffness entries over
+    many decades.  This is the case that exposed the first half-precision smoother copy (one global scale factor: most
+    rows fell below the fp16 range, 7 984 iterations at 1 M points); with the symmetrically scaled copy the half- and
+    the single-precision smoother need the same number of iterations, a small fraction of block-Jacobi's."""
+    w = workloads.config_unstructured(100000, mechanics=True)
+    its = {}
+    us = {}
+    for name, opts in (("half", {}), ("single", dict(flags=backend.FLAG_WARM_START | backend.FLAG_MG_FP32_SMOOTHER)),
+                       ("block-jacobi", dict(mech_precond=backend.PRECOND_BLOCK_JACOBI))):
+        h, dofs = _c5_handle(backend, w, mech_history=0, **opts)
+        assert h.solve_mechanics() == 0
+        st = h.stats()
+        its[name] = st['mech_cg_its']
+        us[name] = h.get_state()[1]
+        if name == "half":
+            assert _free_residual(h, w.c0, us[name], dofs) < 1e-8
+        h.close()
+    print("Delaunay 100 k points: PCG iterations", its)
+    assert abs(its["half"] - its["single"]) <= 0.15 * its["single"] + 2
+    assert its["half"] < 0.25 * its["block-jacobi"] and its["half"] < 200
+    assert rel_l2(us["half"], us["single"]) < 1e-6 and rel_l2(us["half"], us["block-jacobi"]) < 1e-5
