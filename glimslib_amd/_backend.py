@@ -39,7 +39,7 @@ class Options(C.Structure):
                 ("mech_maxit", C.c_int), ("check_every", C.c_int), ("flags", C.c_int),
                 ("mech_precond", C.c_int), ("mech_mixed", C.c_int), ("mech_history", C.c_int),
                 ("mg_smooth", C.c_int), ("mg_coarse_nodes", C.c_int), ("mg_h_factor", C.c_double),
-                ("time_kernels", C.c_int)]
+                ("mg_cheb_ratio", C.c_double), ("time_kernels", C.c_int)]
 
 
 class Stats(C.Structure):

@@ -182,6 +182,7 @@ struct MgHierarchy {
   dvec<int32_t> cell_ptr, cell_nodes;      // mesh nodes sorted by level-1 cell (children lists of the grid nodes)
   dvec<double> x, x2, d, res;              // level-0 work vectors [n_nodes*bs] (ghost slots stay zero)
   double lam0 = 1.0;
+  double cheb_ratio = 30.0;                // the smoothers' interval is [lambda_max / cheb_ratio, lambda_max]
   double dropped_fraction = 0.0;           // mesh edges whose parents lie more than two grid cells apart (not in the coarse operators)
   bool half_smoother = true;               // level-0 smoother streams the half-precision copy of K_el
   bool exact_level0 = false;               // partitioned run with a global frame: level-0 passes see the ghosts (halo exchange)

@@ -714,11 +714,15 @@ __global__ void k_mg_scale(int64_t n, double* __restrict__ x, double s) {
 
 inline unsigned gridn(long long n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
 
-// Chebyshev coefficients of step m (0-based) for the spectrum [lmax / ratio, lmax] of Dinv A
+// Chebyshev coefficients of step m (0-based) for the interval [lmax / ratio, lmax] of Dinv A (glims_options.
+// mg_cheb_ratio; default 30 on lattice meshes, 10 on general ones), lmax = 1.1 x the power-
+// iteration estimate.  The lower end decides how much of the spectrum the smoother takes on itself: with lmax / 4 (the
+// first version) degree 2 / 3 needed 31 / 25 PCG iterations on config C5, with lmax / 30 ... lmax / 60 they need
+// 24 / 17 (Delaunay mesh: 42 / 34 -> 34 / 25; beyond lmax / 100 it gets worse again) -- tools/proto_gmg.py.
 struct Cheb {
   double theta, delta, sigma, rho;
-  explicit Cheb(double lam) {
-    const double lmax = 1.1 * lam, lmin = lmax / 4.0;
+  Cheb(double lam, double ratio) {
+    const double lmax = 1.1 * lam, lmin = lmax / ratio;
     theta = 0.5 * (lmax + lmin);
     delta = 0.5 * (lmax - lmin);
     sigma = theta / delta;
@@ -1167,11 +1171,14 @@ void mg_setup_t(glims_ctx* h) {
   lap("Galerkin products, diagonal inverses");
   // ---- lambda_max(Dinv A) per smoothed level: power iteration -----------------------------------------------------
   gl_block_dinv(h);
+  // measured (tools/run_c5.py, degree 3): config C5 (lattice) 13.0 ms per solve with lmax / 30 against 16.6 with lmax / 10
+  // and 18.7 with lmax / 4; 1 M-point Delaunay mesh 75 ms with lmax / 10 against 83 with lmax / 30
+  mg.cheb_ratio = h->opt.mg_cheb_ratio > 1.0 ? h->opt.mg_cheb_ratio : (lattice ? 30.0 : 10.0);
   mg.exact_level0 = framed;
   mg.half_smoother = (h->opt.flags & GLIMS_FLAG_MG_FP32_SMOOTHER) == 0;
   gl_make_smoother_copy(h, mg.half_smoother, mg.exact_level0);
   mg.rs.alloc_zero(nd0, h->st);
-  const int pit = 12;
+  const int pit = 25;   // 12 under-estimate lambda_max on meshes with slivers (localised top modes); a pass costs 0.1 ms
   {
     const int64_t nd = n * BS;
     hipLaunchKernelGGL(k_mg_fill, dim3(gridn(nd)), dim3(256), 0, h->st, nd, mg.x.p, fx);
@@ -1282,7 +1289,7 @@ void mg_cycle_cart(glims_ctx* h, size_t l, const int* done) {
     return;
   }
   const int deg = std::max(1, std::min(8, h->opt.mg_smooth));
-  Cheb ch(L.lam);
+  Cheb ch(L.lam, mg.cheb_ratio);
   double c1, c2;
   ch.next(0, &c1, &c2);
   hipLaunchKernelGGL(k_mg_first_cart<D>, dim3(gridn(g.nn)), dim3(256), 0, h->st, g, L.dinv.p, L.r.p, L.d.p, L.x.p, c2);
@@ -1303,7 +1310,7 @@ void mg_cycle_cart(glims_ctx* h, size_t l, const int* done) {
   hipLaunchKernelGGL(k_mg_prolong<D>, dim3(gridn(g.nn)), dim3(256), 0, h->st, g, gdev(C.g), fc, C.x.p, xa, xb);
   GL_HIP(hipGetLastError());
   std::swap(xa, xb);
-  Cheb cp(L.lam);
+  Cheb cp(L.lam, mg.cheb_ratio);
   for (int m = 0; m < deg; ++m) {
     cp.next(m, &c1, &c2);
     mg_apply_cart<D>(h, L, mg.R, 1, xa, L.r.p, L.d.p, xb, c1, c2, done);
@@ -1319,7 +1326,7 @@ void mg_apply_t(glims_ctx* h, const double* r, double* u, const int* done) {
   const int64_t n = h->n_own;
   const uint8_t* fx = h->have_fixed_u ? h->fixed_u.p : nullptr;
   const int deg = std::max(1, std::min(8, h->opt.mg_smooth));
-  Cheb ch(mg.lam0);
+  Cheb ch(mg.lam0, mg.cheb_ratio);
   double c1, c2;
   ch.next(0, &c1, &c2);
   hipLaunchKernelGGL(k_mg_first_fine<BS>, dim3(gridn(n)), dim3(256), 0, h->st, n, mg.dinv0.p, mg.sc.p, r, mg.rs.p,
@@ -1346,7 +1353,7 @@ void mg_apply_t(glims_ctx* h, const double* r, double* u, const int* done) {
                      L1.x.p, xa, xb);
   GL_HIP(hipGetLastError());
   std::swap(xa, xb);
-  Cheb cp(mg.lam0);
+  Cheb cp(mg.lam0, mg.cheb_ratio);
   for (int m = 0; m < deg; ++m) {
     cp.next(m, &c1, &c2);
     // the last step leaves the scaled variables and writes the preconditioned residual where the solver wants it

@@ -79,11 +79,13 @@ typedef struct glims_options {
   int    mech_history;    /* right-hand sides / solutions of the last k solves kept for the least-squares initial
                              guess (K_el is linear and time independent), 0..16                     default 8     */
   int    mg_smooth;       /* Chebyshev degree of the pre- and of the post-smoother on every level
-                             (1 = damped block-Jacobi)                                             default 2     */
+                             (1 = damped block-Jacobi)                                             default 3     */
   int    mg_coarse_nodes; /* coarsen until a grid has at most this many nodes; that level is solved with a dense
                              inverse computed once on the host                                      default 216   */
   double mg_h_factor;     /* spacing of the first auxiliary Cartesian grid in units of the mesh width
                              (lattice meshes: of the lattice constant per axis)                    default 2.0   */
+  double mg_cheb_ratio;   /* the Chebyshev smoothers act on [lambda_max / ratio, lambda_max] of Dinv A;
+                             0 = by mesh class: 30 on lattice meshes, 10 on general ones (measured)  default 0     */
   int    time_kernels;    /* HIP-event pairs on the handle's stream around hot kernels of glims_step: 1 = the Krylov
                              SpMV, 2 = also the assembly sweep and the PCG vector update; results in
                              glims_stats.*_steps / us_*_median (bench.py's in-step roofline figures)  default 0     */
