@@ -203,6 +203,18 @@ def test_failure_semantics_and_usage_errors(backend):
     bad[0, 0] = 10 ** 6
     with pytest.raises(backend.BackendError):
         backend.Handle(mesh.points, bad, lab)
+    for bad in (dict(mech_precond=7), dict(mg_smooth=0), dict(mg_cheb_ratio=0.5), dict(mech_mixed=3), dict(mg_h_factor=-1.0)):
+        with pytest.raises(backend.BackendError):
+            h.set_options(**bad)                                  # elasticity-solver options are validated
+        for k in bad:
+            setattr(h.options, k, getattr(backend.Options(), k))
+    opt = backend.Options()
+    backend.load_library().glims_options_default(opt)
+    for k, _ in backend.Options._fields_:
+        setattr(h.options, k, getattr(opt, k))
+    h.set_options(newton_maxit=0)
+    with pytest.raises(backend.BackendError):
+        h.set_mg_frame([0.0, 0.0], [-1.0, 1.0])                  # hi < lo
     with pytest.raises(backend.BackendError, match="Lame"):
         h.set_materials(TABS['D'], TABS['rho'], TABS['gamma'], TABS['E'], [0.3, 0.5, 0.45, 0.1])   # incompressible
     h.close()
