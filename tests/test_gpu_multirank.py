@@ -341,3 +341,56 @@ def test_partitioned_elasticity_multigrid_with_replicated_coarse_levels(tmp_path
           (n, world, its1, its[True], its[False]))
     assert abs(its[True] - its1) <= 2
     assert its[True] < its[False]
+
+
+# ---- time-dependent Dirichlet data of the concentration in a partitioned run ----------------------------------------------
+def _dirichlet_problem():
+    from glimslib_amd import fenics_local as fenics
+    from glimslib_amd.simulation import TumorGrowth
+
+    class Left(fenics.SubDomain):
+        def inside(self, x, on_boundary):
+            return on_boundary and x[0] < 1e-10
+
+    mesh = fenics.BoxMesh(fenics.Point(0, 0, 0), fenics.Point(10, 6, 5), 16, 10, 8)
+    sim = TumorGrowth(mesh, solver_options={'mechanics': False})
+    sim.setup_global_parameters(domain_names={0: 'all'}, boundaries={'left': Left()},
+                                dirichlet_bcs={'inflow': {'bc_value': fenics.Expression('0.1 + 0.05*t', degree=1, t=0.0),
+                                                          'named_boundary': 'left', 'subspace_id': 1}},
+                                von_neumann_bcs={})
+    sim.setup_model_parameters(iv_expression={0: fenics.Constant((0.0, 0.0, 0.0)), 1: fenics.Constant(0.0)},
+                               diffusion=0.5, coupling=0.0, proliferation=0.1, E=1.0, poisson=0.3,
+                               sim_time=4, sim_time_step=1)
+    return sim
+
+
+def _dirichlet_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["GLIMS_TRANSPORT"] = "gloo"
+    os.environ["GLIMS_FORCE_DEVICE"] = "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sim = _dirichlet_problem()
+        sol = sim.run(save_method=None, plot=False)
+        np.savez(os.path.join(out_dir, "dir_rank%d.npz" % rank), c=sol.components[1])
+        sim.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_time_dependent_dirichlet_concentration_in_a_partitioned_run(tmp_path):
+    """Every rank lists its OWN constrained nodes; when the Dirichlet value changes with the simulation time the ghost
+    copies of such nodes on the neighbouring ranks must follow before the step's first sweep (halo exchange after the
+    values were written).  Three ranks through the public API equal the single-process run."""
+    world = 3
+    mp.spawn(_dirichlet_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    z = [np.load(os.path.join(str(tmp_path), "dir_rank%d.npz" % r))['c'] for r in range(world)]
+    assert np.array_equal(z[0], z[1]) and np.array_equal(z[0], z[2])
+    sim = _dirichlet_problem()
+    ref = sim.run(save_method=None, plot=False).components[1]
+    left = np.flatnonzero(sim.mesh.points[:, 0] < 1e-10)
+    sim.close()
+    assert np.allclose(z[0][left], 0.3, rtol=0, atol=1e-15) and ref.max() <= 0.3 + 1e-12
+    assert rel_l2(z[0], ref) < 1e-10
