@@ -97,6 +97,7 @@ def main():
                     help="cells per edge (overrides the workload's size); use --size under torchrun, which claims --n*")
     ap.add_argument("--spmv-reps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the informational fp32-Jacobian-storage pass")
     ap.add_argument("--extrapolate", type=int, default=0)
     ap.add_argument("--cg-rtol", type=float, default=None, help="override glims_options.cg_rtol (tuning runs only)")
     ap.add_argument("--check-every", type=int, default=None)
@@ -369,6 +370,39 @@ def main():
     except Exception:   # noqa: BLE001 -- informational only
         roofline["stream_ceiling"] = None
 
+    # ---- informational: the same K steps with GLIMS_FLAG_FP32_JACOBIAN (A(c) stored / streamed in single precision
+    # inside the Krylov solves; Newton residual, sums and every vector stay fp64).  OFF by default and NOT the headline:
+    # reported next to it, with the distance between the two concentration fields after the same number of steps, so
+    # that the decision about the default can be taken from measured numbers.
+    alt = None
+    if world == 1 and not coupled and status == GLIMS_OK and not args.fp32_jacobian and not args.no_alt:
+        try:
+            n_post = st_k['_steps'] if st_k is not None else 0
+            c_ref = h.get_state(want_u=False)[0].copy()          # default build after W + K + n_post steps
+            h.set_options(flags=flags | 4, time_kernels=0)
+            h.setup(with_mechanics=False)
+            h.set_state(c0)
+            a_status = h.step(args.warmup) if args.warmup > 0 else GLIMS_OK
+            h.reset_stats()
+            barrier()
+            ta = time.perf_counter()
+            a_status |= h.step(args.steps)
+            barrier()
+            ta = time.perf_counter() - ta
+            sa = h.stats()
+            if n_post:
+                a_status |= h.step(n_post)
+            c_alt = h.get_state(want_u=False)[0]
+            alt = {"fp32_jacobian_storage": {
+                "ms_per_step": 1e3 * ta / args.steps, "value": n_global * args.steps / ta, "solver_status": int(a_status),
+                "newton_its_per_step": sa['newton_its'] / args.steps, "cg_its_per_step": sa['cg_its'] / args.steps,
+                "rel_l2_vs_default": float(np.linalg.norm(c_alt - c_ref) / np.linalg.norm(c_ref)),
+                "compared_after_steps": args.warmup + args.steps + n_post,
+                "note": "GLIMS_FLAG_FP32_JACOBIAN, off by default; not the headline value"}}
+            del c_ref, c_alt
+        except Exception as e:   # noqa: BLE001 -- informational only, never in the way of the line
+            log("[bench] alt (fp32 Jacobian storage) pass skipped: %r" % (e,))
+
     if rank == 0:
         out = {
             "metric": "DoF-updates/s (implicit RD timestep) on 3D brain mesh; 1/2/4/8 GPU + %HBM roofline",
@@ -402,6 +436,8 @@ def main():
                        "solver_status": int(status)},
             "roofline": roofline,
         }
+        if alt is not None:
+            out["alt"] = alt
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(None if coupled else w)
         sys.stdout.flush()

@@ -128,6 +128,27 @@ def test_multigrid_iteration_count_does_not_grow_with_the_mesh(backend):
     assert max(its) <= 60 and its[-1] <= its[0] + 8
 
 
+def test_multigrid_near_the_incompressible_limit(backend):
+    """nu = 0.49 in every tissue -- the upper end of the range the reference documents (simulation_tumor_growth.py:60,
+    'poisson ratio nu: 0.4 ... 0.49'): lambda / mu = 49.  The point-block Chebyshev smoother loses some of its grip
+    (39 its at 1 M nodes instead of 19 at nu = 0.45; 0.495 -> 53, 0.499 -> 104) but stays far from the block-Jacobi
+    count (1806 at 1 M), and the answer is the oracle's sparse LU."""
+    w = _c5_reduced(32)
+    w.tables = dict(w.tables, nu=[0.49 if v > 0.4 else v for v in w.tables['nu']])
+    its = {}
+    for name, pre in (("mg", backend.PRECOND_MULTIGRID), ("bj", backend.PRECOND_BLOCK_JACOBI)):
+        h, dofs = _c5_handle(backend, w, mech_history=0, mech_precond=pre, mech_rtol=1e-11)
+        assert h.solve_mechanics() == 0
+        u = h.get_state()[1]
+        its[name] = h.stats()['mech_cg_its']
+        h.close()
+        if name == "mg":
+            uo = _c5_oracle(w, dofs).mech_solve(w.c0)
+        assert rel_l2(u, uo) < 1e-7
+    print("nu = 0.49, n = 32: PCG iterations", its)
+    assert its["mg"] <= 60 and its["mg"] < 0.2 * its["bj"]
+
+
 def test_multigrid_on_an_unstructured_mesh_and_a_misaligned_lattice(backend):
     """General meshes take the 125-point coarse stencils: a Delaunay mesh (volumes over three decades) and a box mesh
     whose nodes were jittered off the lattice; both against the oracle."""

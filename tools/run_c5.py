@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Config C5 (coupled model on the brain-extent box): elasticity solve after every RD step, per preconditioner.
-    python tools/run_c5.py [n] [steps]      env: PRECOND=mg|bj  SMOOTH=k  MIXED=0|1|2  HIST=k  MECH_RTOL"""
+    python tools/run_c5.py [n] [steps]      env: PRECOND=mg|bj  SMOOTH=k  MIXED=0|1|2  HIST=k  MECH_RTOL  NU=0.49"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +12,10 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 w = workloads.config_c5(n) if n < 100000 else workloads.config_unstructured(n, mechanics=True)
 t0 = time.perf_counter()
 h = Handle(w.mesh.points, w.mesh.cells, w.cell_label)
-t = w.tables
+t = dict(w.tables)
+if os.environ.get("NU"):   # Poisson ratio of every tissue with nu > 0.4 (near-incompressible study)
+    t['nu'] = [float(os.environ["NU"]) if v > 0.4 else v for v in t['nu']]
+    print("nu table:", t['nu'])
 h.set_materials(t['D'], t['rho'], t['gamma'], t['E'], t['nu'])
 pre = _backend.PRECOND_BLOCK_JACOBI if os.environ.get("PRECOND", "mg") == "bj" else _backend.PRECOND_MULTIGRID
 h.set_options(dt=w.dt, mech_rtol=float(os.environ.get("MECH_RTOL", "1e-10")), mech_precond=pre,
