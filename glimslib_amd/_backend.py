@@ -22,6 +22,7 @@ FLAG_WARM_START = 2
 FLAG_FP32_JACOBIAN = 4
 FLAG_MG_FP32_SMOOTHER = 8
 FLAG_INT32_COLUMNS = 16
+FLAG_MG_FP64_VECTORS = 32
 PRECOND_BLOCK_JACOBI, PRECOND_MULTIGRID = 0, 1
 ABI_VERSION = 2
 

@@ -331,7 +331,7 @@ int glims_set_options(glims_ctx* h, const glims_options* opt) {
       h->mg.ready = false;
     if (opt->dt != h->opt.dt) h->is_setup = false;
     if ((opt->flags ^ h->opt.flags) & (GLIMS_FLAG_FP32_JACOBIAN | GLIMS_FLAG_INT32_COLUMNS)) h->is_setup = false;
-    if ((opt->flags ^ h->opt.flags) & GLIMS_FLAG_MG_FP32_SMOOTHER) h->mg.ready = false;
+    if ((opt->flags ^ h->opt.flags) & (GLIMS_FLAG_MG_FP32_SMOOTHER | GLIMS_FLAG_MG_FP64_VECTORS)) h->mg.ready = false;
     h->opt = *opt;
     h->pending = false;
     return GLIMS_OK;

@@ -185,6 +185,7 @@ struct MgHierarchy {
   double cheb_ratio = 30.0;                // the smoothers' interval is [lambda_max / cheb_ratio, lambda_max]
   double dropped_fraction = 0.0;           // mesh edges whose parents lie more than two grid cells apart (not in the coarse operators)
   bool half_smoother = true;               // level-0 smoother streams the half-precision copy of K_el
+  bool x32 = false;                        // level-0 cycle vectors in single precision (XNode<BS, float> layout)
   bool exact_level0 = false;               // partitioned run with a global frame: level-0 passes see the ghosts (halo exchange)
   dvec<double> sc;                         // level-0 scaling s = 1 / sqrt(diag K_el) per dof (1 on constrained dofs)
   dvec<float> dinv0;                       // inverse diagonal blocks of the scaled operator S K S, single precision
@@ -254,7 +255,46 @@ static __device__ __forceinline__ void node_allreduce(double* __restrict__ red, 
   if (!ok && lane == 0) *nm.err = 1;
 }
 
+// Level-0 cycle vectors of the elasticity multigrid.  XT = double: [node][BS] doubles.  XT = float (default): the
+// ITERATE lives in node records of 16 B (BS = 3: x, y, z, pad) / 8 B (BS = 2), so that a neighbour's value is ONE
+// aligned load in the smoother's gather instead of three 8-byte ones; residual / direction vectors are packed
+// [node * BS] floats.  In units of doubles a record is GL_XREC(BS) = 2 / 1 long, which is what the halo exchange of a
+// partitioned run is told.
+template <int BS, class XT> struct XNode;
+template <int BS> struct XNode<BS, double> {
+  static __device__ __forceinline__ void load(const double* __restrict__ x, int64_t j, double* o) {
+#pragma unroll
+    for (int a = 0; a < BS; ++a) o[a] = x[j * BS + a];
+  }
+  static __device__ __forceinline__ void store(double* __restrict__ x, int64_t j, const double* v) {
+#pragma unroll
+    for (int a = 0; a < BS; ++a) x[j * BS + a] = v[a];
+  }
+};
+template <> struct XNode<3, float> {
+  static __device__ __forceinline__ void load(const float* __restrict__ x, int64_t j, double* o) {
+    const float4 v = reinterpret_cast<const float4*>(x)[j];
+    o[0] = (double)v.x;
+    o[1] = (double)v.y;
+    o[2] = (double)v.z;
+  }
+  static __device__ __forceinline__ void store(float* __restrict__ x, int64_t j, const double* v) {
+    reinterpret_cast<float4*>(x)[j] = make_float4((float)v[0], (float)v[1], (float)v[2], 0.0f);
+  }
+};
+template <> struct XNode<2, float> {
+  static __device__ __forceinline__ void load(const float* __restrict__ x, int64_t j, double* o) {
+    const float2 v = reinterpret_cast<const float2*>(x)[j];
+    o[0] = (double)v.x;
+    o[1] = (double)v.y;
+  }
+  static __device__ __forceinline__ void store(float* __restrict__ x, int64_t j, const double* v) {
+    reinterpret_cast<float2*>(x)[j] = make_float2((float)v[0], (float)v[1]);
+  }
+};
+
 #endif
+inline int gl_xrec_doubles(int bs, bool x32) { return x32 ? (bs == 3 ? 2 : 1) : bs; }
 
 // scalar slots of the Krylov recurrence (device array `scal`)
 enum { SC_ALPHA = 0, SC_BETA, SC_GAMMA, SC_IT, SC_COUNT = 8 };

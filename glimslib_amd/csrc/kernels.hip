@@ -730,18 +730,19 @@ __global__ __launch_bounds__(256) void k_spmv_block2(int n_launch, int chunk, co
 // direction and the new iterate cost no extra pass over the vectors.  Constrained dofs: rows masked here, columns see
 // x = 0 there (the iterates are zero on constrained dofs by construction).  xout must not alias xin.
 //   MODE 0: xout = r - A xin          MODE 1: d = c1 d + c2 Dinv (r - A xin), xout = xin + d          MODE 2: xout = Dinv A xin
-template <int BS, int MODE, int KB, class VT, int CIDX>
+template <int BS, int MODE, int KB, class VT, int CIDX, class XT>
 __global__ __launch_bounds__(256) void k_mg_fine(int n_launch, int chunk, int64_t n_own,
                                                   const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ cols,
                                                   const uint16_t* __restrict__ cols16,
                                                   const int32_t* __restrict__ win_base,
                                                   const VT* __restrict__ vals,
                                                   const float* __restrict__ dinv, const double* __restrict__ sc,
-                                                  const uint8_t* __restrict__ fixed, const double* __restrict__ xin,
-                                                  const double* __restrict__ r, double* __restrict__ d,
-                                                  double* __restrict__ xout, double* __restrict__ uout, double c1,
+                                                  const uint8_t* __restrict__ fixed, const XT* __restrict__ xin,
+                                                  const XT* __restrict__ r, XT* __restrict__ d,
+                                                  XT* __restrict__ xout, double* __restrict__ uout, double c1,
                                                   double c2, int remap, const int* __restrict__ done) {
   constexpr int B2 = BS * BS;
+  using XN = XNode<BS, XT>;   // layout of the iterate (xin; xout of MODE 1 / 2); r, d and the MODE 0 result are packed
   if (done && *done) return;   // enqueued past the Krylov solver's convergence: nobody reads the result
   const int b = remap > 1 ? xcd_chunk_remap(blockIdx.x, gridDim.x, remap) : blockIdx.x;
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -777,9 +778,13 @@ __global__ __launch_bounds__(256) void k_mg_fine(int n_launch, int chunk, int64_
         for (int j = 0; j < KB; ++j) cj[j] = decode_col((uint32_t)cj[j], wb);
       }
 #pragma unroll
-      for (int j = 0; j < KB; ++j)
+      for (int j = 0; j < KB; ++j) {
+        XN::load(xin, cj[j], xj[j]);   // slots past the row's end repeat its last entry: their products are dropped
+        if (k + j >= len) {
 #pragma unroll
-        for (int bb = 0; bb < BS; ++bb) xj[j][bb] = (k + j < len) ? xin[(int64_t)cj[j] * BS + bb] : 0.0;
+          for (int bb = 0; bb < BS; ++bb) xj[j][bb] = 0.0;
+        }
+      }
 #pragma unroll
       for (int j = 0; j < KB; ++j)
 #pragma unroll
@@ -793,25 +798,35 @@ __global__ __launch_bounds__(256) void k_mg_fine(int n_launch, int chunk, int64_
     for (int a = 0; a < BS; ++a) {
       const bool fx = fixed && fixed[row * BS + a];
       if (MODE == 2) t[a] = fx ? 0.0 : acc[a];
-      else t[a] = fx ? 0.0 : r[row * BS + a] - acc[a];
+      else t[a] = fx ? 0.0 : (double)r[row * BS + a] - acc[a];
     }
     if (MODE == 0) {   // the residual leaves the scaled variables: r - K x = S^-1 (r~ - K~ x~)
 #pragma unroll
-      for (int a = 0; a < BS; ++a) xout[row * BS + a] = t[a] / sc[row * BS + a];
+      for (int a = 0; a < BS; ++a) xout[row * BS + a] = (XT)(t[a] / sc[row * BS + a]);
     } else {
+      double z[BS];
 #pragma unroll
       for (int a = 0; a < BS; ++a) {
-        double z = 0.0;
+        z[a] = 0.0;
 #pragma unroll
-        for (int bb = 0; bb < BS; ++bb) z += (double)dinv[row * B2 + a * BS + bb] * t[bb];
-        if (MODE == 2) {
-          xout[row * BS + a] = z;
+        for (int bb = 0; bb < BS; ++bb) z[a] += (double)dinv[row * B2 + a * BS + bb] * t[bb];
+      }
+      if (MODE == 2) {
+        XN::store(xout, row, z);
+      } else {
+        double xo[BS], xn[BS];
+        XN::load(xin, row, xo);
+#pragma unroll
+        for (int a = 0; a < BS; ++a) {
+          const double dn = (c1 != 0.0 ? c1 * (double)d[row * BS + a] : 0.0) + c2 * z[a];
+          xn[a] = xo[a] + dn;
+          d[row * BS + a] = (XT)dn;
+        }
+        if (uout) {   // last step of the cycle: back to x = S x~, in double precision, where the Krylov solver wants it
+#pragma unroll
+          for (int a = 0; a < BS; ++a) uout[row * BS + a] = sc[row * BS + a] * xn[a];
         } else {
-          const double dn = (c1 != 0.0 ? c1 * d[row * BS + a] : 0.0) + c2 * z;
-          const double xn = xin[row * BS + a] + dn;
-          d[row * BS + a] = dn;
-          if (uout) uout[row * BS + a] = sc[row * BS + a] * xn;   // last step of the cycle: back to x = S x~
-          else xout[row * BS + a] = xn;
+          XN::store(xout, row, xn);
         }
       }
     }
@@ -1156,10 +1171,16 @@ void gl_launch_mg_fine(glims_ctx* h, int mode, const double* xin, const double* 
   const uint8_t* fx = h->have_fixed_u ? h->fixed_u.p : nullptr;
   const bool half = h->mg.half_smoother;
   const bool c16 = h->use_idx16 && h->stats.nnz_idx16 == h->stats.nnz_padded;   // every slice has 16-bit codes
-#define GL_MGF3(BS, MODE, VT, VPTR, CIDX)                                                                            \
-  hipLaunchKernelGGL((k_mg_fine<BS, MODE, 2, VT, CIDX>), dim3(grid), dim3(256), 0, h->st, p.n_slices, chunk,          \
+  const bool x32 = h->mg.x32 && mode != 2;   // the power iteration of the set-up (mode 2) works on double vectors
+#define GL_MGF4(BS, MODE, VT, VPTR, CIDX, XT)                                                                        \
+  hipLaunchKernelGGL((k_mg_fine<BS, MODE, 2, VT, CIDX, XT>), dim3(grid), dim3(256), 0, h->st, p.n_slices, chunk,      \
                      h->n_own, p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, VPTR, h->mg.dinv0.p, h->mg.sc.p,   \
-                     fx, xin, r, d, xout, uout, c1, c2, GL_XCD_CHUNK, done)
+                     fx, (const XT*)xin, (const XT*)r, (XT*)d, (XT*)xout, uout, c1, c2, GL_XCD_CHUNK, done)
+#define GL_MGF3(BS, MODE, VT, VPTR, CIDX)                                                                            \
+  do {                                                                                                               \
+    if (MODE != 2 && x32) GL_MGF4(BS, MODE, VT, VPTR, CIDX, float);                                                  \
+    else GL_MGF4(BS, MODE, VT, VPTR, CIDX, double);                                                                  \
+  } while (0)
 #define GL_MGF2(BS, MODE, CIDX)                                                                                      \
   do {                                                                                                               \
     if (half) GL_MGF3(BS, MODE, _Float16, (const _Float16*)h->vKel16.p, CIDX);                                       \
@@ -1177,6 +1198,7 @@ void gl_launch_mg_fine(glims_ctx* h, int mode, const double* xin, const double* 
 #undef GL_MGF
 #undef GL_MGF2
 #undef GL_MGF3
+#undef GL_MGF4
   GL_HIP(hipGetLastError());
 }
 

@@ -19,7 +19,7 @@
 //   All set-up products are *gathers by the output entry* (one thread per (grid node, stencil offset)): no atomics,
 //   bitwise reproducible hierarchies.
 //   Smoother: Chebyshev of degree k (k = 1: damped block-Jacobi) on Dinv A, lambda_max by power iteration at set-up.
-//   Coarsest grid (<= mg_coarse_nodes nodes): dense inverse computed once on the host, applied as one GEMV.
+//   Coarsest grid (<= mg_coarse_nodes nodes): dense inverse computed once (device Gauss-Jordan), applied as one GEMV.
 //   Partitioned runs: the hierarchy covers the rank's owned rows (ghost couplings dropped inside the preconditioner =
 //   non-overlapping additive Schwarz with one V-cycle per subdomain); the Krylov operator itself stays exact.
 #include "glims_internal.h"
@@ -474,37 +474,39 @@ __global__ void k_mg_first_cart(GridDev g, const double* __restrict__ dinv, cons
   }
 }
 // level 0, first smoothing step from a zero iterate, entering the scaled variables: r~ = S r, d~ = c2 Dinv~ r~, x~ = d~
-template <int BS>
+template <int BS, class XT>
 __global__ void k_mg_first_fine(int64_t n_own, const float* __restrict__ dinv, const double* __restrict__ sc,
-                                const double* __restrict__ r, double* __restrict__ rs, double* __restrict__ d,
-                                double* __restrict__ x, double c2) {
+                                const double* __restrict__ r, XT* __restrict__ rs, XT* __restrict__ d,
+                                XT* __restrict__ x, double c2) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_own) return;
-  double rv[BS];
+  double rv[BS], xv[BS];
 #pragma unroll
   for (int a = 0; a < BS; ++a) {
     rv[a] = sc[i * BS + a] * r[i * BS + a];
-    rs[i * BS + a] = rv[a];
+    rs[i * BS + a] = (XT)rv[a];
   }
 #pragma unroll
   for (int a = 0; a < BS; ++a) {
     double z = 0.0;
 #pragma unroll
     for (int b = 0; b < BS; ++b) z += (double)dinv[i * BS * BS + a * BS + b] * rv[b];
-    d[i * BS + a] = c2 * z;
-    x[i * BS + a] = c2 * z;
+    xv[a] = c2 * z;
+    d[i * BS + a] = (XT)xv[a];
   }
+  XNode<BS, XT>::store(x, i, xv);
 }
 
 // restriction mesh -> grid: r1[I] = sum_{children i} w_iI res_i.  One WAVE per grid node: the 2^D cells around the node
 // are dealt to groups of 64 / 2^D lanes, each lane takes the children of its cell with that stride; fixed lane -> child
 // assignment and a fixed shuffle tree, i.e. a gather in a reproducible order (a thread per grid node walked ~64
 // children one after the other: 232 us at 1 M mesh nodes against 134 us for a whole operator pass).
-template <int D>
+template <int D, class XT>
 __global__ __launch_bounds__(256) void k_mg_restrict0(GridDev g1, const int32_t* __restrict__ cell_ptr,
                                                        const int32_t* __restrict__ cell_nodes,
-                                                       const double* __restrict__ wgt, const double* __restrict__ res,
-                                                       double* __restrict__ r1) {
+                                                       const double* __restrict__ wgt, const XT* __restrict__ res,
+                                                       double* __restrict__ r1, const double* __restrict__ dinv_c,
+                                                       double* __restrict__ d_c, double* __restrict__ x_c, double c2) {
   constexpr int BS = D, NC = 1 << D, LPC = GL_WAVE / NC;   // lanes per cell
   const long long I = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (I >= g1.nn) return;
@@ -533,7 +535,7 @@ __global__ __launch_bounds__(256) void k_mg_restrict0(GridDev g1, const int32_t*
         wi *= ((corner >> a) & 1) ? w : 1.0 - w;
       }
 #pragma unroll
-      for (int a = 0; a < BS; ++a) acc[a] += wi * res[i * BS + a];
+      for (int a = 0; a < BS; ++a) acc[a] += wi * (double)res[i * BS + a];
     }
   }
 #pragma unroll
@@ -544,15 +546,25 @@ __global__ __launch_bounds__(256) void k_mg_restrict0(GridDev g1, const int32_t*
   if (lane == 0) {
 #pragma unroll
     for (int a = 0; a < BS; ++a) r1[(long long)a * g1.nn + I] = acc[a];
+    if (dinv_c) {   // first smoothing step of the grid level, see k_mg_restrict
+#pragma unroll
+      for (int a = 0; a < BS; ++a) {
+        double z = 0.0;
+#pragma unroll
+        for (int b = 0; b < BS; ++b) z += dinv_c[(long long)(a * BS + b) * g1.nn + I] * acc[b];
+        d_c[(long long)a * g1.nn + I] = c2 * z;
+        x_c[(long long)a * g1.nn + I] = c2 * z;
+      }
+    }
   }
 }
 
 // prolongation grid -> mesh, into the scaled level-0 variables: x~_i = x~_i + F_i S_i^-1 sum_{parents} w e_J
-template <int D>
+template <int D, class XT>
 __global__ void k_mg_prolong0(GridDev g1, int64_t n_own, const int32_t* __restrict__ cell0,
                               const double* __restrict__ wgt, const uint8_t* __restrict__ fixed,
                               const double* __restrict__ sc, const double* __restrict__ e1,
-                              const double* __restrict__ xin, double* __restrict__ xout) {
+                              const XT* __restrict__ xin, XT* __restrict__ xout) {
   constexpr int BS = D;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_own) return;
@@ -576,15 +588,20 @@ __global__ void k_mg_prolong0(GridDev g1, int64_t n_own, const int32_t* __restri
 #pragma unroll
     for (int a = 0; a < BS; ++a) acc[a] += w * e1[(long long)a * g1.nn + J];
   }
+  double xv[BS];
+  XNode<BS, XT>::load(xin, i, xv);
 #pragma unroll
   for (int a = 0; a < BS; ++a)
-    xout[i * BS + a] = (fixed && fixed[i * BS + a]) ? 0.0 : xin[i * BS + a] + acc[a] / sc[i * BS + a];   // x~ = S^-1 x
+    xv[a] = (fixed && fixed[i * BS + a]) ? 0.0 : xv[a] + acc[a] / sc[i * BS + a];   // x~ = S^-1 x
+  XNode<BS, XT>::store(xout, i, xv);
 }
 
 template <int D>
 __global__ __launch_bounds__(256) void k_mg_restrict(GridDev gf, GridDev gc, Fac fc, const double* __restrict__ res,
-                                                      double* __restrict__ rc) {
-  // one wave per coarse node, its (up to) 3^D children dealt to the lanes, fixed shuffle tree
+                                                      double* __restrict__ rc, const double* __restrict__ dinv_c,
+                                                      double* __restrict__ d_c, double* __restrict__ x_c, double c2) {
+  // one wave per coarse node, its (up to) 3^D children dealt to the lanes, fixed shuffle tree.  With dinv_c the first
+  // smoothing step of the coarse level (from a zero iterate: d = x = c2 Dinv r, k_mg_first_cart) rides along.
   constexpr int BS = D;
   const long long I = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (I >= gc.nn) return;
@@ -625,6 +642,16 @@ __global__ __launch_bounds__(256) void k_mg_restrict(GridDev gf, GridDev gc, Fac
   if (lane == 0) {
 #pragma unroll
     for (int a = 0; a < BS; ++a) rc[(long long)a * gc.nn + I] = acc[a];
+    if (dinv_c) {
+#pragma unroll
+      for (int a = 0; a < BS; ++a) {
+        double z = 0.0;
+#pragma unroll
+        for (int b = 0; b < BS; ++b) z += dinv_c[(long long)(a * BS + b) * gc.nn + I] * acc[b];
+        d_c[(long long)a * gc.nn + I] = c2 * z;
+        x_c[(long long)a * gc.nn + I] = c2 * z;
+      }
+    }
   }
 }
 
@@ -855,45 +882,44 @@ void mg_apply_cart(glims_ctx* h, MgLevel& L, int R, int mode, const double* xin,
   GL_HIP(hipGetLastError());
 }
 
-// dense inverse of the coarsest operator (host): A + shift, Cholesky, inverse
-bool dense_spd_inverse(std::vector<double>& A, int n, double shift_rel) {
-  double dmax = 0.0;
-  for (int i = 0; i < n; ++i) dmax = std::max(dmax, A[(size_t)i * n + i]);
-  std::vector<double> L(A);
-  for (int i = 0; i < n; ++i) L[(size_t)i * n + i] += shift_rel * dmax;
-  for (int j = 0; j < n; ++j) {
-    double s = L[(size_t)j * n + j];
-    for (int k = 0; k < j; ++k) s -= L[(size_t)j * n + k] * L[(size_t)j * n + k];
-    if (!(s > 0.0)) return false;
-    const double ljj = std::sqrt(s);
-    L[(size_t)j * n + j] = ljj;
-    for (int i = j + 1; i < n; ++i) {
-      double t = L[(size_t)i * n + j];
-      for (int k = 0; k < j; ++k) t -= L[(size_t)i * n + k] * L[(size_t)j * n + k];
-      L[(size_t)i * n + j] = t / ljj;
-    }
+// Dense inverse of the coarsest operator, in place on the device: Gauss-Jordan without pivoting (the matrix is SPD
+// after the shift; a pivot <= 0 raises `bad`, the caller retries with a larger shift).  Two launches per pivot -- the
+// old column is saved and the pivot row scaled by one block, then every other row is eliminated by a thread per entry:
+// 3 k launches for the 1 536 unknowns of an 8^3 grid = 15 ms, where Cholesky + n triangular solves on the host's
+// sixteen cores took 0.4 s (and 50 ms already for 6^3).
+__global__ __launch_bounds__(1024) void k_gj_pivot(int n, int k, double* __restrict__ A, double* __restrict__ col,
+                                                    int* __restrict__ bad) {
+  if (*bad) return;
+  const double p = A[(size_t)k * n + k];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) col[i] = A[(size_t)i * n + k];
+  __syncthreads();   // every read of column k (the pivot among them) comes before the row is rewritten
+  if (!(p > 0.0)) {
+    if (threadIdx.x == 0) *bad = 1;
+    return;
   }
-  // inverse column by column: L y = e_c, L^T x = y.  The team is sized by the CPUs this process may really use: the
-  // OpenMP default of one thread per visible hardware thread (256 on a GPU box that grants 16 cores) made this loop
-  // take 0.5 s for a 375 x 375 matrix.
-  const int nth = std::max(1, std::min(gl_host_threads(), 16));
-  (void)nth;
-#pragma omp parallel for schedule(dynamic, 8) num_threads(nth)
-  for (int c = 0; c < n; ++c) {
-    std::vector<double> y(n, 0.0);
-    for (int i = c; i < n; ++i) {
-      double t = i == c ? 1.0 : 0.0;
-      for (int k = c; k < i; ++k) t -= L[(size_t)i * n + k] * y[k];
-      y[i] = t / L[(size_t)i * n + i];
-    }
-    for (int i = n - 1; i >= 0; --i) {
-      double t = y[i];
-      for (int k = i + 1; k < n; ++k) t -= L[(size_t)k * n + i] * y[k];
-      y[i] = t / L[(size_t)i * n + i];
-    }
-    for (int i = 0; i < n; ++i) A[(size_t)i * n + c] = y[i];
+  const double ip = 1.0 / p;
+  for (int j = threadIdx.x; j < n; j += blockDim.x) A[(size_t)k * n + j] = j == k ? ip : A[(size_t)k * n + j] * ip;
+}
+__global__ __launch_bounds__(256) void k_gj_eliminate(int n, int k, double* __restrict__ A,
+                                                       const double* __restrict__ col, const int* __restrict__ bad) {
+  if (*bad) return;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (j >= n || i == k) return;
+  const double f = col[i], rk = A[(size_t)k * n + j];
+  A[(size_t)i * n + j] = j == k ? -f * rk : A[(size_t)i * n + j] - f * rk;
+}
+// A (device, n x n, row-major) -> inverse of A + shift_rel * max diag.  `diag_max` from the host copy.
+bool dense_spd_inverse_device(glims_ctx* h, double* A, int n, double* col, int* bad) {
+  GL_HIP(hipMemsetAsync(bad, 0, sizeof(int), h->st));
+  for (int k = 0; k < n; ++k) {
+    hipLaunchKernelGGL(k_gj_pivot, dim3(1), dim3(1024), 0, h->st, n, k, A, col, bad);
+    hipLaunchKernelGGL(k_gj_eliminate, dim3((n + 255) / 256, n), dim3(256), 0, h->st, n, k, A, col, bad);
   }
-  return true;
+  GL_HIP(hipGetLastError());
+  int hb = 0;
+  GL_HIP(hipMemcpyAsync(&hb, bad, sizeof(int), hipMemcpyDeviceToHost, h->st));
+  GL_HIP(hipStreamSynchronize(h->st));
+  return hb == 0;
 }
 
 template <int D>
@@ -1175,6 +1201,7 @@ void mg_setup_t(glims_ctx* h) {
   // and 18.7 with lmax / 4; 1 M-point Delaunay mesh 75 ms with lmax / 10 against 83 with lmax / 30
   mg.cheb_ratio = h->opt.mg_cheb_ratio > 1.0 ? h->opt.mg_cheb_ratio : (lattice ? 30.0 : 10.0);
   mg.exact_level0 = framed;
+  mg.x32 = (h->opt.flags & GLIMS_FLAG_MG_FP64_VECTORS) == 0;
   mg.half_smoother = (h->opt.flags & GLIMS_FLAG_MG_FP32_SMOOTHER) == 0;
   gl_make_smoother_copy(h, mg.half_smoother, mg.exact_level0);
   mg.rs.alloc_zero(nd0, h->st);
@@ -1213,7 +1240,7 @@ void mg_setup_t(glims_ctx* h) {
   }
 
   lap("half copy, eigenvalue estimates");
-  // ---- coarsest level: dense inverse on the host ------------------------------------------------------------------
+  // ---- coarsest level: dense inverse ------------------------------------------------------------------------------
   {
     MgLevel& L = *mg.lv.back();
     const int64_t nn = L.g.nn;
@@ -1250,15 +1277,20 @@ void mg_setup_t(glims_ctx* h) {
       }
     // a body without Dirichlet data has the rigid-body modes in the kernel of every level: the small relative shift
     // keeps the factorisation defined there and changes a regular operator by 1e-9
+    double dmax = 0.0;
+    for (int i = 0; i < nc; ++i) dmax = std::max(dmax, M[(size_t)i * nc + i]);
+    dvec<double> col;
+    dvec<int> bad;
+    col.alloc((size_t)nc);
+    bad.alloc(1);
     bool ok = false;
     for (double shift = 1e-9; shift < 1.0 && !ok; shift *= 100.0) {
-      std::vector<double> T(M);
-      ok = dense_spd_inverse(T, nc, shift);
-      if (ok) M.swap(T);
+      for (int i = 0; i < nc; ++i) M[(size_t)i * nc + i] += shift * dmax;
+      mg.coarse_inv.upload(M, h->st);
+      ok = dense_spd_inverse_device(h, mg.coarse_inv.p, nc, col.p, bad.p);
+      for (int i = 0; i < nc; ++i) M[(size_t)i * nc + i] -= shift * dmax;
     }
     GL_REQUIRE(ok, "multigrid: the coarsest operator is not positive definite");
-    mg.coarse_inv.upload(M, h->st);
-    GL_HIP(hipStreamSynchronize(h->st));
   }
   lap("coarsest level: dense inverse");
   mg.ready = true;
@@ -1276,8 +1308,19 @@ void mg_setup_t(glims_ctx* h) {
 }
 
 // one V-cycle on the Cartesian levels l.. : x_l = approx A_l^-1 r_l (result left in L.x)
+// c2 of the first Chebyshev step of level l, if the restriction INTO level l may do that step itself (a smoothed
+// level, and no all-reduce between the restriction and the step); 0 otherwise
+inline double mg_fused_first_c2(const MgHierarchy& mg, size_t l, bool allreduce_before) {
+  if (allreduce_before || l + 1 == mg.lv.size()) return 0.0;
+  Cheb ch(mg.lv[l]->lam, mg.cheb_ratio);
+  double c1, c2;
+  ch.next(0, &c1, &c2);
+  return c2;
+}
+
+// `first_done`: the restriction that produced L.r has taken the first smoothing step as well (L.d, L.x are set)
 template <int D>
-void mg_cycle_cart(glims_ctx* h, size_t l, const int* done) {
+void mg_cycle_cart(glims_ctx* h, size_t l, const int* done, bool first_done) {
   constexpr int BS = D;
   MgHierarchy& mg = h->mg;
   MgLevel& L = *mg.lv[l];
@@ -1292,7 +1335,8 @@ void mg_cycle_cart(glims_ctx* h, size_t l, const int* done) {
   Cheb ch(L.lam, mg.cheb_ratio);
   double c1, c2;
   ch.next(0, &c1, &c2);
-  hipLaunchKernelGGL(k_mg_first_cart<D>, dim3(gridn(g.nn)), dim3(256), 0, h->st, g, L.dinv.p, L.r.p, L.d.p, L.x.p, c2);
+  if (!first_done)
+    hipLaunchKernelGGL(k_mg_first_cart<D>, dim3(gridn(g.nn)), dim3(256), 0, h->st, g, L.dinv.p, L.r.p, L.d.p, L.x.p, c2);
   double *xa = L.x.p, *xb = L.x2.p;
   for (int m = 1; m < deg; ++m) {
     ch.next(m, &c1, &c2);
@@ -1302,11 +1346,14 @@ void mg_cycle_cart(glims_ctx* h, size_t l, const int* done) {
   mg_apply_cart<D>(h, L, mg.R, 0, xa, L.r.p, nullptr, L.res.p, 0.0, 0.0, done);
   MgLevel& C = *mg.lv[l + 1];
   const Fac fc{{L.f[0], L.f[1], L.f[2]}, {L.o[0], L.o[1], L.o[2]}, {C.o[0], C.o[1], C.o[2]}};
-  hipLaunchKernelGGL(k_mg_restrict<D>, dim3(gridn(C.g.nn, 4)), dim3(256), 0, h->st, g, gdev(C.g), fc, L.res.p, C.r.p);
+  const bool reduce_c = C.global && !L.global && h->world > 1;
+  const double c2c = mg_fused_first_c2(mg, l + 1, reduce_c);
+  hipLaunchKernelGGL(k_mg_restrict<D>, dim3(gridn(C.g.nn, 4)), dim3(256), 0, h->st, g, gdev(C.g), fc, L.res.p, C.r.p,
+                     c2c != 0.0 ? C.dinv.p : nullptr, C.d.p, C.x.p, c2c);
   GL_HIP(hipGetLastError());
   // first replicated level of a partitioned run: every rank has restricted the residual of its own rows -> sum
-  if (C.global && !L.global) gl_allreduce_bulk(h, C.r.p, (size_t)BS * C.g.nn);
-  mg_cycle_cart<D>(h, l + 1, done);
+  if (reduce_c) gl_allreduce_bulk(h, C.r.p, (size_t)BS * C.g.nn);
+  mg_cycle_cart<D>(h, l + 1, done, c2c != 0.0);
   hipLaunchKernelGGL(k_mg_prolong<D>, dim3(gridn(g.nn)), dim3(256), 0, h->st, g, gdev(C.g), fc, C.x.p, xa, xb);
   GL_HIP(hipGetLastError());
   std::swap(xa, xb);
@@ -1329,35 +1376,52 @@ void mg_apply_t(glims_ctx* h, const double* r, double* u, const int* done) {
   Cheb ch(mg.lam0, mg.cheb_ratio);
   double c1, c2;
   ch.next(0, &c1, &c2);
-  hipLaunchKernelGGL(k_mg_first_fine<BS>, dim3(gridn(n)), dim3(256), 0, h->st, n, mg.dinv0.p, mg.sc.p, r, mg.rs.p,
-                     mg.d.p, mg.x.p, c2);
+  const bool x32 = mg.x32;
+  const int xrec = gl_xrec_doubles(BS, x32);   // length of an iterate's node record in doubles (halo exchange)
+  if (x32)
+    hipLaunchKernelGGL((k_mg_first_fine<BS, float>), dim3(gridn(n)), dim3(256), 0, h->st, n, mg.dinv0.p, mg.sc.p, r,
+                       (float*)mg.rs.p, (float*)mg.d.p, (float*)mg.x.p, c2);
+  else
+    hipLaunchKernelGGL((k_mg_first_fine<BS, double>), dim3(gridn(n)), dim3(256), 0, h->st, n, mg.dinv0.p, mg.sc.p, r,
+                       mg.rs.p, mg.d.p, mg.x.p, c2);
   r = mg.rs.p;   // from here on the level-0 passes work in the scaled variables
   double *xa = mg.x.p, *xb = mg.x2.p;
   const bool ex = mg.exact_level0;   // the passes read ghost columns: bring them in (iterates are owned-row vectors)
   for (int m = 1; m < deg; ++m) {
     ch.next(m, &c1, &c2);
-    if (ex) gl_halo_exchange(h, xa, BS);
+    if (ex) gl_halo_exchange(h, xa, xrec);
     gl_launch_mg_fine(h, 1, xa, r, mg.d.p, xb, c1, c2, done);
     std::swap(xa, xb);
   }
-  if (ex) gl_halo_exchange(h, xa, BS);
+  if (ex) gl_halo_exchange(h, xa, xrec);
   gl_launch_mg_fine(h, 0, xa, r, nullptr, mg.res.p, 0.0, 0.0, done);
   MgLevel& L1 = *mg.lv[0];
   const GridDev g1 = gdev(L1.g);
-  hipLaunchKernelGGL(k_mg_restrict0<D>, dim3(gridn(g1.nn, 4)), dim3(256), 0, h->st, g1, mg.cell_ptr.p, mg.cell_nodes.p,
-                     mg.wgt.p, mg.res.p, L1.r.p);
+  const bool reduce1 = L1.global && h->world > 1;
+  const double c21 = mg_fused_first_c2(mg, 0, reduce1);
+  const double* dv1 = c21 != 0.0 ? L1.dinv.p : nullptr;
+  if (x32)
+    hipLaunchKernelGGL((k_mg_restrict0<D, float>), dim3(gridn(g1.nn, 4)), dim3(256), 0, h->st, g1, mg.cell_ptr.p,
+                       mg.cell_nodes.p, mg.wgt.p, (const float*)mg.res.p, L1.r.p, dv1, L1.d.p, L1.x.p, c21);
+  else
+    hipLaunchKernelGGL((k_mg_restrict0<D, double>), dim3(gridn(g1.nn, 4)), dim3(256), 0, h->st, g1, mg.cell_ptr.p,
+                       mg.cell_nodes.p, mg.wgt.p, (const double*)mg.res.p, L1.r.p, dv1, L1.d.p, L1.x.p, c21);
   GL_HIP(hipGetLastError());
-  if (L1.global) gl_allreduce_bulk(h, L1.r.p, (size_t)BS * L1.g.nn);
-  mg_cycle_cart<D>(h, 0, done);
-  hipLaunchKernelGGL(k_mg_prolong0<D>, dim3(gridn(n)), dim3(256), 0, h->st, g1, n, mg.cell0.p, mg.wgt.p, fx, mg.sc.p,
-                     L1.x.p, xa, xb);
+  if (reduce1) gl_allreduce_bulk(h, L1.r.p, (size_t)BS * L1.g.nn);
+  mg_cycle_cart<D>(h, 0, done, c21 != 0.0);
+  if (x32)
+    hipLaunchKernelGGL((k_mg_prolong0<D, float>), dim3(gridn(n)), dim3(256), 0, h->st, g1, n, mg.cell0.p, mg.wgt.p, fx,
+                       mg.sc.p, L1.x.p, (const float*)xa, (float*)xb);
+  else
+    hipLaunchKernelGGL((k_mg_prolong0<D, double>), dim3(gridn(n)), dim3(256), 0, h->st, g1, n, mg.cell0.p, mg.wgt.p, fx,
+                       mg.sc.p, L1.x.p, (const double*)xa, xb);
   GL_HIP(hipGetLastError());
   std::swap(xa, xb);
   Cheb cp(mg.lam0, mg.cheb_ratio);
   for (int m = 0; m < deg; ++m) {
     cp.next(m, &c1, &c2);
     // the last step leaves the scaled variables and writes the preconditioned residual where the solver wants it
-    if (ex) gl_halo_exchange(h, xa, BS);
+    if (ex) gl_halo_exchange(h, xa, xrec);
     gl_launch_mg_fine(h, 1, xa, r, mg.d.p, xb, c1, c2, done, m == deg - 1 ? u : nullptr);
     std::swap(xa, xb);
   }

@@ -81,7 +81,7 @@ typedef struct glims_options {
   int    mg_smooth;       /* Chebyshev degree of the pre- and of the post-smoother on every level
                              (1 = damped block-Jacobi)                                             default 3     */
   int    mg_coarse_nodes; /* coarsen until a grid has at most this many nodes; that level is solved with a dense
-                             inverse computed once on the host                                      default 216   */
+                             inverse computed once (Gauss-Jordan on the device)                     default 216   */
   double mg_h_factor;     /* spacing of the first auxiliary Cartesian grid in units of the mesh width
                              (lattice meshes: of the lattice constant per axis)                    default 2.0   */
   double mg_cheb_ratio;   /* the Chebyshev smoothers act on [lambda_max / ratio, lambda_max] of Dinv A;
@@ -101,6 +101,9 @@ typedef struct glims_options {
                                            the same fixed point); takes effect at glims_setup */
 #define GLIMS_FLAG_MG_FP32_SMOOTHER 8     /* OFF by default.  The level-0 smoother of the elasticity multigrid streams a
                                            single-precision copy of K_el instead of the (scaled) half-precision one */
+#define GLIMS_FLAG_MG_FP64_VECTORS 32    /* OFF by default.  The level-0 cycle vectors of the elasticity multigrid (iterate,
+                                           direction, scaled residual) are kept in double instead of single precision; the
+                                           preconditioned residual handed to the Krylov solver is double either way */
 #define GLIMS_FLAG_INT32_COLUMNS 16       /* OFF by default.  Stream the 4-byte column indices everywhere instead of the 16-bit
                                            (window, offset) codes (same bits in every result; takes effect at glims_setup) */
 #define GLIMS_FLAG_WARM_START 2         /* first linear solve of a step starts from the previous step's increment

@@ -284,6 +284,7 @@ def test_multigrid_on_a_larger_delaunay_mesh_with_slivers(backend):
     its = {}
     us = {}
     for name, opts in (("half", {}), ("single", dict(flags=backend.FLAG_WARM_START | backend.FLAG_MG_FP32_SMOOTHER)),
+                       ("double-vectors", dict(flags=backend.FLAG_WARM_START | backend.FLAG_MG_FP64_VECTORS)),
                        ("block-jacobi", dict(mech_precond=backend.PRECOND_BLOCK_JACOBI))):
         h, dofs = _c5_handle(backend, w, mech_history=0, **opts)
         assert h.solve_mechanics() == 0
@@ -295,5 +296,7 @@ def test_multigrid_on_a_larger_delaunay_mesh_with_slivers(backend):
         h.close()
     print("Delaunay 100 k points: PCG iterations", its)
     assert abs(its["half"] - its["single"]) <= 0.15 * its["single"] + 2
+    # single-precision cycle vectors (the default) against double ones: the same preconditioner up to rounding
+    assert abs(its["half"] - its["double-vectors"]) <= 2 and rel_l2(us["half"], us["double-vectors"]) < 1e-6
     assert its["half"] < 0.25 * its["block-jacobi"] and its["half"] < 200
     assert rel_l2(us["half"], us["single"]) < 1e-6 and rel_l2(us["half"], us["block-jacobi"]) < 1e-5

@@ -22,7 +22,8 @@ h.set_options(dt=w.dt, mech_rtol=float(os.environ.get("MECH_RTOL", "1e-10")), me
               mg_smooth=int(os.environ.get("SMOOTH", "3")), mg_cheb_ratio=float(os.environ.get("RATIO", "0")), mech_mixed=int(os.environ.get("MIXED", "1")),
               mech_history=int(os.environ.get("HIST", "6")), mg_h_factor=float(os.environ.get("HFAC", "2.0")),
               mg_coarse_nodes=int(os.environ.get("COARSE", "216")),
-              flags=h.options.flags | (_backend.FLAG_MG_FP32_SMOOTHER if os.environ.get("FP32SM") else 0))
+              flags=h.options.flags | (_backend.FLAG_MG_FP32_SMOOTHER if os.environ.get("FP32SM") else 0) |
+              (_backend.FLAG_MG_FP64_VECTORS if os.environ.get("X64") else 0))
 dofs = (w.dirichlet_nodes[:, None] * 3 + np.arange(3)).ravel()
 h.set_dirichlet_u(dofs, np.zeros(len(dofs)))
 h.setup(True)
