@@ -505,8 +505,7 @@ template <int D, class XT>
 __global__ __launch_bounds__(256) void k_mg_restrict0(GridDev g1, const int32_t* __restrict__ cell_ptr,
                                                        const int32_t* __restrict__ cell_nodes,
                                                        const double* __restrict__ wgt, const XT* __restrict__ res,
-                                                       double* __restrict__ r1, const double* __restrict__ dinv_c,
-                                                       double* __restrict__ d_c, double* __restrict__ x_c, double c2) {
+                                                       double* __restrict__ r1) {
   constexpr int BS = D, NC = 1 << D, LPC = GL_WAVE / NC;   // lanes per cell
   const long long I = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (I >= g1.nn) return;
@@ -546,16 +545,6 @@ __global__ __launch_bounds__(256) void k_mg_restrict0(GridDev g1, const int32_t*
   if (lane == 0) {
 #pragma unroll
     for (int a = 0; a < BS; ++a) r1[(long long)a * g1.nn + I] = acc[a];
-    if (dinv_c) {   // first smoothing step of the grid level, see k_mg_restrict
-#pragma unroll
-      for (int a = 0; a < BS; ++a) {
-        double z = 0.0;
-#pragma unroll
-        for (int b = 0; b < BS; ++b) z += dinv_c[(long long)(a * BS + b) * g1.nn + I] * acc[b];
-        d_c[(long long)a * g1.nn + I] = c2 * z;
-        x_c[(long long)a * g1.nn + I] = c2 * z;
-      }
-    }
   }
 }
 
@@ -1397,18 +1386,17 @@ void mg_apply_t(glims_ctx* h, const double* r, double* u, const int* done) {
   gl_launch_mg_fine(h, 0, xa, r, nullptr, mg.res.p, 0.0, 0.0, done);
   MgLevel& L1 = *mg.lv[0];
   const GridDev g1 = gdev(L1.g);
-  const bool reduce1 = L1.global && h->world > 1;
-  const double c21 = mg_fused_first_c2(mg, 0, reduce1);
-  const double* dv1 = c21 != 0.0 ? L1.dinv.p : nullptr;
+  // (the first smoothing step of the grid level is NOT fused into this restriction as it is between the Cartesian levels:
+  // one active lane per wave fetching Dinv made the kernel 33 us slower at 125 k grid nodes, the separate pass costs 5)
   if (x32)
     hipLaunchKernelGGL((k_mg_restrict0<D, float>), dim3(gridn(g1.nn, 4)), dim3(256), 0, h->st, g1, mg.cell_ptr.p,
-                       mg.cell_nodes.p, mg.wgt.p, (const float*)mg.res.p, L1.r.p, dv1, L1.d.p, L1.x.p, c21);
+                       mg.cell_nodes.p, mg.wgt.p, (const float*)mg.res.p, L1.r.p);
   else
     hipLaunchKernelGGL((k_mg_restrict0<D, double>), dim3(gridn(g1.nn, 4)), dim3(256), 0, h->st, g1, mg.cell_ptr.p,
-                       mg.cell_nodes.p, mg.wgt.p, (const double*)mg.res.p, L1.r.p, dv1, L1.d.p, L1.x.p, c21);
+                       mg.cell_nodes.p, mg.wgt.p, (const double*)mg.res.p, L1.r.p);
   GL_HIP(hipGetLastError());
-  if (reduce1) gl_allreduce_bulk(h, L1.r.p, (size_t)BS * L1.g.nn);
-  mg_cycle_cart<D>(h, 0, done, c21 != 0.0);
+  if (L1.global) gl_allreduce_bulk(h, L1.r.p, (size_t)BS * L1.g.nn);
+  mg_cycle_cart<D>(h, 0, done, false);
   if (x32)
     hipLaunchKernelGGL((k_mg_prolong0<D, float>), dim3(gridn(n)), dim3(256), 0, h->st, g1, n, mg.cell0.p, mg.wgt.p, fx,
                        mg.sc.p, L1.x.p, (const float*)xa, (float*)xb);
