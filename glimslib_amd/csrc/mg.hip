@@ -454,6 +454,77 @@ __global__ __launch_bounds__(256) void k_mg_cart_w(GridDev g, int R, int S, cons
   }
 }
 
+// The same pass for MEDIUM grids (a few thousand to a few ten thousand nodes): G lanes per node, each walking every
+// G-th stencil offset, partial sums combined by a fixed xor-shuffle tree.  Lane = sub * (64 / G) + node-in-wave, so that
+// the lanes of one `sub` read 64 / G consecutive nodes of one operator plane.  A thread per node is a serial chain of
+// 27 (125) x B2 loads with too few threads to fill the device at these sizes; a wave per node wastes 37 of 64 lanes.
+template <int D, int MODE, int G>
+__global__ __launch_bounds__(256) void k_mg_cart_g(GridDev g, int R, int S, const float* __restrict__ A,
+                                                    const double* __restrict__ dinv, const double* __restrict__ xin,
+                                                    const double* __restrict__ r, double* __restrict__ d,
+                                                    double* __restrict__ xout, double c1, double c2,
+                                                    const int* __restrict__ done) {
+  constexpr int BS = D, B2 = D * D, NPW = GL_WAVE / G;   // nodes per wave
+  if (done && *done) return;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / NPW;
+  const long long I = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * NPW + (lane % NPW);
+  const bool live = I < g.nn;
+  int Iv[3] = {0, 0, 0};
+  if (live) lin2v(I, g, Iv);
+  double acc[BS];
+#pragma unroll
+  for (int a = 0; a < BS; ++a) acc[a] = 0.0;
+  if (live)
+    for (int off = sub; off < S; off += G) {
+      int o[3], nv[3] = {0, 0, 0};
+      off2v<D>(off, R, o);
+      bool in = true;
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        nv[a] = Iv[a] + o[a];
+        in = in && nv[a] >= 0 && nv[a] < gn(g, a);
+      }
+      if (!in) continue;
+      const long long nb = v2lin(nv, g);
+      const float* a0 = A + (long long)off * B2 * g.nn + I;
+      double xb[BS];
+#pragma unroll
+      for (int b = 0; b < BS; ++b) xb[b] = xin[(long long)b * g.nn + nb];
+#pragma unroll
+      for (int a = 0; a < BS; ++a)
+#pragma unroll
+        for (int b = 0; b < BS; ++b) acc[a] += (double)a0[(long long)(a * BS + b) * g.nn] * xb[b];
+    }
+#pragma unroll
+  for (int a = 0; a < BS; ++a) {
+#pragma unroll
+    for (int o = GL_WAVE / 2; o >= NPW; o >>= 1) acc[a] += __shfl_xor(acc[a], o, 64);
+  }
+  if (!live || sub != 0) return;
+  double t[BS];
+#pragma unroll
+  for (int a = 0; a < BS; ++a) t[a] = MODE == 2 ? acc[a] : r[(long long)a * g.nn + I] - acc[a];
+  if (MODE == 0) {
+#pragma unroll
+    for (int a = 0; a < BS; ++a) xout[(long long)a * g.nn + I] = t[a];
+    return;
+  }
+#pragma unroll
+  for (int a = 0; a < BS; ++a) {
+    double z = 0.0;
+#pragma unroll
+    for (int b = 0; b < BS; ++b) z += dinv[(long long)(a * BS + b) * g.nn + I] * t[b];
+    if (MODE == 2) {
+      xout[(long long)a * g.nn + I] = z;
+    } else {
+      const double dn = (c1 != 0.0 ? c1 * d[(long long)a * g.nn + I] : 0.0) + c2 * z;
+      d[(long long)a * g.nn + I] = dn;
+      xout[(long long)a * g.nn + I] = xin[(long long)a * g.nn + I] + dn;
+    }
+  }
+}
+
 // first smoothing step from a zero iterate: d = c2 Dinv r, x = d   (no operator pass)
 template <int D>
 __global__ void k_mg_first_cart(GridDev g, const double* __restrict__ dinv, const double* __restrict__ r,
@@ -850,6 +921,18 @@ void mg_apply_cart(glims_ctx* h, MgLevel& L, int R, int mode, const double* xin,
                    double* xout, double c1, double c2, const int* done = nullptr) {
   const GridDev g = gdev(L.g);
   const unsigned grid = gridn(g.nn);
+  if (g.nn > 6000 && g.nn <= 60000) {   // medium grid: 4 lanes per node (26^3 nodes: -2.4 % per solve against a thread per
+    const int S = h->mg.S;              // node; 8 / 16 lanes the same; on 51^3 a thread per node is faster, below 6 k a wave)
+    const unsigned gw = gridn(g.nn, 4 * (GL_WAVE / 4));
+    if (mode == 0)
+      hipLaunchKernelGGL((k_mg_cart_g<D, 0, 4>), dim3(gw), dim3(256), 0, h->st, g, R, S, L.A.p, L.dinv.p, xin, r, d, xout, c1, c2, done);
+    else if (mode == 1)
+      hipLaunchKernelGGL((k_mg_cart_g<D, 1, 4>), dim3(gw), dim3(256), 0, h->st, g, R, S, L.A.p, L.dinv.p, xin, r, d, xout, c1, c2, done);
+    else
+      hipLaunchKernelGGL((k_mg_cart_g<D, 2, 4>), dim3(gw), dim3(256), 0, h->st, g, R, S, L.A.p, L.dinv.p, xin, r, d, xout, c1, c2, done);
+    GL_HIP(hipGetLastError());
+    return;
+  }
   if (g.nn <= 6000) {   // small grid: one wave per node (see k_mg_cart_w; slower than a thread per node from ~17 k nodes)
     const unsigned gw = gridn(g.nn, 4);
     const int S = h->mg.S;
