@@ -255,6 +255,17 @@ static __device__ __forceinline__ void node_allreduce(double* __restrict__ red, 
   if (!ok && lane == 0) *nm.err = 1;
 }
 
+static __device__ __forceinline__ int xcd_chunk_remap(int b, int nb, int G) {
+  // Hardware deals block b to XCD b % 8.  Give every XCD chunks of G consecutive logical blocks, chunk after chunk
+  // round-robin over the XCDs: neighbouring slices (overlapping x gathers) share one L2, while the eight XCDs
+  // together still walk the matrix front to back (one shared, moving x window in the Infinity Cache; DRAM pages are
+  // visited nearly sequentially).  Blocks beyond the last full group of 8*G keep their index -> bijective.
+  const int full = (nb / (8 * G)) * (8 * G);
+  if (b >= full) return b;
+  const int q = b >> 3, xcd = b & 7;
+  return ((q / G) * 8 + xcd) * G + (q % G);
+}
+
 // Level-0 cycle vectors of the elasticity multigrid.  XT = double: [node][BS] doubles.  XT = float (default): the
 // ITERATE lives in node records of 16 B (BS = 3: x, y, z, pad) / 8 B (BS = 2), so that a neighbour's value is ONE
 // aligned load in the smoother's gather instead of three 8-byte ones; residual / direction vectors are packed

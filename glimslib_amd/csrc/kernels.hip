@@ -14,17 +14,6 @@
 
 namespace {
 
-__device__ __forceinline__ int xcd_chunk_remap(int b, int nb, int G) {
-  // Hardware deals block b to XCD b % 8.  Give every XCD chunks of G consecutive logical blocks, chunk after chunk
-  // round-robin over the XCDs: neighbouring slices (overlapping x gathers) share one L2, while the eight XCDs
-  // together still walk the matrix front to back (one shared, moving x window in the Infinity Cache; DRAM pages are
-  // visited nearly sequentially).  Blocks beyond the last full group of 8*G keep their index -> bijective.
-  const int full = (nb / (8 * G)) * (8 * G);
-  if (b >= full) return b;
-  const int q = b >> 3, xcd = b & 7;
-  return ((q / G) * 8 + xcd) * G + (q % G);
-}
-
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);

@@ -103,19 +103,27 @@ __global__ void k_mg_reach(int64_t n_own, int64_t n_col, GridDev g1, const int64
 // A1[I, off] = sum_{i child of I} sum_{j in row i, I + off parent of j} w_iI w_j(I+off) F_i K_ij F_j
 // one thread per (grid node, stencil offset): a gather in a fixed order
 template <int D>
-__global__ void k_mg_rap0(GridDev g1, int R, int S, int64_t n_own, int64_t n_col,
+__global__ void k_mg_rap0(GridDev g1, int nbx, int nby, int R, int S, int64_t n_own, int64_t n_col,
                           const int32_t* __restrict__ cell_ptr,
                           const int32_t* __restrict__ cell_nodes, const int32_t* __restrict__ cell0,
                           const double* __restrict__ wgt, const int64_t* __restrict__ slice_ptr,
                           const int32_t* __restrict__ cols, const double* __restrict__ vK,
                           const uint8_t* __restrict__ fixed, float* __restrict__ A1) {
   constexpr int BS = D, B2 = D * D;
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= g1.nn * S) return;
-  const long long I = t / S;
-  const int off = (int)(t - I * S);
-  int Iv[3], o[3], Jv[3] = {0, 0, 0};
-  lin2v(I, g1, Iv);
+  // grid nodes in bricks of 4^3 (8^2), the blocks of four bricks in a row on one XCD: the nodes around a cell all
+  // walk the rows of its children (see k_mg_restrict0)
+  constexpr int BW = D == 3 ? 4 : 8;
+  const long long t = (long long)xcd_chunk_remap(blockIdx.x, gridDim.x, S) * blockDim.x + threadIdx.x;   // S blocks = 4 bricks
+  const long long Ib = t / S;
+  const int off = (int)(t - Ib * S);
+  const long long brick = Ib >> 6;
+  const int q = (int)(Ib & 63);
+  int Iv[3] = {0, 0, 0}, o[3], Jv[3] = {0, 0, 0};
+  Iv[0] = (int)(brick % nbx) * BW + (D == 3 ? (q & 3) : (q & 7));
+  Iv[1] = (int)((brick / nbx) % nby) * BW + (D == 3 ? ((q >> 2) & 3) : (q >> 3));
+  if (D == 3) Iv[2] = (int)(brick / ((long long)nbx * nby)) * BW + (q >> 4);
+  if (Iv[0] >= g1.n0 || Iv[1] >= g1.n1 || (D == 3 && Iv[2] >= g1.n2)) return;   // also every thread past the last brick
+  const long long I = v2lin(Iv, g1);
   off2v<D>(off, R, o);
   bool inside = true;
 #pragma unroll
@@ -573,17 +581,27 @@ __global__ void k_mg_first_fine(int64_t n_own, const float* __restrict__ dinv, c
 // assignment and a fixed shuffle tree, i.e. a gather in a reproducible order (a thread per grid node walked ~64
 // children one after the other: 232 us at 1 M mesh nodes against 134 us for a whole operator pass).
 template <int D, class XT>
-__global__ __launch_bounds__(256) void k_mg_restrict0(GridDev g1, const int32_t* __restrict__ cell_ptr,
+__global__ __launch_bounds__(256) void k_mg_restrict0(GridDev g1, int nbx, int nby, const int32_t* __restrict__ cell_ptr,
                                                        const int32_t* __restrict__ cell_nodes,
                                                        const double* __restrict__ wgt, const XT* __restrict__ res,
                                                        double* __restrict__ r1) {
   constexpr int BS = D, NC = 1 << D, LPC = GL_WAVE / NC;   // lanes per cell
-  const long long I = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (I >= g1.nn) return;
+  // Grid nodes are dealt to the waves in BRICKS of 4^3 (8^2) nodes = 16 blocks, four bricks in a row per XCD chunk: the
+  // 2^D grid nodes around a cell all read its children, and with the nodes in plain x-fastest order those eight reads
+  // came from eight different L2s (PMC: 296 MB per launch at 1 M mesh nodes for 50 MB of operands).
+  constexpr int BW = D == 3 ? 4 : 8;
+  const int b = xcd_chunk_remap(blockIdx.x, gridDim.x, 64);
+  const long long w = (long long)b * 4 + (threadIdx.x >> 6);
+  const long long brick = w >> 6;
+  const int q = (int)(w & 63);
   const int lane = threadIdx.x & 63;
+  int Iv[3] = {0, 0, 0};
+  Iv[0] = (int)(brick % nbx) * BW + (D == 3 ? (q & 3) : (q & 7));
+  Iv[1] = (int)((brick / nbx) % nby) * BW + (D == 3 ? ((q >> 2) & 3) : (q >> 3));
+  if (D == 3) Iv[2] = (int)(brick / ((long long)nbx * nby)) * BW + (q >> 4);
+  if (Iv[0] >= g1.n0 || Iv[1] >= g1.n1 || (D == 3 && Iv[2] >= g1.n2)) return;   // wave-uniform
+  const long long I = v2lin(Iv, g1);
   const int corner = lane / LPC, sub = lane % LPC;
-  int Iv[3];
-  lin2v(I, g1, Iv);
   int cv[3] = {0, 0, 0};
   bool ok = true;
 #pragma unroll
@@ -596,13 +614,13 @@ __global__ __launch_bounds__(256) void k_mg_restrict0(GridDev g1, const int32_t*
   for (int a = 0; a < BS; ++a) acc[a] = 0.0;
   if (ok) {
     const long long c = v2lin(cv, g1);
-    for (int32_t q = cell_ptr[c] + sub; q < cell_ptr[c + 1]; q += LPC) {
-      const int64_t i = cell_nodes[q];
+    for (int32_t p = cell_ptr[c] + sub; p < cell_ptr[c + 1]; p += LPC) {
+      const int64_t i = cell_nodes[p];
       double wi = 1.0;
 #pragma unroll
       for (int a = 0; a < D; ++a) {
-        const double w = wgt[i * D + a];
-        wi *= ((corner >> a) & 1) ? w : 1.0 - w;
+        const double wa = wgt[i * D + a];
+        wi *= ((corner >> a) & 1) ? wa : 1.0 - wa;
       }
 #pragma unroll
       for (int a = 0; a < BS; ++a) acc[a] += wi * (double)res[i * BS + a];
@@ -1215,7 +1233,10 @@ void mg_setup_t(glims_ctx* h) {
   };
   const bool g1_global = framed;
   MgLevel* L1 = new_level(g1, o1, ng1, g1_global);
-  hipLaunchKernelGGL(k_mg_rap0<D>, dim3(gridn((long long)g1.nn * mg.S)), dim3(256), 0, h->st, gdev(g1), mg.R, mg.S, n,
+  constexpr int BW0 = D == 3 ? 4 : 8;   // bricks of k_mg_rap0
+  const int nbx0 = (g1.n[0] + BW0 - 1) / BW0, nby0 = (g1.n[1] + BW0 - 1) / BW0, nbz0 = D == 3 ? (g1.n[2] + BW0 - 1) / BW0 : 1;
+  hipLaunchKernelGGL(k_mg_rap0<D>, dim3(gridn((long long)nbx0 * nby0 * nbz0 * 64 * mg.S)), dim3(256), 0, h->st, gdev(g1),
+                     nbx0, nby0, mg.R, mg.S, n,
                      n_all, mg.cell_ptr.p, mg.cell_nodes.p, mg.cell0.p, mg.wgt.p, p.slice_ptr.p, p.cols.p, h->vKel.p,
                      fxr, L1->A.p);
   GL_HIP(hipGetLastError());
@@ -1471,11 +1492,14 @@ void mg_apply_t(glims_ctx* h, const double* r, double* u, const int* done) {
   const GridDev g1 = gdev(L1.g);
   // (the first smoothing step of the grid level is NOT fused into this restriction as it is between the Cartesian levels:
   // one active lane per wave fetching Dinv made the kernel 33 us slower at 125 k grid nodes, the separate pass costs 5)
+  constexpr int BW = D == 3 ? 4 : 8;   // brick edge of k_mg_restrict0: 64 grid nodes = 16 blocks per brick
+  const int nbx = (g1.n0 + BW - 1) / BW, nby = (g1.n1 + BW - 1) / BW, nbz = D == 3 ? (g1.n2 + BW - 1) / BW : 1;
+  const unsigned gr0 = (unsigned)((long long)nbx * nby * nbz * 16);
   if (x32)
-    hipLaunchKernelGGL((k_mg_restrict0<D, float>), dim3(gridn(g1.nn, 4)), dim3(256), 0, h->st, g1, mg.cell_ptr.p,
+    hipLaunchKernelGGL((k_mg_restrict0<D, float>), dim3(gr0), dim3(256), 0, h->st, g1, nbx, nby, mg.cell_ptr.p,
                        mg.cell_nodes.p, mg.wgt.p, (const float*)mg.res.p, L1.r.p);
   else
-    hipLaunchKernelGGL((k_mg_restrict0<D, double>), dim3(gridn(g1.nn, 4)), dim3(256), 0, h->st, g1, mg.cell_ptr.p,
+    hipLaunchKernelGGL((k_mg_restrict0<D, double>), dim3(gr0), dim3(256), 0, h->st, g1, nbx, nby, mg.cell_ptr.p,
                        mg.cell_nodes.p, mg.wgt.p, (const double*)mg.res.p, L1.r.p);
   GL_HIP(hipGetLastError());
   if (L1.global) gl_allreduce_bulk(h, L1.r.p, (size_t)BS * L1.g.nn);
