@@ -169,6 +169,9 @@ struct MgLevel {                           // one Cartesian level
   int ng[3] = {1, 1, 1};                   // nodes per axis of the level's GLOBAL grid
   bool global = false;                     // replicated on every rank (box = whole grid), residual all-reduced per cycle
   dvec<float> A;                           // [S][bs*bs][nn] stencil-major planes
+  bool half = false;                       // smoothed in symmetrically scaled variables with the half-precision copy A16
+  dvec<uint16_t> A16;                      // [S][bs*bs][nn] _Float16 planes of S A S, S = diag(1 / sqrt(a_ii))   (half only)
+  dvec<double> sc;                         // [bs][nn] the scale factors s; dinv then holds (S A S)_ii^-1       (half only)
   dvec<double> dinv;                       // [bs*bs][nn] inverse diagonal blocks
   dvec<double> x, x2, r, d, res;           // [bs][nn] (component-major)
   double lam = 1.0;                        // estimate of lambda_max(Dinv A)

@@ -335,13 +335,46 @@ __global__ void k_mg_dinv(GridDev g, int S, const float* __restrict__ A, double*
 // ---------------------------------------------------------------------------------------------------
 // cycle kernels, Cartesian levels (vectors component-major [BS][nn])
 // ---------------------------------------------------------------------------------------------------
+// what every Cartesian pass does with the row sum acc = (A xin)_I (one thread per node holds it)
+template <int BS, int MODE>
+__device__ __forceinline__ void cart_epilogue(long long nn, long long I, const double* acc,
+                                              const double* __restrict__ dinv, const double* __restrict__ xin,
+                                              const double* __restrict__ r, double* __restrict__ d,
+                                              double* __restrict__ xout, double c1, double c2,
+                                              const double* __restrict__ osc) {
+  double t[BS];
+#pragma unroll
+  for (int a = 0; a < BS; ++a) t[a] = MODE == 2 ? acc[a] : r[(long long)a * nn + I] - acc[a];
+  if (MODE == 0) {
+#pragma unroll
+    for (int a = 0; a < BS; ++a) xout[(long long)a * nn + I] = osc ? t[a] / osc[(long long)a * nn + I] : t[a];
+    return;
+  }
+#pragma unroll
+  for (int a = 0; a < BS; ++a) {
+    double z = 0.0;
+#pragma unroll
+    for (int b = 0; b < BS; ++b) z += dinv[(long long)(a * BS + b) * nn + I] * t[b];
+    if (MODE == 2) {
+      xout[(long long)a * nn + I] = z;
+    } else {
+      const double dn = (c1 != 0.0 ? c1 * d[(long long)a * nn + I] : 0.0) + c2 * z;
+      const double xn = xin[(long long)a * nn + I] + dn;
+      d[(long long)a * nn + I] = dn;
+      xout[(long long)a * nn + I] = osc ? osc[(long long)a * nn + I] * xn : xn;
+    }
+  }
+}
+
 // MODE 0: xout = r - A xin     MODE 1: d = c1 d + c2 Dinv (r - A xin); xout = xin + d     MODE 2: xout = Dinv A xin
-template <int D, int MODE>
-__global__ __launch_bounds__(256) void k_mg_cart(GridDev g, int R, const float* __restrict__ A,
+// osc (levels smoothed in scaled variables, MgLevel::half): MODE 0 leaves them, xout = (r~ - A~ x~) / s; MODE 1 with osc
+// is the last step of the cycle on this level, xout = s (x~ + d~)
+template <int D, int MODE, class AT>
+__global__ __launch_bounds__(256) void k_mg_cart(GridDev g, int R, const AT* __restrict__ A,
                                                   const double* __restrict__ dinv, const double* __restrict__ xin,
                                                   const double* __restrict__ r, double* __restrict__ d,
                                                   double* __restrict__ xout, double c1, double c2,
-                                                  const int* __restrict__ done) {
+                                                  const int* __restrict__ done, const double* __restrict__ osc) {
   constexpr int BS = D, B2 = D * D;
   if (done && *done) return;   // launches enqueued past the Krylov solver's convergence: nobody reads the result
   const long long I = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -361,37 +394,17 @@ __global__ __launch_bounds__(256) void k_mg_cart(GridDev g, int R, const float* 
       const int off0 = (D == 3 ? (oz + R) * W * W : 0) + (oy + R) * W + R;
       for (int ox = xlo; ox <= xhi; ++ox) {
         const long long nb = nb0 + ox;
-        const float* a0 = A + (long long)(off0 + ox) * B2 * g.nn + I;
+        const AT* a0 = A + (long long)(off0 + ox) * B2 * g.nn + I;
         double xb[BS];
 #pragma unroll
         for (int b = 0; b < BS; ++b) xb[b] = xin[(long long)b * g.nn + nb];
 #pragma unroll
         for (int a = 0; a < BS; ++a)
 #pragma unroll
-          for (int b = 0; b < BS; ++b) acc[a] += (double)a0[(long long)(a * BS + b) * g.nn] * xb[b];
+          for (int b = 0; b < BS; ++b) acc[a] += (double)(float)a0[(long long)(a * BS + b) * g.nn] * xb[b];
       }
     }
-  double t[BS];
-#pragma unroll
-  for (int a = 0; a < BS; ++a) t[a] = MODE == 2 ? acc[a] : r[(long long)a * g.nn + I] - acc[a];
-  if (MODE == 0) {
-#pragma unroll
-    for (int a = 0; a < BS; ++a) xout[(long long)a * g.nn + I] = t[a];
-    return;
-  }
-#pragma unroll
-  for (int a = 0; a < BS; ++a) {
-    double z = 0.0;
-#pragma unroll
-    for (int b = 0; b < BS; ++b) z += dinv[(long long)(a * BS + b) * g.nn + I] * t[b];
-    if (MODE == 2) {
-      xout[(long long)a * g.nn + I] = z;
-    } else {
-      const double dn = (c1 != 0.0 ? c1 * d[(long long)a * g.nn + I] : 0.0) + c2 * z;
-      d[(long long)a * g.nn + I] = dn;
-      xout[(long long)a * g.nn + I] = xin[(long long)a * g.nn + I] + dn;
-    }
-  }
+  cart_epilogue<BS, MODE>(g.nn, I, acc, dinv, xin, r, d, xout, c1, c2, osc);
 }
 
 // The same pass for SMALL grids: one wave per node, the stencil offsets dealt to the lanes, then a fixed shuffle tree.
@@ -466,12 +479,12 @@ __global__ __launch_bounds__(256) void k_mg_cart_w(GridDev g, int R, int S, cons
 // G-th stencil offset, partial sums combined by a fixed xor-shuffle tree.  Lane = sub * (64 / G) + node-in-wave, so that
 // the lanes of one `sub` read 64 / G consecutive nodes of one operator plane.  A thread per node is a serial chain of
 // 27 (125) x B2 loads with too few threads to fill the device at these sizes; a wave per node wastes 37 of 64 lanes.
-template <int D, int MODE, int G>
-__global__ __launch_bounds__(256) void k_mg_cart_g(GridDev g, int R, int S, const float* __restrict__ A,
+template <int D, int MODE, int G, class AT>
+__global__ __launch_bounds__(256) void k_mg_cart_g(GridDev g, int R, int S, const AT* __restrict__ A,
                                                     const double* __restrict__ dinv, const double* __restrict__ xin,
                                                     const double* __restrict__ r, double* __restrict__ d,
                                                     double* __restrict__ xout, double c1, double c2,
-                                                    const int* __restrict__ done) {
+                                                    const int* __restrict__ done, const double* __restrict__ osc) {
   constexpr int BS = D, B2 = D * D, NPW = GL_WAVE / G;   // nodes per wave
   if (done && *done) return;
   const int lane = threadIdx.x & 63;
@@ -495,14 +508,14 @@ __global__ __launch_bounds__(256) void k_mg_cart_g(GridDev g, int R, int S, cons
       }
       if (!in) continue;
       const long long nb = v2lin(nv, g);
-      const float* a0 = A + (long long)off * B2 * g.nn + I;
+      const AT* a0 = A + (long long)off * B2 * g.nn + I;
       double xb[BS];
 #pragma unroll
       for (int b = 0; b < BS; ++b) xb[b] = xin[(long long)b * g.nn + nb];
 #pragma unroll
       for (int a = 0; a < BS; ++a)
 #pragma unroll
-        for (int b = 0; b < BS; ++b) acc[a] += (double)a0[(long long)(a * BS + b) * g.nn] * xb[b];
+        for (int b = 0; b < BS; ++b) acc[a] += (double)(float)a0[(long long)(a * BS + b) * g.nn] * xb[b];
     }
 #pragma unroll
   for (int a = 0; a < BS; ++a) {
@@ -510,39 +523,27 @@ __global__ __launch_bounds__(256) void k_mg_cart_g(GridDev g, int R, int S, cons
     for (int o = GL_WAVE / 2; o >= NPW; o >>= 1) acc[a] += __shfl_xor(acc[a], o, 64);
   }
   if (!live || sub != 0) return;
-  double t[BS];
-#pragma unroll
-  for (int a = 0; a < BS; ++a) t[a] = MODE == 2 ? acc[a] : r[(long long)a * g.nn + I] - acc[a];
-  if (MODE == 0) {
-#pragma unroll
-    for (int a = 0; a < BS; ++a) xout[(long long)a * g.nn + I] = t[a];
-    return;
-  }
-#pragma unroll
-  for (int a = 0; a < BS; ++a) {
-    double z = 0.0;
-#pragma unroll
-    for (int b = 0; b < BS; ++b) z += dinv[(long long)(a * BS + b) * g.nn + I] * t[b];
-    if (MODE == 2) {
-      xout[(long long)a * g.nn + I] = z;
-    } else {
-      const double dn = (c1 != 0.0 ? c1 * d[(long long)a * g.nn + I] : 0.0) + c2 * z;
-      d[(long long)a * g.nn + I] = dn;
-      xout[(long long)a * g.nn + I] = xin[(long long)a * g.nn + I] + dn;
-    }
-  }
+  cart_epilogue<BS, MODE>(g.nn, I, acc, dinv, xin, r, d, xout, c1, c2, osc);
 }
 
 // first smoothing step from a zero iterate: d = c2 Dinv r, x = d   (no operator pass)
+// sc (MgLevel::half): the level enters its scaled variables here, r <- r~ = s r in place
 template <int D>
-__global__ void k_mg_first_cart(GridDev g, const double* __restrict__ dinv, const double* __restrict__ r,
-                                double* __restrict__ d, double* __restrict__ x, double c2) {
+__global__ void k_mg_first_cart(GridDev g, const double* __restrict__ dinv, double* __restrict__ r,
+                                double* __restrict__ d, double* __restrict__ x, double c2,
+                                const double* __restrict__ sc) {
   constexpr int BS = D;
   const long long I = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (I >= g.nn) return;
   double rv[BS];
 #pragma unroll
-  for (int a = 0; a < BS; ++a) rv[a] = r[(long long)a * g.nn + I];
+  for (int a = 0; a < BS; ++a) {
+    rv[a] = r[(long long)a * g.nn + I];
+    if (sc) {
+      rv[a] *= sc[(long long)a * g.nn + I];
+      r[(long long)a * g.nn + I] = rv[a];
+    }
+  }
 #pragma unroll
   for (int a = 0; a < BS; ++a) {
     double z = 0.0;
@@ -733,9 +734,11 @@ __global__ __launch_bounds__(256) void k_mg_restrict(GridDev gf, GridDev gc, Fac
   }
 }
 
+// isc (fine level in scaled variables): x~ += (P e) / s
 template <int D>
 __global__ void k_mg_prolong(GridDev gf, GridDev gc, Fac fc, const double* __restrict__ ec,
-                             const double* __restrict__ xin, double* __restrict__ xout) {
+                             const double* __restrict__ xin, double* __restrict__ xout,
+                             const double* __restrict__ isc) {
   constexpr int BS = D;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= gf.nn) return;
@@ -770,7 +773,8 @@ __global__ void k_mg_prolong(GridDev gf, GridDev gc, Fac fc, const double* __res
     for (int a = 0; a < BS; ++a) acc[a] += w * ec[(long long)a * gc.nn + J];
   }
 #pragma unroll
-  for (int a = 0; a < BS; ++a) xout[(long long)a * gf.nn + i] = xin[(long long)a * gf.nn + i] + acc[a];
+  for (int a = 0; a < BS; ++a)
+    xout[(long long)a * gf.nn + i] = xin[(long long)a * gf.nn + i] + (isc ? acc[a] / isc[(long long)a * gf.nn + i] : acc[a]);
 }
 
 // coarsest level: x = Ainv r, one wave per row of the dense inverse
@@ -815,6 +819,56 @@ __global__ void k_mg_fill(int64_t n, double* __restrict__ x, const uint8_t* __re
 __global__ void k_mg_scale(int64_t n, double* __restrict__ x, double s) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] *= s;
+}
+
+// A level enters symmetrically scaled variables (MgLevel::half): s = 1 / sqrt(a_ii) per dof (1 where the level's
+// operator has no stiffness), Dinv <- S^-1 Dinv S^-1 = inverse diagonal blocks of S A S ...
+template <int D>
+__global__ void k_mg_level_scale(GridDev g, int S, const float* __restrict__ A, double* __restrict__ sc,
+                                 double* __restrict__ dinv) {
+  constexpr int BS = D, B2 = D * D;
+  const long long I = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (I >= g.nn) return;
+  const int ctr = S / 2;
+  double s[BS];
+#pragma unroll
+  for (int a = 0; a < BS; ++a) {
+    const double aii = (double)A[((long long)ctr * B2 + a * BS + a) * g.nn + I];
+    s[a] = aii > 0.0 ? 1.0 / sqrt(aii) : 1.0;
+    sc[(long long)a * g.nn + I] = s[a];
+  }
+#pragma unroll
+  for (int a = 0; a < BS; ++a)
+#pragma unroll
+    for (int b = 0; b < BS; ++b) dinv[(long long)(a * BS + b) * g.nn + I] /= s[a] * s[b];
+}
+// ... and its operator becomes the half-precision copy of S A S (entries <= 1 in magnitude: no overflow, and whatever
+// falls below the half-precision range is 1e-5 of a diagonal entry).  One thread per (node, stencil offset).
+template <int D>
+__global__ void k_mg_half_copy(GridDev g, int R, int S, const float* __restrict__ A, const double* __restrict__ sc,
+                               _Float16* __restrict__ A16) {
+  constexpr int BS = D, B2 = D * D;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= g.nn * S) return;
+  const int off = (int)(t / g.nn);
+  const long long I = t - (long long)off * g.nn;
+  int Iv[3], o[3], Jv[3] = {0, 0, 0};
+  lin2v(I, g, Iv);
+  off2v<D>(off, R, o);
+  bool in = true;
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    Jv[a] = Iv[a] + o[a];
+    in = in && Jv[a] >= 0 && Jv[a] < gn(g, a);
+  }
+  const long long J = in ? v2lin(Jv, g) : I;
+#pragma unroll
+  for (int a = 0; a < BS; ++a)
+#pragma unroll
+    for (int b = 0; b < BS; ++b) {
+      const long long e = ((long long)off * B2 + a * BS + b) * g.nn + I;
+      A16[e] = in ? (_Float16)(float)(sc[(long long)a * g.nn + I] * (double)A[e] * sc[(long long)b * g.nn + J]) : (_Float16)0.0f;
+    }
 }
 
 inline unsigned gridn(long long n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
@@ -934,26 +988,21 @@ void gl_mesh_metrics(glims_ctx* h, const HostPattern& hp, const double* xyz_old)
 // ===================================================================================================
 namespace {
 
+// One operator pass on a Cartesian level.  Kernel by size: a wave per node up to 6 k nodes, 4 lanes per node for medium
+// grids (<= 60 k nodes with 27-point stencils -- 26^3: -2.4 % per solve against a thread per node, 8 / 16 lanes the same,
+// on 51^3 a thread per node is faster -- and every larger grid with 125-point stencils: 1 M-point Delaunay mesh 133.5 ->
+// 126.7 ms per solve), a thread per node otherwise.  `osc`: see k_mg_cart (levels with MgLevel::half only).
 template <int D>
 void mg_apply_cart(glims_ctx* h, MgLevel& L, int R, int mode, const double* xin, const double* r, double* d,
-                   double* xout, double c1, double c2, const int* done = nullptr) {
+                   double* xout, double c1, double c2, const int* done = nullptr, const double* osc = nullptr) {
   const GridDev g = gdev(L.g);
-  const unsigned grid = gridn(g.nn);
-  if (g.nn > 6000 && g.nn <= 60000) {   // medium grid: 4 lanes per node (26^3 nodes: -2.4 % per solve against a thread per
-    const int S = h->mg.S;              // node; 8 / 16 lanes the same; on 51^3 a thread per node is faster, below 6 k a wave)
-    const unsigned gw = gridn(g.nn, 4 * (GL_WAVE / 4));
-    if (mode == 0)
-      hipLaunchKernelGGL((k_mg_cart_g<D, 0, 4>), dim3(gw), dim3(256), 0, h->st, g, R, S, L.A.p, L.dinv.p, xin, r, d, xout, c1, c2, done);
-    else if (mode == 1)
-      hipLaunchKernelGGL((k_mg_cart_g<D, 1, 4>), dim3(gw), dim3(256), 0, h->st, g, R, S, L.A.p, L.dinv.p, xin, r, d, xout, c1, c2, done);
-    else
-      hipLaunchKernelGGL((k_mg_cart_g<D, 2, 4>), dim3(gw), dim3(256), 0, h->st, g, R, S, L.A.p, L.dinv.p, xin, r, d, xout, c1, c2, done);
-    GL_HIP(hipGetLastError());
-    return;
-  }
-  if (g.nn <= 6000) {   // small grid: one wave per node (see k_mg_cart_w; slower than a thread per node from ~17 k nodes)
+  const int S = h->mg.S;
+  GL_REQUIRE(!(L.half && mode == 2), "internal: the single-precision planes of this level are gone");   // (power iteration: before)
+  const bool half = L.half;
+  const _Float16* A16 = (const _Float16*)L.A16.p;
+  if (g.nn <= 6000) {
+    GL_REQUIRE(!half, "internal: half-precision operator on a small grid");
     const unsigned gw = gridn(g.nn, 4);
-    const int S = h->mg.S;
     if (mode == 0)
       hipLaunchKernelGGL((k_mg_cart_w<D, 0>), dim3(gw), dim3(256), 0, h->st, g, R, S, L.A.p, L.dinv.p, xin, r, d, xout, c1, c2, done);
     else if (mode == 1)
@@ -963,12 +1012,25 @@ void mg_apply_cart(glims_ctx* h, MgLevel& L, int R, int mode, const double* xin,
     GL_HIP(hipGetLastError());
     return;
   }
-  if (mode == 0)
-    hipLaunchKernelGGL((k_mg_cart<D, 0>), dim3(grid), dim3(256), 0, h->st, g, R, L.A.p, L.dinv.p, xin, r, d, xout, c1, c2, done);
-  else if (mode == 1)
-    hipLaunchKernelGGL((k_mg_cart<D, 1>), dim3(grid), dim3(256), 0, h->st, g, R, L.A.p, L.dinv.p, xin, r, d, xout, c1, c2, done);
-  else
-    hipLaunchKernelGGL((k_mg_cart<D, 2>), dim3(grid), dim3(256), 0, h->st, g, R, L.A.p, L.dinv.p, xin, r, d, xout, c1, c2, done);
+  const bool lanes = g.nn <= 60000 || R >= 2;
+  const unsigned grid = lanes ? gridn(g.nn, 4 * (GL_WAVE / 4)) : gridn(g.nn);
+#define GL_CART(MODE)                                                                                                 \
+  do {                                                                                                               \
+    if (lanes && half)                                                                                               \
+      hipLaunchKernelGGL((k_mg_cart_g<D, MODE, 4, _Float16>), dim3(grid), dim3(256), 0, h->st, g, R, S, A16, L.dinv.p, \
+                         xin, r, d, xout, c1, c2, done, osc);                                                        \
+    else if (lanes)                                                                                                  \
+      hipLaunchKernelGGL((k_mg_cart_g<D, MODE, 4, float>), dim3(grid), dim3(256), 0, h->st, g, R, S, L.A.p, L.dinv.p, \
+                         xin, r, d, xout, c1, c2, done, osc);                                                        \
+    else if (half)                                                                                                   \
+      hipLaunchKernelGGL((k_mg_cart<D, MODE, _Float16>), dim3(grid), dim3(256), 0, h->st, g, R, A16, L.dinv.p, xin, r, \
+                         d, xout, c1, c2, done, osc);                                                                \
+    else                                                                                                             \
+      hipLaunchKernelGGL((k_mg_cart<D, MODE, float>), dim3(grid), dim3(256), 0, h->st, g, R, L.A.p, L.dinv.p, xin, r,  \
+                         d, xout, c1, c2, done, osc);                                                                \
+  } while (0)
+  if (mode == 0) GL_CART(0); else if (mode == 1) GL_CART(1); else GL_CART(2);
+#undef GL_CART
   GL_HIP(hipGetLastError());
 }
 
@@ -1332,7 +1394,23 @@ void mg_setup_t(glims_ctx* h) {
     L.lam = (std::isfinite(lam) && lam > 0.0) ? lam : 2.0;
   }
 
-  lap("half copy, eigenvalue estimates");
+  // The first grid carries 1 / 8 of the mesh's nodes but dense 27- (125-)point stencils of 3 x 3 blocks: 1 / 2 (general
+  // meshes: more than 1 x) of level 0's operator bytes per pass.  It is smoothed like level 0: scaled variables, operator in
+  // half precision (C5: k_mg_cart 29 -> see DESIGN.md section 7; the single-precision planes are released).
+  if (mg.lv.size() >= 2 && mg.lv[0]->g.nn > 6000 && mg.half_smoother) {
+    MgLevel& L = *mg.lv[0];
+    const GridDev g = gdev(L.g);
+    L.sc.alloc((size_t)BS * L.g.nn);
+    L.A16.alloc((size_t)mg.S * B2 * L.g.nn);
+    hipLaunchKernelGGL(k_mg_level_scale<D>, dim3(gridn(g.nn)), dim3(256), 0, h->st, g, mg.S, L.A.p, L.sc.p, L.dinv.p);
+    hipLaunchKernelGGL(k_mg_half_copy<D>, dim3(gridn((long long)g.nn * mg.S)), dim3(256), 0, h->st, g, mg.R, mg.S, L.A.p,
+                       L.sc.p, (_Float16*)L.A16.p);
+    GL_HIP(hipGetLastError());
+    GL_HIP(hipStreamSynchronize(h->st));
+    L.A.release();
+    L.half = true;
+  }
+  lap("half copies, eigenvalue estimates");
   // ---- coarsest level: dense inverse ------------------------------------------------------------------------------
   {
     MgLevel& L = *mg.lv.back();
@@ -1428,15 +1506,17 @@ void mg_cycle_cart(glims_ctx* h, size_t l, const int* done, bool first_done) {
   Cheb ch(L.lam, mg.cheb_ratio);
   double c1, c2;
   ch.next(0, &c1, &c2);
+  const double* sc = L.half ? L.sc.p : nullptr;   // this level works in scaled variables between first_cart and its last pass
+  GL_REQUIRE(!(first_done && L.half), "internal: fused first step on a level with scaled variables");
   if (!first_done)
-    hipLaunchKernelGGL(k_mg_first_cart<D>, dim3(gridn(g.nn)), dim3(256), 0, h->st, g, L.dinv.p, L.r.p, L.d.p, L.x.p, c2);
+    hipLaunchKernelGGL(k_mg_first_cart<D>, dim3(gridn(g.nn)), dim3(256), 0, h->st, g, L.dinv.p, L.r.p, L.d.p, L.x.p, c2, sc);
   double *xa = L.x.p, *xb = L.x2.p;
   for (int m = 1; m < deg; ++m) {
     ch.next(m, &c1, &c2);
     mg_apply_cart<D>(h, L, mg.R, 1, xa, L.r.p, L.d.p, xb, c1, c2, done);
     std::swap(xa, xb);
   }
-  mg_apply_cart<D>(h, L, mg.R, 0, xa, L.r.p, nullptr, L.res.p, 0.0, 0.0, done);
+  mg_apply_cart<D>(h, L, mg.R, 0, xa, L.r.p, nullptr, L.res.p, 0.0, 0.0, done, sc);
   MgLevel& C = *mg.lv[l + 1];
   const Fac fc{{L.f[0], L.f[1], L.f[2]}, {L.o[0], L.o[1], L.o[2]}, {C.o[0], C.o[1], C.o[2]}};
   const bool reduce_c = C.global && !L.global && h->world > 1;
@@ -1447,13 +1527,13 @@ void mg_cycle_cart(glims_ctx* h, size_t l, const int* done, bool first_done) {
   // first replicated level of a partitioned run: every rank has restricted the residual of its own rows -> sum
   if (reduce_c) gl_allreduce_bulk(h, C.r.p, (size_t)BS * C.g.nn);
   mg_cycle_cart<D>(h, l + 1, done, c2c != 0.0);
-  hipLaunchKernelGGL(k_mg_prolong<D>, dim3(gridn(g.nn)), dim3(256), 0, h->st, g, gdev(C.g), fc, C.x.p, xa, xb);
+  hipLaunchKernelGGL(k_mg_prolong<D>, dim3(gridn(g.nn)), dim3(256), 0, h->st, g, gdev(C.g), fc, C.x.p, xa, xb, sc);
   GL_HIP(hipGetLastError());
   std::swap(xa, xb);
   Cheb cp(L.lam, mg.cheb_ratio);
   for (int m = 0; m < deg; ++m) {
     cp.next(m, &c1, &c2);
-    mg_apply_cart<D>(h, L, mg.R, 1, xa, L.r.p, L.d.p, xb, c1, c2, done);
+    mg_apply_cart<D>(h, L, mg.R, 1, xa, L.r.p, L.d.p, xb, c1, c2, done, m == deg - 1 ? sc : nullptr);
     std::swap(xa, xb);
   }
   if (xa != L.x.p) std::swap(L.x.p, L.x2.p);   // the result is always handed up in L.x

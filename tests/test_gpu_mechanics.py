@@ -128,6 +128,19 @@ def test_multigrid_iteration_count_does_not_grow_with_the_mesh(backend):
     assert max(its) <= 60 and its[-1] <= its[0] + 8
 
 
+def test_multigrid_index_streams_give_the_same_bits(backend):
+    """The level-0 smoother reads its columns as 16-bit window codes (default) or as int32 (GLIMS_FLAG_INT32_COLUMNS):
+    the same columns in the same order, hence bitwise the same displacement and the same iteration count."""
+    w = _c5_reduced(24)
+    out = []
+    for flags in (backend.FLAG_WARM_START, backend.FLAG_WARM_START | backend.FLAG_INT32_COLUMNS):
+        h, dofs = _c5_handle(backend, w, mech_history=0, flags=flags)
+        assert h.solve_mechanics() == 0
+        out.append((h.get_state()[1], h.stats()['mech_cg_its']))
+        h.close()
+    assert out[0][1] == out[1][1] and np.array_equal(out[0][0], out[1][0])
+
+
 def test_multigrid_near_the_incompressible_limit(backend):
     """nu = 0.49 in every tissue -- the upper end of the range the reference documents (simulation_tumor_growth.py:60,
     'poisson ratio nu: 0.4 ... 0.49'): lambda / mu = 49.  The point-block Chebyshev smoother loses some of its grip
