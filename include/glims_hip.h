@@ -100,7 +100,8 @@ typedef struct glims_options {
                                            residual stay fp64, so the iteration still converges to the fp64 tolerance of
                                            the same fixed point); takes effect at glims_setup */
 #define GLIMS_FLAG_MG_FP32_SMOOTHER 8     /* OFF by default.  The level-0 smoother of the elasticity multigrid streams a
-                                           single-precision copy of K_el instead of the (scaled) half-precision one */
+                                           single-precision copy of K_el instead of the (scaled) half-precision one, and
+                                           the first Cartesian grid keeps its single-precision stencils */
 #define GLIMS_FLAG_MG_FP64_VECTORS 32    /* OFF by default.  The level-0 cycle vectors of the elasticity multigrid (iterate,
                                            direction, scaled residual) are kept in double instead of single precision; the
                                            preconditioned residual handed to the Krylov solver is double either way */
