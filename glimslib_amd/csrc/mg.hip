@@ -6,22 +6,28 @@
 // iteration makes the count independent of the mesh width (tools/proto_gmg.py: 47 / 51 / 53 at n = 16 / 24 / 32).
 //
 // Design (MI355X first): *geometric multigrid on auxiliary Cartesian grids*.
-//   level 0   the mesh (any P1 simplex mesh): block SELL-64 operator, single-precision copy, smoother fused into the SpMV
+//   level 0   the mesh (any P1 simplex mesh): block SELL-64 operator; the smoother works in symmetrically scaled variables
+//             (K~ = S K S, S = diag(1 / sqrt(k_ii))) on a HALF-precision copy of K~, with single-precision cycle vectors whose
+//             iterate lives in 16-byte node records (one aligned gather per neighbour), fused into the SpMV (k_mg_fine)
 //   level 1   a Cartesian grid of width H ~ 2h laid over the mesh; prolongation = d-linear interpolation from the
 //             grid nodes onto the mesh nodes (8 parents per node, weights from coordinates alone -- no graph
-//             algorithms, no aggregates, no QR)
+//             algorithms, no aggregates, no QR); smoothed like level 0 (scaled variables, half-precision operator)
 //   level 2.. 2:1 coarsenings with d-linear interpolation
 //   coarse operators = Galerkin products P^T A P, stored as *dense stencils* [(2R+1)^d][d*d][nodes] in single
 //   precision: no column indices, every load unit-stride over the grid nodes, the neighbour gather of x contiguous.
 //   R = 1 (27-point) when the mesh nodes sit on a lattice that the grid can align with (the BASELINE box meshes),
-//   R = 2 (125-point) for general meshes.  Rigid-body modes are d-linear, i.e. reproduced exactly on every level, which
-//   is what smoothed aggregation buys with its near-nullspace vectors.
+//   R = 2 (125-point) for general meshes; mesh edges that reach further stay on level 0 (dropped from the products).
+//   Rigid-body modes are d-linear, i.e. reproduced exactly on every level, which is what smoothed aggregation buys with
+//   its near-nullspace vectors.
 //   All set-up products are *gathers by the output entry* (one thread per (grid node, stencil offset)): no atomics,
-//   bitwise reproducible hierarchies.
+//   bitwise reproducible hierarchies.  Grid nodes are walked in XCD-local bricks where neighbours share operands.
 //   Smoother: Chebyshev of degree k (k = 1: damped block-Jacobi) on Dinv A, lambda_max by power iteration at set-up.
 //   Coarsest grid (<= mg_coarse_nodes nodes): dense inverse computed once (device Gauss-Jordan), applied as one GEMV.
-//   Partitioned runs: the hierarchy covers the rank's owned rows (ghost couplings dropped inside the preconditioner =
-//   non-overlapping additive Schwarz with one V-cycle per subdomain); the Krylov operator itself stays exact.
+//   Partitioned runs: with glims_set_mg_frame every rank lays the SAME grids over the partitioned mesh -- level-0 passes
+//   exact through halo exchanges, the first grid's operator and, per cycle, its restricted residual all-reduced, the
+//   Cartesian levels computed redundantly: the iteration count does not depend on the rank count.  Without a frame the
+//   hierarchy covers the rank's owned rows only (ghost couplings dropped inside the preconditioner = non-overlapping
+//   additive Schwarz with one V-cycle per subdomain); the Krylov operator itself is exact either way.
 #include "glims_internal.h"
 
 #include <omp.h>
