@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Config C5 (coupled model on the brain-extent box): elasticity solve after every RD step, per preconditioner.
-    python tools/run_c5.py [n] [steps]      env: PRECOND=mg|bj  SMOOTH=k  MIXED=0|1|2  HIST=k  MECH_RTOL  NU=0.49"""
+    python tools/run_c5.py [n] [steps]      env: PRECOND=mg|bj  SMOOTH=k  RATIO  MIXED=0|1|2  HIST=k  HFAC  COARSE  FP32SM=1  X64=1  MECH_RTOL  NU=0.49"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
