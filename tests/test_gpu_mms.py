@@ -13,36 +13,11 @@ A wrong factor, sign or missing term in any form shows up as an error that does 
 """
 import numpy as np
 import pytest
-import sympy as sp
 
 from glimslib_amd.mesh import BoxMesh, RectangleMesh
+from mms_common import D_, E_, GAMMA, NU, RHO, manufactured as _manufactured
 
 pytestmark = pytest.mark.gpu
-
-D_, RHO, GAMMA, E_, NU = 0.7, 1.3, 0.2, 2.5, 0.3
-MU = E_ / (2 * (1 + NU))
-LAM = E_ * NU / ((1 + NU) * (1 - 2 * NU))
-
-
-def _symbols(dim):
-    return sp.symbols('x y z')[:dim]
-
-
-def _manufactured(dim):
-    X = _symbols(dim)
-    pi = sp.pi
-    c = sp.Rational(3, 10) + sp.Rational(1, 5) * sp.prod([sp.sin(pi * x) for x in X]) + sp.Rational(1, 10) * X[0] * X[-1]
-    u = [sp.sin(pi * X[0]) * sp.cos(pi * X[1] / 2) * (1 + (X[-1] if dim == 3 else 0)) / 10,
-         X[0] * (1 - X[1]) * sp.exp(X[0] / 2) / 8]
-    if dim == 3:
-        u.append(sp.sin(pi * X[2] / 2) * (X[0] + X[1] ** 2) / 12)
-    lap = lambda f: sum(sp.diff(f, x, 2) for x in X)
-    s = -D_ * lap(c) - RHO * c * (1 - c)
-    div_u = sum(sp.diff(u[a], X[a]) for a in range(dim))
-    kappa = GAMMA * (2 * MU + dim * LAM)
-    f = [-(MU * lap(u[a]) + (LAM + MU) * sp.diff(div_u, X[a])) + kappa * sp.diff(c, X[a]) for a in range(dim)]
-    fn = lambda e: sp.lambdify(X, e, 'numpy')
-    return fn(c), fn(s), [fn(e) for e in u], [fn(e) for e in f]
 
 
 def _solve(backend, dim, n):
