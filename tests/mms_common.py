@@ -29,3 +29,13 @@ def manufactured(dim):
     f = [-(MU * lap(u[a]) + (LAM + MU) * sp.diff(div_u, X[a])) + kappa * sp.diff(c, X[a]) for a in range(dim)]
     fn = lambda e: sp.lambdify(X, e, 'numpy')
     return fn(c), fn(s), [fn(e) for e in u], [fn(e) for e in f]
+
+
+def manufactured_transient():
+    """2-D, time dependent: c(x, y, t) and the source s = c_t - D lap c - rho c (1 - c), as numpy callables of (x, y, t).
+    For the temporal order of the backward-Euler step (1), with time-dependent source AND Dirichlet data."""
+    x, y, t = sp.symbols('x y t')
+    c = sp.Rational(3, 10) + sp.Rational(1, 5) * sp.sin(sp.pi * x) * sp.sin(sp.pi * y) * sp.exp(-t) \
+        + sp.Rational(1, 10) * x * y * sp.cos(2 * t)
+    s = sp.diff(c, t) - D_ * (sp.diff(c, x, 2) + sp.diff(c, y, 2)) - RHO * c * (1 - c)
+    return sp.lambdify((x, y, t), c, 'numpy'), sp.lambdify((x, y, t), s, 'numpy')

@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 
 from glimslib_amd.mesh import BoxMesh, RectangleMesh
-from mms_common import D_, E_, GAMMA, NU, RHO, manufactured as _manufactured
+from mms_common import D_, E_, GAMMA, NU, RHO, manufactured as _manufactured, manufactured_transient
 
 pytestmark = pytest.mark.gpu
 
@@ -67,3 +67,38 @@ def test_manufactured_solutions_converge_with_order_two(backend, dim, levels):
           (dim, ["%.2e" % e for e in ec], ["%.2f" % o for o in oc], ["%.2e" % e for e in eu], ["%.2f" % o for o in ou]))
     assert oc.min() > 1.9 and ou.min() > 1.9
     assert ec[-1] < 2e-3 and eu[-1] < 2e-3
+
+
+def test_backward_euler_is_first_order_in_time(backend):
+    """Transient manufactured solution on a fine 2-D mesh, source and Dirichlet data changing every step
+    (glims_set_rd_load / glims_set_dirichlet_c between the steps): the error at T = 1 halves with the time step.  This is
+    the M (c - c_prev) term and its dt scaling, which the steady cases do not see, and the time-dependent boundary data
+    of simulation_base.py's run loop against an analytical answer."""
+    n, T = 128, 1.0
+    mesh = RectangleMesh((0, 0), (1, 1), n, n)
+    P = mesh.points
+    X, Y = P[:, 0].copy(), P[:, 1].copy()
+    c_f, s_f = manufactured_transient()
+    fac = mesh.facets()
+    bn = np.unique(fac['vertices'][fac['exterior']])
+    errs = []
+    for steps in (5, 10, 20):
+        dt = T / steps
+        h = backend.Handle(P, mesh.cells, np.ones(mesh.num_cells(), np.int32))
+        h.set_materials([0, D_], [0, RHO], [0, 0.0], [1, 1.0], [0.3, 0.3])
+        h.set_options(dt=dt)
+        h.setup(False)
+        h.set_state(np.asarray(c_f(X, Y, 0.0), dtype=np.float64))
+        for k in range(1, steps + 1):
+            t1 = k * dt
+            h.set_rd_load(dt * h.apply(2, np.asarray(s_f(X, Y, t1), dtype=np.float64))[0])
+            h.set_dirichlet_c(bn, np.asarray(c_f(X[bn], Y[bn], t1), dtype=np.float64))
+            assert h.step(1) == 0
+        c = h.get_state(want_u=False)[0]
+        e = c - c_f(X, Y, T)
+        errs.append(np.sqrt(max(e @ h.apply(2, e)[0], 0.0)))
+        h.close()
+    errs = np.array(errs)
+    orders = np.log2(errs[:-1] / errs[1:])
+    print("transient: L2 errors %s, temporal orders %s" % (["%.2e" % e for e in errs], ["%.2f" % o for o in orders]))
+    assert orders.min() > 0.9 and orders.max() < 1.15

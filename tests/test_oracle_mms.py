@@ -8,7 +8,7 @@ missing term in its forms leaves an error that does not fall with order 2 under 
 import numpy as np
 import pytest
 
-from mms_common import D_, E_, GAMMA, NU, RHO, manufactured
+from mms_common import D_, E_, GAMMA, NU, RHO, manufactured, manufactured_transient
 from oracle.glims_oracle import OracleTumorGrowth, boundary_facets, box_mesh, rectangle_mesh
 
 
@@ -51,3 +51,29 @@ def test_oracle_converges_to_the_manufactured_solution_with_order_two(dim, level
     # form would give is an order near 0
     assert oc.min() > (1.9 if dim == 2 else 1.85) and ou.min() > (1.9 if dim == 2 else 1.85)
     assert oc[-1] > 1.9 and ou[-1] > 1.9
+
+
+def test_oracle_backward_euler_is_first_order_in_time():
+    """Transient manufactured solution with time-dependent source and Dirichlet data on a fine 2-D mesh: the error at
+    T = 1 halves with the time step (the M (c - c_prev) term and its dt scaling, which the steady cases do not see)."""
+    n, T = 128, 1.0
+    pts, cells = rectangle_mesh((0, 0), (1, 1), n, n)
+    c_f, s_f = manufactured_transient()
+    X, Y = pts[:, 0], pts[:, 1]
+    bn = np.unique(boundary_facets(cells)[0])
+    errs = []
+    for steps in (5, 10, 20):
+        dt = T / steps
+        o = OracleTumorGrowth(pts, cells, D_, RHO, 0.0, 1.0, 0.3, dt)
+        c = np.asarray(c_f(X, Y, 0.0), dtype=np.float64)
+        for k in range(1, steps + 1):
+            t1 = k * dt
+            o.rd_load = dt * (o.M @ s_f(X, Y, t1))
+            o.dirichlet_c = (bn, c_f(X[bn], Y[bn], t1))
+            c, _its = o.rd_step(c, rtol=1e-10, atol=1e-12)
+        e = c - c_f(X, Y, T)
+        errs.append(np.sqrt(e @ (o.M @ e)))
+    errs = np.array(errs)
+    orders = np.log2(errs[:-1] / errs[1:])
+    print("oracle, transient: L2 errors %s, temporal orders %s" % (["%.2e" % e for e in errs], ["%.2f" % o for o in orders]))
+    assert orders.min() > 0.9 and orders.max() < 1.15
