@@ -371,7 +371,7 @@ struct glims_ctx {
   // history of solved elasticity problems (right-hand side, free-dof solution): the operator is linear and time
   // independent, so the least-squares fit of a new right-hand side by the stored ones gives the initial guess
   static constexpr int MHIST = 16;  // upper bound of glims_options.mech_history
-  dvec<double> mh_rhs[MHIST], mh_x[MHIST];
+  dvec<double> mh_rhs[MHIST], mh_x[MHIST], mh_w[MHIST];   // solve history: right-hand sides, solutions, K_el x (= rhs - final residual)
   int mh_count = 0, mh_next = 0;           // depth: glims_options.mech_history
   double mh_G[MHIST][MHIST] = {{0.0}};     // Gram matrix (rhs_k, rhs_l) of the stored right-hand sides (host copy)
   bool have_c_old = false;                                    // c_old holds the state at the start of the previous step

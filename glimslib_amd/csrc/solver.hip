@@ -1213,13 +1213,16 @@ int gl_solve_mechanics(glims_ctx* h, const double* c_dev) {
       lc.a[k] = k < m ? a[k] : 0.0;
     }
     hipLaunchKernelGGL(k_lincomb, dim3(grid_exact(nd)), dim3(256), 0, h->st, nd, m, lc, h->U.p);
+    // K_el of that combination without an operator pass: K x_k = rhs_k - (final residual of solve k) was stored with x_k
+    for (int k = 0; k < 16; ++k) lc.x[k] = h->mh_w[k < m ? k : 0].p;
+    hipLaunchKernelGGL(k_lincomb, dim3(grid_exact(nd)), dim3(256), 0, h->st, nd, m, lc, h->m_w.p);
     GL_HIP(hipGetLastError());
   }
   // x = guess on the free dofs (previous displacement if there is no history), 0 on constrained ones
   if (fx) hipLaunchKernelGGL(k_mask_assign, dim3(grid_exact(nd)), dim3(256), 0, h->st, nd, h->U.p, fx,
                              (const double*)nullptr);
   gl_halo_exchange(h, h->U.p, bs);
-  gl_launch_spmv_block(h, h->st, p.n_slices, nullptr, h->U.p, h->m_w.p, fx, nullptr, nullptr, 0, nullptr);
+  if (m_hist == 0) gl_launch_spmv_block(h, h->st, p.n_slices, nullptr, h->U.p, h->m_w.p, fx, nullptr, nullptr, 0, nullptr);
   hipLaunchKernelGGL(k_sub, dim3(grid_exact(nd)), dim3(256), 0, h->st, nd, h->m_r.p, h->m_rhs.p, h->m_w.p, fx);
   GL_HIP(hipGetLastError());
   CgVecs v{h->U.p, h->m_r.p, h->m_u.p, h->m_w.p, h->m_p.p, h->m_s.p, h->m_dinv.p, nullptr, fx, bs};
@@ -1288,6 +1291,10 @@ int gl_solve_mechanics(glims_ctx* h, const double* c_dev) {
     h->mh_x[slot].alloc((size_t)h->n_nodes * bs);
     GL_HIP(hipMemcpyAsync(h->mh_rhs[slot].p, h->m_rhs.p, (size_t)nd * sizeof(double), hipMemcpyDeviceToDevice, h->st));
     GL_HIP(hipMemcpyAsync(h->mh_x[slot].p, h->U.p, (size_t)nd * sizeof(double), hipMemcpyDeviceToDevice, h->st));
+    // m_r = rhs - K U on the free dofs (true residual of the verification pass, or the recurrence's): K U = rhs - m_r
+    h->mh_w[slot].alloc((size_t)h->n_nodes * bs);
+    hipLaunchKernelGGL(k_sub, dim3(grid_exact(nd)), dim3(256), 0, h->st, nd, h->mh_w[slot].p, h->m_rhs.p, h->m_r.p, fx);
+    GL_HIP(hipGetLastError());
     for (int l = 0; l < m_hist; ++l) h->mh_G[slot][l] = h->mh_G[l][slot] = g[l];   // g against the slots that stay
     h->mh_G[slot][slot] = nb2;
     h->mh_next = (slot + 1) % mh_depth;
