@@ -141,6 +141,25 @@ def test_multigrid_index_streams_give_the_same_bits(backend):
     assert out[0][1] == out[1][1] and np.array_equal(out[0][0], out[1][0])
 
 
+def test_multigrid_with_a_stiff_clamped_exterior(backend):
+    """The situation of TumorGrowthBrain's 'outside' subdomain (simulation_tumor_growth_brain.py:37-38: E = 10e3 next to
+    tissue at 3e-3): the shell that touches the clamped hull 3e6 times stiffer than the ellipsoid inside.  1 M nodes: 31
+    iterations (no jump: 19; block-Jacobi at a jump of 1e4: 891).  A FLOATING stiff inclusion is the hard case for
+    d-linear interpolation (jump 1e2 / 1e4: 27 / 124 iterations at 1 M nodes)."""
+    w = _c5_reduced(32)
+    E = list(w.tables['E'])
+    E[2] *= 3e6
+    w.tables = dict(w.tables, E=E)
+    h, dofs = _c5_handle(backend, w, mech_history=0, mech_rtol=1e-11)
+    assert h.solve_mechanics() == 0
+    u = h.get_state()[1]
+    its = h.stats()['mech_cg_its']
+    h.close()
+    uo = _c5_oracle(w, dofs).mech_solve(w.c0)
+    print("stiff clamped exterior (3e6), n = 32: %d PCG iterations, u vs LU %.2e" % (its, rel_l2(u, uo)))
+    assert rel_l2(u, uo) < 1e-6 and its <= 60
+
+
 def test_multigrid_near_the_incompressible_limit(backend):
     """nu = 0.49 in every tissue -- the upper end of the range the reference documents (simulation_tumor_growth.py:60,
     'poisson ratio nu: 0.4 ... 0.49'): lambda / mu = 49.  The point-block Chebyshev smoother loses some of its grip

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Config C5 (coupled model on the brain-extent box): elasticity solve after every RD step, per preconditioner.
-    python tools/run_c5.py [n] [steps]      env: PRECOND=mg|bj  SMOOTH=k  RATIO  MIXED=0|1|2  HIST=k  HFAC  COARSE  FP32SM=1  X64=1  MECH_RTOL  NU=0.49"""
+    python tools/run_c5.py [n] [steps]      env: PRECOND=mg|bj  SMOOTH=k  RATIO  MIXED=0|1|2  HIST=k  HFAC  COARSE  FP32SM=1  X64=1  MECH_RTOL  NU=0.49  EWM=1e4  EGM=1e4"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,6 +16,12 @@ t = dict(w.tables)
 if os.environ.get("NU"):   # Poisson ratio of every tissue with nu > 0.4 (near-incompressible study)
     t['nu'] = [float(os.environ["NU"]) if v > 0.4 else v for v in t['nu']]
     print("nu table:", t['nu'])
+if os.environ.get("EWM"):   # stiffness of the white-matter ellipsoid relative to the table's (coefficient-jump study)
+    t['E'] = list(t['E']); t['E'][3] = t['E'][3] * float(os.environ["EWM"])
+    print("E table:", t['E'])
+if os.environ.get("EGM"):   # the same for the grey-matter shell (touches the clamped hull)
+    t['E'] = list(t['E']); t['E'][2] = t['E'][2] * float(os.environ["EGM"])
+    print("E table:", t['E'])
 h.set_materials(t['D'], t['rho'], t['gamma'], t['E'], t['nu'])
 pre = _backend.PRECOND_BLOCK_JACOBI if os.environ.get("PRECOND", "mg") == "bj" else _backend.PRECOND_MULTIGRID
 h.set_options(dt=w.dt, mech_rtol=float(os.environ.get("MECH_RTOL", "1e-10")), mech_precond=pre,
