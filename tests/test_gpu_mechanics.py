@@ -146,7 +146,7 @@ def test_multigrid_with_a_stiff_clamped_exterior(backend):
     tissue at 3e-3): the shell that touches the clamped hull 3e6 times stiffer than the ellipsoid inside.  1 M nodes: 31
     iterations (no jump: 19; block-Jacobi at a jump of 1e4: 891).  A FLOATING stiff inclusion is the hard case for
     d-linear interpolation (jump 1e2 / 1e4: 27 / 124 iterations at 1 M nodes)."""
-    w = _c5_reduced(32)
+    w = _c5_reduced(24)
     E = list(w.tables['E'])
     E[2] *= 3e6
     w.tables = dict(w.tables, E=E)
@@ -156,7 +156,7 @@ def test_multigrid_with_a_stiff_clamped_exterior(backend):
     its = h.stats()['mech_cg_its']
     h.close()
     uo = _c5_oracle(w, dofs).mech_solve(w.c0)
-    print("stiff clamped exterior (3e6), n = 32: %d PCG iterations, u vs LU %.2e" % (its, rel_l2(u, uo)))
+    print("stiff clamped exterior (3e6), n = 24: %d PCG iterations, u vs LU %.2e" % (its, rel_l2(u, uo)))
     assert rel_l2(u, uo) < 1e-6 and its <= 60
 
 
@@ -165,7 +165,7 @@ def test_multigrid_near_the_incompressible_limit(backend):
     'poisson ratio nu: 0.4 ... 0.49'): lambda / mu = 49.  The point-block Chebyshev smoother loses some of its grip
     (39 its at 1 M nodes instead of 19 at nu = 0.45; 0.495 -> 53, 0.499 -> 104) but stays far from the block-Jacobi
     count (1806 at 1 M), and the answer is the oracle's sparse LU."""
-    w = _c5_reduced(32)
+    w = _c5_reduced(24)
     w.tables = dict(w.tables, nu=[0.49 if v > 0.4 else v for v in w.tables['nu']])
     its = {}
     for name, pre in (("mg", backend.PRECOND_MULTIGRID), ("bj", backend.PRECOND_BLOCK_JACOBI)):
@@ -177,7 +177,7 @@ def test_multigrid_near_the_incompressible_limit(backend):
         if name == "mg":
             uo = _c5_oracle(w, dofs).mech_solve(w.c0)
         assert rel_l2(u, uo) < 1e-7
-    print("nu = 0.49, n = 32: PCG iterations", its)
+    print("nu = 0.49, n = 24: PCG iterations", its)
     assert its["mg"] <= 60 and its["mg"] < 0.2 * its["bj"]
 
 
