@@ -461,5 +461,6 @@ void gl_mg_setup(glims_ctx* h);
 void gl_make_smoother_copy(glims_ctx* h, bool half, bool exchange_scale);
 void gl_mg_apply(glims_ctx* h, const double* r, double* u, const int* done = nullptr);   // u = V-cycle(r); r zero on constrained dofs
 // level-0 operator pass of the multigrid (kernels.hip): mode 0 out = r - A x, 1 Chebyshev step, 2 out = Dinv A x
+void gl_make_kel32(glims_ctx* h);
 void gl_launch_mg_fine(glims_ctx* h, int mode, const double* xin, const double* r, double* d, double* xout, double c1,
                        double c2, const int* done = nullptr, double* uout = nullptr);

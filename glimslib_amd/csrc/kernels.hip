@@ -997,12 +997,7 @@ static void assemble_static_t(glims_ctx* h, int with_mechanics) {
     for (int a = 0; a < D; ++a)
       for (int b = 0; b < D; ++b) assemble_plane<D>(h, MODE_KEL, a, b, h->vKel.p, D * D, (a * D + b) * GL_WAVE);
     for (int a = 0; a < D; ++a) assemble_plane<D>(h, MODE_G, a, 0, h->vG.p, D, a * GL_WAVE);
-    // single-precision copy of K_el for the inner solves of the mixed-precision elasticity solver
-    h->vKel32.alloc(ne * D * D);
-    const size_t nk = ne * D * D;
-    hipLaunchKernelGGL(k_to_float, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, h->st, (int64_t)nk, h->vKel.p,
-                       h->vKel32.p);
-    GL_HIP(hipGetLastError());
+    h->vKel32.release();   // the single-precision copy (mixed-precision solver only) is rebuilt on demand, gl_make_kel32
   }
 }
 
@@ -1137,6 +1132,16 @@ void gl_spmv_scalar(glims_ctx* h, const double* vals, const double* x, double* y
 void gl_spmv_block(glims_ctx* h, const double* x, double* y, bool masked) {
   gl_launch_spmv_block(h, h->st, h->pat.n_slices, nullptr, x, y,
                        masked && h->have_fixed_u ? h->fixed_u.p : nullptr, nullptr, nullptr, 0, nullptr, false);
+}
+
+// single-precision copy of K_el for the inner solves of the mixed-precision elasticity solver (built on first use)
+void gl_make_kel32(glims_ctx* h) {
+  if (h->vKel32.n == h->vKel.n && h->vKel32.p) return;
+  const size_t nk = h->vKel.n;
+  h->vKel32.alloc(nk);
+  hipLaunchKernelGGL(k_to_float, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, h->st, (int64_t)nk, h->vKel.p,
+                     h->vKel32.p);
+  GL_HIP(hipGetLastError());
 }
 
 void gl_apply_G(glims_ctx* h, const double* c, double* y) {

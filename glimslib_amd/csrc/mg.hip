@@ -1098,7 +1098,7 @@ void mg_setup_t(glims_ctx* h) {
     t_last = t;
   };
   mg.clear();
-  GL_REQUIRE(h->vKel32.n != 0 && h->vKel.n != 0, "multigrid set-up before the elasticity operator was assembled");
+  GL_REQUIRE(h->vKel.n != 0, "multigrid set-up before the elasticity operator was assembled");
   GL_REQUIRE(!mm.xyz.empty(), "mesh metrics missing");
   const uint8_t* fx = h->have_fixed_u ? h->fixed_u.p : nullptr;
   const double hf = h->opt.mg_h_factor > 0.5 ? h->opt.mg_h_factor : 2.0;

@@ -1230,10 +1230,15 @@ int gl_solve_mechanics(glims_ctx* h, const double* c_dev) {
   int64_t its = 0;
   double res = 0.0;
   int cs = GLIMS_OK;
-  // worth it only where the operator is streamed from HBM: below ~256 MB (Infinity Cache) an iteration is latency
-  // bound and the restarts of the refinement loop only add iterations (GLIMS_MECH_MIXED: 0 off, 1 auto, 2 always)
+  // Mixed precision (mech_mixed: 0 off, 1 auto, 2 always).  Auto = with the block-Jacobi preconditioner, where an
+  // iteration IS one operator pass, and only where the operator is streamed from HBM (below ~256 MB, the Infinity Cache,
+  // an iteration is latency bound and the restarts of the refinement loop only add iterations).  Never with the multigrid
+  // preconditioner: the operator pass is 7 % of an iteration there, and the restarts cost more than that -- C5 at 10 M
+  // nodes 102 vs 107 ms per solve, Delaunay 1 M points 99 vs 117 ms, and with a stiff inclusion (stiffness jump 1e4) the
+  // restarted iteration loses the superlinear phase of CG altogether: 11 iterations against 29-55.
   const bool big = (size_t)p.total_entries * bs * bs * sizeof(double) > ((size_t)256 << 20);
-  const bool mixed = h->vKel32.n != 0 && (h->opt.mech_mixed == 2 || (h->opt.mech_mixed == 1 && big));
+  const bool mixed = h->opt.mech_mixed == 2 || (h->opt.mech_mixed == 1 && big && !use_mg);
+  if (mixed) gl_make_kel32(h);
   if (!mixed) {
     cs = cg_solve(h, v, tol, h->opt.mech_maxit, h->mech_hint, &its, &res);
     h->mech_hint = (int)its;

@@ -75,7 +75,8 @@ typedef struct glims_options {
    * (simulation_tumor_growth_brain_quad.py:116-119); here: PCG preconditioned by one multigrid V-cycle. */
   int    mech_precond;    /* GLIMS_PRECOND_BLOCK_JACOBI | GLIMS_PRECOND_MULTIGRID                default MULTIGRID */
   int    mech_mixed;      /* inner PCG streams a single-precision copy of K_el under an fp64 iterative-refinement
-                             loop: 0 off, 1 when K_el exceeds the Infinity Cache, 2 always          default 1     */
+                             loop: 0 off, 1 auto (block-Jacobi preconditioner and K_el larger than the Infinity
+                             Cache; never with the multigrid preconditioner), 2 always              default 1     */
   int    mech_history;    /* right-hand sides / solutions of the last k solves kept for the least-squares initial
                              guess (K_el is linear and time independent), 0..16                     default 8     */
   int    mg_smooth;       /* Chebyshev degree of the pre- and of the post-smoother on every level

@@ -267,8 +267,9 @@ def test_config_c5_full_size_properties(backend):
     Kx, Ky = h.apply(3, x)[0], h.apply(3, y)[0]
     assert abs(x @ Ky - y @ Kx) < 1e-11 * abs(x @ Ky)
     h.close()
-    # all-fp64 inner solve and block-Jacobi preconditioner: same displacement
-    h2, _ = _c5_handle(backend, w, mech_mixed=0)
+    # mixed-precision refinement around the multigrid-preconditioned solve (off by default with this preconditioner) and
+    # the block-Jacobi preconditioner (mixed by default at this size): same displacement
+    h2, _ = _c5_handle(backend, w, mech_mixed=2)
     h2.set_state(c)
     assert h2.solve_mechanics() == 0
     assert rel_l2(h2.get_state()[1], u) < 1e-8
