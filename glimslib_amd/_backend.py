@@ -24,7 +24,8 @@ FLAG_MG_FP32_SMOOTHER = 8
 FLAG_INT32_COLUMNS = 16
 FLAG_MG_FP64_VECTORS = 32
 PRECOND_BLOCK_JACOBI, PRECOND_MULTIGRID = 0, 1
-ABI_VERSION = 2
+RD_PRECOND_AUTO, RD_PRECOND_JACOBI, RD_PRECOND_MULTIGRID = 0, 1, 2
+ABI_VERSION = 3
 
 
 class BackendError(RuntimeError):
@@ -40,7 +41,8 @@ class Options(C.Structure):
                 ("mech_maxit", C.c_int), ("check_every", C.c_int), ("flags", C.c_int),
                 ("mech_precond", C.c_int), ("mech_mixed", C.c_int), ("mech_history", C.c_int),
                 ("mg_smooth", C.c_int), ("mg_coarse_nodes", C.c_int), ("mg_h_factor", C.c_double),
-                ("mg_cheb_ratio", C.c_double), ("time_kernels", C.c_int)]
+                ("mg_cheb_ratio", C.c_double), ("time_kernels", C.c_int),
+                ("rd_precond", C.c_int), ("rd_mg_smooth", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -54,7 +56,9 @@ class Stats(C.Structure):
                 ("mg_complexity", C.c_double), ("ms_mg_setup", C.c_double), ("ms_mech", C.c_double),
                 ("ms_sweep_steps", C.c_double), ("n_sweep_steps", C.c_int64), ("ms_update_steps", C.c_double),
                 ("n_update_steps", C.c_int64), ("us_spmv_median", C.c_double), ("us_sweep_median", C.c_double),
-                ("us_update_median", C.c_double)]
+                ("us_update_median", C.c_double),
+                ("rd_precond_used", C.c_int64), ("rd_stiffness_ratio", C.c_double), ("rd_mg_levels", C.c_int64),
+                ("rd_mg_cycles", C.c_int64), ("rd_mg_complexity", C.c_double), ("ms_rd_mg_setup", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -101,6 +101,8 @@ int glims_options_default(glims_options* o) {
   o->mg_h_factor = 2.0;
   o->mg_cheb_ratio = 0.0;
   o->time_kernels = 0;
+  o->rd_precond = GLIMS_RD_PRECOND_AUTO;
+  o->rd_mg_smooth = 1;
   return GLIMS_OK;
 }
 
@@ -289,7 +291,8 @@ int glims_set_materials(glims_ctx* h, int n_labels, const double* D, const doubl
                         const double* E, const double* nu) {
   return guarded(h, [&]() {
     h->mh_count = h->mh_next = 0;   // the elasticity solve history belongs to one operator
-    h->mg.ready = false;
+    h->mg.ready = h->mg_rd.ready = false;
+    h->rd_precond_active = 0;
     GL_REQUIRE(n_labels > 0 && n_labels <= GL_MAX_LABELS, "n_labels out of range");
     GL_REQUIRE(D && rho && gamma && E && nu, "null material table");
     std::vector<double> m(5 * GL_MAX_LABELS, 0.0);
@@ -326,12 +329,20 @@ int glims_set_options(glims_ctx* h, const glims_options* opt) {
     GL_REQUIRE(opt->mech_mixed >= 0 && opt->mech_mixed <= 2 && opt->mech_history >= 0 && opt->mg_smooth >= 1 &&
                    opt->mg_coarse_nodes >= 1 && opt->mg_h_factor > 0.0 && (opt->mg_cheb_ratio == 0.0 || opt->mg_cheb_ratio > 1.0),
                "bad elasticity solver options");
-    if (opt->mg_smooth != h->opt.mg_smooth || opt->mg_coarse_nodes != h->opt.mg_coarse_nodes ||
-        opt->mg_h_factor != h->opt.mg_h_factor)
-      h->mg.ready = false;
+    GL_REQUIRE(opt->rd_precond >= GLIMS_RD_PRECOND_AUTO && opt->rd_precond <= GLIMS_RD_PRECOND_MULTIGRID &&
+                   opt->rd_mg_smooth >= 1 && opt->rd_mg_smooth <= 8,
+               "bad RD preconditioner options");
+    // mg_smooth and mg_cheb_ratio are read by every cycle (no rebuild); the grids depend on the other two
+    if (opt->mg_coarse_nodes != h->opt.mg_coarse_nodes || opt->mg_h_factor != h->opt.mg_h_factor)
+      h->mg.ready = h->mg_rd.ready = false;
+    if (opt->rd_precond != h->opt.rd_precond) h->rd_precond_active = 0;   // decided again by the next glims_step
+    // the solve history is a ring of `mech_history` slots: a new depth starts an empty ring (a larger depth would
+    // otherwise count never-allocated slots as stored solves)
+    if (opt->mech_history != h->opt.mech_history) h->mh_count = h->mh_next = 0;
     if (opt->dt != h->opt.dt) h->is_setup = false;
     if ((opt->flags ^ h->opt.flags) & (GLIMS_FLAG_FP32_JACOBIAN | GLIMS_FLAG_INT32_COLUMNS)) h->is_setup = false;
-    if ((opt->flags ^ h->opt.flags) & (GLIMS_FLAG_MG_FP32_SMOOTHER | GLIMS_FLAG_MG_FP64_VECTORS)) h->mg.ready = false;
+    if ((opt->flags ^ h->opt.flags) & (GLIMS_FLAG_MG_FP32_SMOOTHER | GLIMS_FLAG_MG_FP64_VECTORS))
+      h->mg.ready = h->mg_rd.ready = false;
     h->opt = *opt;
     h->pending = false;
     return GLIMS_OK;
@@ -342,7 +353,9 @@ int glims_set_dirichlet_c(glims_ctx* h, int64_t n, const int64_t* node_ids, cons
   return guarded(h, [&]() {
     h->pending = false;
     if (n <= 0) {
+      if (h->have_fixed_c) h->mg_rd.ready = false;   // the RD hierarchy eliminates the constrained nodes
       h->have_fixed_c = false;
+      h->fixed_c_host.clear();
       h->dirichlet_c_dirty = false;
       return GLIMS_OK;
     }
@@ -355,6 +368,8 @@ int glims_set_dirichlet_c(glims_ctx* h, int64_t n, const int64_t* node_ids, cons
       fx[h->old2new[node_ids[k]]] = 1;
       val[h->old2new[node_ids[k]]] = values[k];
     }
+    if (fx != h->fixed_c_host) h->mg_rd.ready = false;   // new VALUES every step are the normal case: no rebuild for those
+    h->fixed_c_host = fx;
     h->fixed_c.upload(fx, h->st);
     h->fixed_c_val.upload(val, h->st);
     h->have_fixed_c = true;
@@ -423,7 +438,9 @@ int glims_set_mech_load(glims_ctx* h, const double* f) {
 int glims_setup(glims_ctx* h, int with_mechanics) {
   return guarded(h, [&]() {
     h->mh_count = h->mh_next = 0;   // the elasticity solve history belongs to one operator
-    h->mg.ready = false;
+    h->mg.ready = h->mg_rd.ready = false;
+    h->rd_precond_active = 0;       // decided by the first glims_step (a collective in partitioned runs)
+    h->stats.rd_precond_used = 0;
     GL_REQUIRE(h->have_materials, "glims_setup before glims_set_materials");
     if (with_mechanics) {
       const size_t nd = (size_t)h->n_nodes * h->dim;
@@ -511,6 +528,11 @@ int glims_reset_stats(glims_ctx* h) {
   h->stats.mg_levels = keep.mg_levels;
   h->stats.mg_complexity = keep.mg_complexity;
   h->stats.ms_mg_setup = keep.ms_mg_setup;
+  h->stats.rd_precond_used = keep.rd_precond_used;
+  h->stats.rd_stiffness_ratio = keep.rd_stiffness_ratio;
+  h->stats.rd_mg_levels = keep.rd_mg_levels;
+  h->stats.rd_mg_complexity = keep.rd_mg_complexity;
+  h->stats.ms_rd_mg_setup = keep.ms_rd_mg_setup;
   h->tev_used = 0;
   h->stats.steps = keep.steps;   // step counter drives the extrapolated guess; keep it
   return GLIMS_OK;
@@ -749,13 +771,13 @@ int glims_set_transport(glims_ctx* h, int rank, int world, glims_halo_fn halo, g
 
 int glims_set_mg_frame(glims_ctx* h, const double* lo, const double* hi) {
   return guarded(h, [&]() {
-    h->mg.ready = false;
+    h->mg.ready = h->mg_rd.ready = false;
     if (!lo || !hi) {
       h->mg_frame_set = false;
       return GLIMS_OK;
     }
     for (int a = 0; a < h->dim; ++a) {
-      GL_REQUIRE(std::isfinite(lo[a]) && std::isfinite(hi[a]) && hi[a] >= lo[a], "bad bounding box");
+      GL_REQUIRE(std::isfinite(lo[a]) && std::isfinite(hi[a]) && hi[a] > lo[a], "bad bounding box (need hi > lo on every axis)");
       h->mg_frame_lo[a] = lo[a];
       h->mg_frame_hi[a] = hi[a];
     }

@@ -18,10 +18,11 @@
 // streams 2 B instead of 4 B of index per entry.  Slices that need more windows fall back to the 32-bit stream.
 #define GL_WIN_BITS 11
 #define GL_N_WIN 32
-// elasticity multigrid, partitioned runs with glims_set_mg_frame: the auxiliary grids are replicated on every rank; the
-// first one may have at most this many nodes (operator 27 x 9 x 4 B per node = 4 GB, residual all-reduce 100 MB per
-// cycle at the limit) -- beyond it the grid spacing is widened until it fits
-#define GL_MG_GLOBAL_NODES (4ll << 20)
+// multigrid, partitioned runs with glims_set_mg_frame: the auxiliary grids are replicated on every rank; the operator of
+// the first one (stencil entries x block entries x 4 B per node: 27 x 9 x 4 B for elasticity on a lattice mesh = 4 M
+// nodes, 125 x 9 x 4 B on a general mesh = 0.9 M nodes) may take at most this many bytes -- beyond it the grid spacing
+// is widened until it fits
+#define GL_MG_GLOBAL_BYTES (4ll << 30)
 // Blocks are dealt to the 8 XCDs in chunks of this many consecutive logical blocks: neighbouring slices (overlapping x
 // gathers) share one L2 while the XCDs together still walk the matrix front to back (measured: time of the plain
 // mapping, fabric reads 2.21 -> 1.97 GB per SpMV at 10 M rows; contiguous eighths are 1-5 % slower).
@@ -178,6 +179,18 @@ struct MgLevel {                           // one Cartesian level
 };
 struct MgHierarchy {
   bool ready = false;
+  // The operator this hierarchy preconditions (set by the caller of gl_mg_setup; borrowed pointers that must stay valid
+  // while `ready`): K_el with bs = dim (elasticity), or the static part S of the RD Jacobian with bs = 1.
+  int bs = 0;                              // dofs per mesh node
+  const double* op_vals = nullptr;         // fp64 SELL-64 planes [entry][bs * bs][64]
+  const uint8_t* op_fixed = nullptr;       // constrained dofs [n_nodes * bs], nullptr = none
+  const double* op_dinv = nullptr;         // fp64 inverse diagonal blocks of the constrained operator [n_own][bs * bs]
+  dvec<double> own_dinv;                   // ... kept here when nobody else owns them (RD hierarchy)
+  dvec<uint16_t> v16;                      // level 0: half-precision copy of S A S (bit pattern of _Float16)
+  bool lattice = false;
+  int n_levels = 0;                        // incl. the mesh itself
+  int64_t cycles = 0;
+  double complexity = 0.0, ms_setup = 0.0;
   int R = 1, S = 27;                       // stencil radius / entries of the Cartesian levels
   double lo[3] = {0, 0, 0}, H[3] = {1, 1, 1};
   dvec<int32_t> cell0;                     // [n_own] lower-corner grid node of the level-1 cell that holds a mesh node
@@ -296,6 +309,10 @@ template <> struct XNode<3, float> {
     reinterpret_cast<float4*>(x)[j] = make_float4((float)v[0], (float)v[1], (float)v[2], 0.0f);
   }
 };
+template <> struct XNode<1, float> {
+  static __device__ __forceinline__ void load(const float* __restrict__ x, int64_t j, double* o) { o[0] = (double)x[j]; }
+  static __device__ __forceinline__ void store(float* __restrict__ x, int64_t j, const double* v) { x[j] = (float)v[0]; }
+};
 template <> struct XNode<2, float> {
   static __device__ __forceinline__ void load(const float* __restrict__ x, int64_t j, double* o) {
     const float2 v = reinterpret_cast<const float2*>(x)[j];
@@ -308,6 +325,8 @@ template <> struct XNode<2, float> {
 };
 
 #endif
+// (bs = 1 with single-precision vectors has no whole-double record: such a hierarchy keeps double vectors whenever its
+// level-0 passes exchange halos, see mg_setup_t)
 inline int gl_xrec_doubles(int bs, bool x32) { return x32 ? (bs == 3 ? 2 : 1) : bs; }
 
 // scalar slots of the Krylov recurrence (device array `scal`)
@@ -362,7 +381,6 @@ struct glims_ctx {
   bool pair_A = false;                     // vA / vA32 and cols16p use the slot-pair layout (GLIMS_PAIR_A, needs 16-bit codes everywhere)
   int tune_pair_A = 1;
   dvec<float> vKel32;                      // single-precision copy of K_el (inner solves of the elasticity solver)
-  dvec<uint16_t> vKel16;                   // half-precision copy of S K_el S (bit pattern of _Float16): level-0 multigrid smoother
   // vectors (internal numbering; length n_nodes unless noted)
   dvec<double> c, c_old, b, load_rd, dinv;
   dvec<double> cg_p, cg_s, cg_u, cg_w, cg_r, cg_r2, b2;     // scalar CG work vectors; r2/b2: speculative next step
@@ -380,7 +398,11 @@ struct glims_ctx {
   dvec<double> U, mload, m_rhs, m_p, m_s, m_u, m_w, m_r, m_dinv, m_uD;   // mechanics, [n_nodes*dim]
   dvec<uint8_t> fixed_c, fixed_u;
   bool have_fixed_c = false, have_fixed_u = false, have_load_rd = false, have_mload = false;
-  MgHierarchy mg;
+  MgHierarchy mg;                           // elasticity: K_el, 3 x 3 (2 x 2) blocks
+  MgHierarchy mg_rd;                        // RD Jacobian: built on its static part S = (1 - dt rho) M + dt K_D, scalar
+  int rd_precond_active = 0;                // what the RD solves use: GLIMS_RD_PRECOND_JACOBI | _MULTIGRID (decided at glims_setup)
+  double rd_stiffness_ratio = 0.0;          // mean over the rows of S_ii / M_ii (the quantity `auto` decides on)
+  std::vector<uint8_t> fixed_c_host;        // host copy of the concentration's Dirichlet mask (did the SET of nodes change?)
   bool mg_frame_set = false;               // glims_set_mg_frame: global bounding box of a partitioned mesh
   double mg_frame_lo[3] = {0, 0, 0}, mg_frame_hi[3] = {0, 0, 0};
   MeshMetrics mm;
@@ -457,10 +479,15 @@ void gl_block_dinv(glims_ctx* h);                                            // 
 
 // mg.hip --------------------------------------------------------------------------------------------
 void gl_mesh_metrics(glims_ctx* h, const HostPattern& hp, const double* xyz_old);
-void gl_mg_setup(glims_ctx* h);
-void gl_make_smoother_copy(glims_ctx* h, bool half, bool exchange_scale);
-void gl_mg_apply(glims_ctx* h, const double* r, double* u, const int* done = nullptr);   // u = V-cycle(r); r zero on constrained dofs
-// level-0 operator pass of the multigrid (kernels.hip): mode 0 out = r - A x, 1 Chebyshev step, 2 out = Dinv A x
+void gl_mg_setup(glims_ctx* h, MgHierarchy& mg);   // mg.bs / op_vals / op_fixed / op_dinv set by the caller
+void gl_make_smoother_copy(glims_ctx* h, MgHierarchy& mg, bool half, bool exchange_scale);
+// u = V-cycle(r) with Chebyshev smoothers of the given degree; r zero on constrained dofs
+void gl_mg_apply(glims_ctx* h, MgHierarchy& mg, int degree, const double* r, double* u, const int* done = nullptr);
 void gl_make_kel32(glims_ctx* h);
-void gl_launch_mg_fine(glims_ctx* h, int mode, const double* xin, const double* r, double* d, double* xout, double c1,
-                       double c2, const int* done = nullptr, double* uout = nullptr);
+// level-0 operator pass of the multigrid (kernels.hip): mode 0 out = r - A x, 1 Chebyshev step, 2 out = Dinv A x
+void gl_launch_mg_fine(glims_ctx* h, MgHierarchy& mg, int mode, const double* xin, const double* r, double* d,
+                       double* xout, double c1, double c2, const int* done = nullptr, double* uout = nullptr);
+// solver.hip: the two hierarchies
+void gl_mg_setup_mech(glims_ctx* h);
+void gl_mg_setup_rd(glims_ctx* h);
+void gl_rd_choose_precond(glims_ctx* h);    // glims_options.rd_precond -> rd_precond_active (collective in partitioned runs)

@@ -1157,38 +1157,42 @@ void gl_apply_G(glims_ctx* h, const double* c, double* y) {
   GL_HIP(hipGetLastError());
 }
 
-void gl_launch_mg_fine(glims_ctx* h, int mode, const double* xin, const double* r, double* d, double* xout, double c1,
-                       double c2, const int* done, double* uout) {
+void gl_launch_mg_fine(glims_ctx* h, MgHierarchy& mg, int mode, const double* xin, const double* r, double* d,
+                       double* xout, double c1, double c2, const int* done, double* uout) {
   const DevPattern& p = h->pat;
   const int grid = gl_spmv_grid(p.n_slices);
   const int chunk = (p.n_slices + grid - 1) / grid;
-  const uint8_t* fx = h->have_fixed_u ? h->fixed_u.p : nullptr;
-  const bool half = h->mg.half_smoother;
+  const uint8_t* fx = mg.op_fixed;
+  const bool half = mg.half_smoother;
   const bool c16 = h->use_idx16 && h->stats.nnz_idx16 == h->stats.nnz_padded;   // every slice has 16-bit codes
-  const bool x32 = h->mg.x32 && mode != 2;   // the power iteration of the set-up (mode 2) works on double vectors
-#define GL_MGF4(BS, MODE, VT, VPTR, CIDX, XT)                                                                        \
-  hipLaunchKernelGGL((k_mg_fine<BS, MODE, 2, VT, CIDX, XT>), dim3(grid), dim3(256), 0, h->st, p.n_slices, chunk,      \
-                     h->n_own, p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, VPTR, h->mg.dinv0.p, h->mg.sc.p,   \
+  const bool x32 = mg.x32 && mode != 2;   // the power iteration of the set-up (mode 2) works on double vectors
+  // entries in flight per lane: 2 blocks of 3 x 3 (2 x 2), or 8 scalars (an interior row of a tetrahedral mesh has 15)
+#define GL_MGF4(BS, KB, MODE, VT, VPTR, CIDX, XT)                                                                    \
+  hipLaunchKernelGGL((k_mg_fine<BS, MODE, KB, VT, CIDX, XT>), dim3(grid), dim3(256), 0, h->st, p.n_slices, chunk,     \
+                     h->n_own, p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, VPTR, mg.dinv0.p, mg.sc.p,         \
                      fx, (const XT*)xin, (const XT*)r, (XT*)d, (XT*)xout, uout, c1, c2, GL_XCD_CHUNK, done)
-#define GL_MGF3(BS, MODE, VT, VPTR, CIDX)                                                                            \
+#define GL_MGF3(BS, KB, MODE, VT, VPTR, CIDX)                                                                        \
   do {                                                                                                               \
-    if (MODE != 2 && x32) GL_MGF4(BS, MODE, VT, VPTR, CIDX, float);                                                  \
-    else GL_MGF4(BS, MODE, VT, VPTR, CIDX, double);                                                                  \
+    if (MODE != 2 && x32) GL_MGF4(BS, KB, MODE, VT, VPTR, CIDX, float);                                              \
+    else GL_MGF4(BS, KB, MODE, VT, VPTR, CIDX, double);                                                              \
   } while (0)
-#define GL_MGF2(BS, MODE, CIDX)                                                                                      \
+#define GL_MGF2(BS, KB, MODE, CIDX)                                                                                  \
   do {                                                                                                               \
-    if (half) GL_MGF3(BS, MODE, _Float16, (const _Float16*)h->vKel16.p, CIDX);                                       \
-    else GL_MGF3(BS, MODE, float, h->mg.vK32s.p, CIDX);                                                              \
+    if (half) GL_MGF3(BS, KB, MODE, _Float16, (const _Float16*)mg.v16.p, CIDX);                                      \
+    else GL_MGF3(BS, KB, MODE, float, mg.vK32s.p, CIDX);                                                             \
   } while (0)
-#define GL_MGF(BS, MODE)                                                                                             \
+#define GL_MGF(BS, KB, MODE)                                                                                         \
   do {                                                                                                               \
-    if (c16) GL_MGF2(BS, MODE, 1); else GL_MGF2(BS, MODE, 0);                                                        \
+    if (c16) GL_MGF2(BS, KB, MODE, 1); else GL_MGF2(BS, KB, MODE, 0);                                                \
   } while (0)
-  if (h->dim == 2) {
-    if (mode == 0) GL_MGF(2, 0); else if (mode == 1) GL_MGF(2, 1); else GL_MGF(2, 2);
-  } else {
-    if (mode == 0) GL_MGF(3, 0); else if (mode == 1) GL_MGF(3, 1); else GL_MGF(3, 2);
-  }
+#define GL_MGFM(BS, KB)                                                                                              \
+  do {                                                                                                               \
+    if (mode == 0) GL_MGF(BS, KB, 0); else if (mode == 1) GL_MGF(BS, KB, 1); else GL_MGF(BS, KB, 2);                 \
+  } while (0)
+  if (mg.bs == 1) GL_MGFM(1, 8);
+  else if (mg.bs == 2) GL_MGFM(2, 2);
+  else GL_MGFM(3, 2);
+#undef GL_MGFM
 #undef GL_MGF
 #undef GL_MGF2
 #undef GL_MGF3
@@ -1196,43 +1200,40 @@ void gl_launch_mg_fine(glims_ctx* h, int mode, const double* xin, const double* 
   GL_HIP(hipGetLastError());
 }
 
-// The smoother's operator of level 0: scaling vector, scaled inverse diagonal blocks, and the scaled copy of K_el in
-// half precision (default) or single precision (GLIMS_FLAG_MG_FP32_SMOOTHER).  Needs m_dinv (gl_block_dinv).
+// The smoother's operator of level 0: scaling vector, scaled inverse diagonal blocks, and the scaled copy of the
+// hierarchy's operator (K_el, or S of the RD block) in half precision (default) or single precision
+// (GLIMS_FLAG_MG_FP32_SMOOTHER).  Needs mg.op_dinv.
 // exchange_scale: partitioned run whose level-0 passes see the ghosts -- their scale factors come from their owners.
-void gl_make_smoother_copy(glims_ctx* h, bool half, bool exchange_scale) {
+void gl_make_smoother_copy(glims_ctx* h, MgHierarchy& mg, bool half, bool exchange_scale) {
   const DevPattern& p = h->pat;
-  const int bs = h->dim;
+  const int bs = mg.bs;
   const int64_t n_pad = std::max<int64_t>((int64_t)p.n_slices * GL_WAVE, h->n_nodes);
-  h->mg.sc.alloc((size_t)n_pad * bs);
-  h->mg.dinv0.alloc((size_t)h->n_own * bs * bs);
-  const uint8_t* fx = h->have_fixed_u ? h->fixed_u.p : nullptr;
+  mg.sc.alloc((size_t)n_pad * bs);
+  mg.dinv0.alloc((size_t)h->n_own * bs * bs);
+  const uint8_t* fx = mg.op_fixed;
   const unsigned g = (unsigned)((n_pad + 255) / 256);
-  if (bs == 2)
-    hipLaunchKernelGGL(k_mg_scaling<2>, dim3(g), dim3(256), 0, h->st, h->n_own, n_pad, p.slice_ptr.p, p.diag_k.p,
-                       h->vKel.p, fx, h->m_dinv.p, h->mg.sc.p, h->mg.dinv0.p);
-  else
-    hipLaunchKernelGGL(k_mg_scaling<3>, dim3(g), dim3(256), 0, h->st, h->n_own, n_pad, p.slice_ptr.p, p.diag_k.p,
-                       h->vKel.p, fx, h->m_dinv.p, h->mg.sc.p, h->mg.dinv0.p);
+#define GL_SCALING(BS)                                                                                               \
+  hipLaunchKernelGGL(k_mg_scaling<BS>, dim3(g), dim3(256), 0, h->st, h->n_own, n_pad, p.slice_ptr.p, p.diag_k.p,       \
+                     mg.op_vals, fx, mg.op_dinv, mg.sc.p, mg.dinv0.p)
+  if (bs == 1) GL_SCALING(1); else if (bs == 2) GL_SCALING(2); else GL_SCALING(3);
+#undef GL_SCALING
   GL_HIP(hipGetLastError());
-  if (exchange_scale) gl_halo_exchange(h, h->mg.sc.p, bs);
+  if (exchange_scale) gl_halo_exchange(h, mg.sc.p, bs);
   const size_t nk = (size_t)p.total_entries * bs * bs;
+#define GL_COPY(BS, OT, OUT)                                                                                         \
+  hipLaunchKernelGGL((k_scaled_copy<BS, OT>), dim3(p.n_slices), dim3(GL_WAVE), 0, h->st, p.n_slices, p.slice_ptr.p,   \
+                     p.cols.p, mg.op_vals, mg.sc.p, OUT)
   if (half) {
-    h->vKel16.alloc(nk);
-    if (bs == 2)
-      hipLaunchKernelGGL((k_scaled_copy<2, _Float16>), dim3(p.n_slices), dim3(GL_WAVE), 0, h->st, p.n_slices,
-                         p.slice_ptr.p, p.cols.p, h->vKel.p, h->mg.sc.p, (_Float16*)h->vKel16.p);
-    else
-      hipLaunchKernelGGL((k_scaled_copy<3, _Float16>), dim3(p.n_slices), dim3(GL_WAVE), 0, h->st, p.n_slices,
-                         p.slice_ptr.p, p.cols.p, h->vKel.p, h->mg.sc.p, (_Float16*)h->vKel16.p);
+    mg.v16.alloc(nk);
+    mg.vK32s.release();
+    _Float16* out = (_Float16*)mg.v16.p;
+    if (bs == 1) GL_COPY(1, _Float16, out); else if (bs == 2) GL_COPY(2, _Float16, out); else GL_COPY(3, _Float16, out);
   } else {
-    h->mg.vK32s.alloc(nk);
-    if (bs == 2)
-      hipLaunchKernelGGL((k_scaled_copy<2, float>), dim3(p.n_slices), dim3(GL_WAVE), 0, h->st, p.n_slices,
-                         p.slice_ptr.p, p.cols.p, h->vKel.p, h->mg.sc.p, h->mg.vK32s.p);
-    else
-      hipLaunchKernelGGL((k_scaled_copy<3, float>), dim3(p.n_slices), dim3(GL_WAVE), 0, h->st, p.n_slices,
-                         p.slice_ptr.p, p.cols.p, h->vKel.p, h->mg.sc.p, h->mg.vK32s.p);
+    mg.vK32s.alloc(nk);
+    mg.v16.release();
+    if (bs == 1) GL_COPY(1, float, mg.vK32s.p); else if (bs == 2) GL_COPY(2, float, mg.vK32s.p); else GL_COPY(3, float, mg.vK32s.p);
   }
+#undef GL_COPY
   GL_HIP(hipGetLastError());
 }
 

@@ -108,14 +108,14 @@ __global__ void k_mg_reach(int64_t n_own, int64_t n_col, GridDev g1, const int64
 
 // A1[I, off] = sum_{i child of I} sum_{j in row i, I + off parent of j} w_iI w_j(I+off) F_i K_ij F_j
 // one thread per (grid node, stencil offset): a gather in a fixed order
-template <int D>
+template <int D, int BS>
 __global__ void k_mg_rap0(GridDev g1, int nbx, int nby, int R, int S, int64_t n_own, int64_t n_col,
                           const int32_t* __restrict__ cell_ptr,
                           const int32_t* __restrict__ cell_nodes, const int32_t* __restrict__ cell0,
                           const double* __restrict__ wgt, const int64_t* __restrict__ slice_ptr,
                           const int32_t* __restrict__ cols, const double* __restrict__ vK,
                           const uint8_t* __restrict__ fixed, float* __restrict__ A1) {
-  constexpr int BS = D, B2 = D * D;
+  constexpr int B2 = BS * BS;
   // grid nodes in bricks of 4^3 (8^2), the blocks of four bricks in a row on one XCD: the nodes around a cell all
   // walk the rows of its children (see k_mg_restrict0)
   constexpr int BW = D == 3 ? 4 : 8;
@@ -213,10 +213,10 @@ __device__ __forceinline__ double w1d(int f, int j, int J) {
 }
 
 // Galerkin product between two Cartesian levels, one thread per (coarse node, stencil offset)
-template <int D>
+template <int D, int BS>
 __global__ void k_mg_rap(GridDev gf, GridDev gc, Fac fc, int R, int S, const float* __restrict__ Af,
                          float* __restrict__ Ac) {
-  constexpr int B2 = D * D;
+  constexpr int B2 = BS * BS;
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= gc.nn * S) return;
   const long long I = t / S;
@@ -294,7 +294,9 @@ __device__ __forceinline__ void inv_block(double (*A)[BS], double* o) {
       for (int b = 0; b < BS; ++b) A[a][b] = A[b][a] = 0.0;
       A[a][a] = 1.0;
     }
-  if constexpr (BS == 2) {
+  if constexpr (BS == 1) {
+    o[0] = 1.0 / A[0][0];
+  } else if constexpr (BS == 2) {
     const double inv = 1.0 / (A[0][0] * A[1][1] - A[0][1] * A[1][0]);
     o[0] = A[1][1] * inv;
     o[1] = -A[0][1] * inv;
@@ -317,9 +319,9 @@ __device__ __forceinline__ void inv_block(double (*A)[BS], double* o) {
   }
 }
 
-template <int D>
+template <int D, int BS>
 __global__ void k_mg_dinv(GridDev g, int S, const float* __restrict__ A, double* __restrict__ dinv) {
-  constexpr int BS = D, B2 = D * D;
+  constexpr int B2 = BS * BS;
   const long long I = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (I >= g.nn) return;
   const int ctr = S / 2;
@@ -375,13 +377,13 @@ __device__ __forceinline__ void cart_epilogue(long long nn, long long I, const d
 // MODE 0: xout = r - A xin     MODE 1: d = c1 d + c2 Dinv (r - A xin); xout = xin + d     MODE 2: xout = Dinv A xin
 // osc (levels smoothed in scaled variables, MgLevel::half): MODE 0 leaves them, xout = (r~ - A~ x~) / s; MODE 1 with osc
 // is the last step of the cycle on this level, xout = s (x~ + d~)
-template <int D, int MODE, class AT>
+template <int D, int BS, int MODE, class AT>
 __global__ __launch_bounds__(256) void k_mg_cart(GridDev g, int R, const AT* __restrict__ A,
                                                   const double* __restrict__ dinv, const double* __restrict__ xin,
                                                   const double* __restrict__ r, double* __restrict__ d,
                                                   double* __restrict__ xout, double c1, double c2,
                                                   const int* __restrict__ done, const double* __restrict__ osc) {
-  constexpr int BS = D, B2 = D * D;
+  constexpr int B2 = BS * BS;
   if (done && *done) return;   // launches enqueued past the Krylov solver's convergence: nobody reads the result
   const long long I = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (I >= g.nn) return;
@@ -416,13 +418,13 @@ __global__ __launch_bounds__(256) void k_mg_cart(GridDev g, int R, const AT* __r
 // The same pass for SMALL grids: one wave per node, the stencil offsets dealt to the lanes, then a fixed shuffle tree.
 // A thread per node walks its 27 (125) offsets one after the other -- on a grid of a few thousand nodes that serial
 // chain, not bandwidth, is the whole kernel time (12-18 us per pass at 5^3 .. 26^3 nodes, measured).
-template <int D, int MODE>
+template <int D, int BS, int MODE>
 __global__ __launch_bounds__(256) void k_mg_cart_w(GridDev g, int R, int S, const float* __restrict__ A,
                                                     const double* __restrict__ dinv, const double* __restrict__ xin,
                                                     const double* __restrict__ r, double* __restrict__ d,
                                                     double* __restrict__ xout, double c1, double c2,
                                                     const int* __restrict__ done) {
-  constexpr int BS = D, B2 = D * D;
+  constexpr int B2 = BS * BS;
   if (done && *done) return;
   const long long I = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (I >= g.nn) return;
@@ -485,13 +487,13 @@ __global__ __launch_bounds__(256) void k_mg_cart_w(GridDev g, int R, int S, cons
 // G-th stencil offset, partial sums combined by a fixed xor-shuffle tree.  Lane = sub * (64 / G) + node-in-wave, so that
 // the lanes of one `sub` read 64 / G consecutive nodes of one operator plane.  A thread per node is a serial chain of
 // 27 (125) x B2 loads with too few threads to fill the device at these sizes; a wave per node wastes 37 of 64 lanes.
-template <int D, int MODE, int G, class AT>
+template <int D, int BS, int MODE, int G, class AT>
 __global__ __launch_bounds__(256) void k_mg_cart_g(GridDev g, int R, int S, const AT* __restrict__ A,
                                                     const double* __restrict__ dinv, const double* __restrict__ xin,
                                                     const double* __restrict__ r, double* __restrict__ d,
                                                     double* __restrict__ xout, double c1, double c2,
                                                     const int* __restrict__ done, const double* __restrict__ osc) {
-  constexpr int BS = D, B2 = D * D, NPW = GL_WAVE / G;   // nodes per wave
+  constexpr int B2 = BS * BS, NPW = GL_WAVE / G;   // nodes per wave
   if (done && *done) return;
   const int lane = threadIdx.x & 63;
   const int sub = lane / NPW;
@@ -534,11 +536,10 @@ __global__ __launch_bounds__(256) void k_mg_cart_g(GridDev g, int R, int S, cons
 
 // first smoothing step from a zero iterate: d = c2 Dinv r, x = d   (no operator pass)
 // sc (MgLevel::half): the level enters its scaled variables here, r <- r~ = s r in place
-template <int D>
+template <int D, int BS>
 __global__ void k_mg_first_cart(GridDev g, const double* __restrict__ dinv, double* __restrict__ r,
                                 double* __restrict__ d, double* __restrict__ x, double c2,
                                 const double* __restrict__ sc) {
-  constexpr int BS = D;
   const long long I = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (I >= g.nn) return;
   double rv[BS];
@@ -587,12 +588,12 @@ __global__ void k_mg_first_fine(int64_t n_own, const float* __restrict__ dinv, c
 // are dealt to groups of 64 / 2^D lanes, each lane takes the children of its cell with that stride; fixed lane -> child
 // assignment and a fixed shuffle tree, i.e. a gather in a reproducible order (a thread per grid node walked ~64
 // children one after the other: 232 us at 1 M mesh nodes against 134 us for a whole operator pass).
-template <int D, class XT>
+template <int D, int BS, class XT>
 __global__ __launch_bounds__(256) void k_mg_restrict0(GridDev g1, int nbx, int nby, const int32_t* __restrict__ cell_ptr,
                                                        const int32_t* __restrict__ cell_nodes,
                                                        const double* __restrict__ wgt, const XT* __restrict__ res,
                                                        double* __restrict__ r1) {
-  constexpr int BS = D, NC = 1 << D, LPC = GL_WAVE / NC;   // lanes per cell
+  constexpr int NC = 1 << D, LPC = GL_WAVE / NC;   // lanes per cell
   // Grid nodes are dealt to the waves in BRICKS of 4^3 (8^2) nodes = 16 blocks, four bricks in a row per XCD chunk: the
   // 2^D grid nodes around a cell all read its children, and with the nodes in plain x-fastest order those eight reads
   // came from eight different L2s (PMC: 296 MB per launch at 1 M mesh nodes for 50 MB of operands).
@@ -645,12 +646,11 @@ __global__ __launch_bounds__(256) void k_mg_restrict0(GridDev g1, int nbx, int n
 }
 
 // prolongation grid -> mesh, into the scaled level-0 variables: x~_i = x~_i + F_i S_i^-1 sum_{parents} w e_J
-template <int D, class XT>
+template <int D, int BS, class XT>
 __global__ void k_mg_prolong0(GridDev g1, int64_t n_own, const int32_t* __restrict__ cell0,
                               const double* __restrict__ wgt, const uint8_t* __restrict__ fixed,
                               const double* __restrict__ sc, const double* __restrict__ e1,
                               const XT* __restrict__ xin, XT* __restrict__ xout) {
-  constexpr int BS = D;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_own) return;
   int cv[3];
@@ -681,13 +681,12 @@ __global__ void k_mg_prolong0(GridDev g1, int64_t n_own, const int32_t* __restri
   XNode<BS, XT>::store(xout, i, xv);
 }
 
-template <int D>
+template <int D, int BS>
 __global__ __launch_bounds__(256) void k_mg_restrict(GridDev gf, GridDev gc, Fac fc, const double* __restrict__ res,
                                                       double* __restrict__ rc, const double* __restrict__ dinv_c,
                                                       double* __restrict__ d_c, double* __restrict__ x_c, double c2) {
   // one wave per coarse node, its (up to) 3^D children dealt to the lanes, fixed shuffle tree.  With dinv_c the first
   // smoothing step of the coarse level (from a zero iterate: d = x = c2 Dinv r, k_mg_first_cart) rides along.
-  constexpr int BS = D;
   const long long I = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (I >= gc.nn) return;
   const int lane = threadIdx.x & 63;
@@ -741,11 +740,10 @@ __global__ __launch_bounds__(256) void k_mg_restrict(GridDev gf, GridDev gc, Fac
 }
 
 // isc (fine level in scaled variables): x~ += (P e) / s
-template <int D>
+template <int D, int BS>
 __global__ void k_mg_prolong(GridDev gf, GridDev gc, Fac fc, const double* __restrict__ ec,
                              const double* __restrict__ xin, double* __restrict__ xout,
                              const double* __restrict__ isc) {
-  constexpr int BS = D;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= gf.nn) return;
   int iv[3];
@@ -829,10 +827,10 @@ __global__ void k_mg_scale(int64_t n, double* __restrict__ x, double s) {
 
 // A level enters symmetrically scaled variables (MgLevel::half): s = 1 / sqrt(a_ii) per dof (1 where the level's
 // operator has no stiffness), Dinv <- S^-1 Dinv S^-1 = inverse diagonal blocks of S A S ...
-template <int D>
+template <int D, int BS>
 __global__ void k_mg_level_scale(GridDev g, int S, const float* __restrict__ A, double* __restrict__ sc,
                                  double* __restrict__ dinv) {
-  constexpr int BS = D, B2 = D * D;
+  constexpr int B2 = BS * BS;
   const long long I = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (I >= g.nn) return;
   const int ctr = S / 2;
@@ -850,10 +848,10 @@ __global__ void k_mg_level_scale(GridDev g, int S, const float* __restrict__ A, 
 }
 // ... and its operator becomes the half-precision copy of S A S (entries <= 1 in magnitude: no overflow, and whatever
 // falls below the half-precision range is 1e-5 of a diagonal entry).  One thread per (node, stencil offset).
-template <int D>
+template <int D, int BS>
 __global__ void k_mg_half_copy(GridDev g, int R, int S, const float* __restrict__ A, const double* __restrict__ sc,
                                _Float16* __restrict__ A16) {
-  constexpr int BS = D, B2 = D * D;
+  constexpr int B2 = BS * BS;
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= g.nn * S) return;
   const int off = (int)(t / g.nn);
@@ -998,11 +996,11 @@ namespace {
 // grids (<= 60 k nodes with 27-point stencils -- 26^3: -2.4 % per solve against a thread per node, 8 / 16 lanes the same,
 // on 51^3 a thread per node is faster -- and every larger grid with 125-point stencils: 1 M-point Delaunay mesh 133.5 ->
 // 126.7 ms per solve), a thread per node otherwise.  `osc`: see k_mg_cart (levels with MgLevel::half only).
-template <int D>
-void mg_apply_cart(glims_ctx* h, MgLevel& L, int R, int mode, const double* xin, const double* r, double* d,
+template <int D, int BS>
+void mg_apply_cart(glims_ctx* h, MgHierarchy& mg, MgLevel& L, int R, int mode, const double* xin, const double* r, double* d,
                    double* xout, double c1, double c2, const int* done = nullptr, const double* osc = nullptr) {
   const GridDev g = gdev(L.g);
-  const int S = h->mg.S;
+  const int S = mg.S;
   GL_REQUIRE(!(L.half && mode == 2), "internal: the single-precision planes of this level are gone");   // (power iteration: before)
   const bool half = L.half;
   const _Float16* A16 = (const _Float16*)L.A16.p;
@@ -1010,11 +1008,11 @@ void mg_apply_cart(glims_ctx* h, MgLevel& L, int R, int mode, const double* xin,
     GL_REQUIRE(!half, "internal: half-precision operator on a small grid");
     const unsigned gw = gridn(g.nn, 4);
     if (mode == 0)
-      hipLaunchKernelGGL((k_mg_cart_w<D, 0>), dim3(gw), dim3(256), 0, h->st, g, R, S, L.A.p, L.dinv.p, xin, r, d, xout, c1, c2, done);
+      hipLaunchKernelGGL((k_mg_cart_w<D, BS, 0>), dim3(gw), dim3(256), 0, h->st, g, R, S, L.A.p, L.dinv.p, xin, r, d, xout, c1, c2, done);
     else if (mode == 1)
-      hipLaunchKernelGGL((k_mg_cart_w<D, 1>), dim3(gw), dim3(256), 0, h->st, g, R, S, L.A.p, L.dinv.p, xin, r, d, xout, c1, c2, done);
+      hipLaunchKernelGGL((k_mg_cart_w<D, BS, 1>), dim3(gw), dim3(256), 0, h->st, g, R, S, L.A.p, L.dinv.p, xin, r, d, xout, c1, c2, done);
     else
-      hipLaunchKernelGGL((k_mg_cart_w<D, 2>), dim3(gw), dim3(256), 0, h->st, g, R, S, L.A.p, L.dinv.p, xin, r, d, xout, c1, c2, done);
+      hipLaunchKernelGGL((k_mg_cart_w<D, BS, 2>), dim3(gw), dim3(256), 0, h->st, g, R, S, L.A.p, L.dinv.p, xin, r, d, xout, c1, c2, done);
     GL_HIP(hipGetLastError());
     return;
   }
@@ -1023,16 +1021,16 @@ void mg_apply_cart(glims_ctx* h, MgLevel& L, int R, int mode, const double* xin,
 #define GL_CART(MODE)                                                                                                 \
   do {                                                                                                               \
     if (lanes && half)                                                                                               \
-      hipLaunchKernelGGL((k_mg_cart_g<D, MODE, 4, _Float16>), dim3(grid), dim3(256), 0, h->st, g, R, S, A16, L.dinv.p, \
+      hipLaunchKernelGGL((k_mg_cart_g<D, BS, MODE, 4, _Float16>), dim3(grid), dim3(256), 0, h->st, g, R, S, A16, L.dinv.p, \
                          xin, r, d, xout, c1, c2, done, osc);                                                        \
     else if (lanes)                                                                                                  \
-      hipLaunchKernelGGL((k_mg_cart_g<D, MODE, 4, float>), dim3(grid), dim3(256), 0, h->st, g, R, S, L.A.p, L.dinv.p, \
+      hipLaunchKernelGGL((k_mg_cart_g<D, BS, MODE, 4, float>), dim3(grid), dim3(256), 0, h->st, g, R, S, L.A.p, L.dinv.p, \
                          xin, r, d, xout, c1, c2, done, osc);                                                        \
     else if (half)                                                                                                   \
-      hipLaunchKernelGGL((k_mg_cart<D, MODE, _Float16>), dim3(grid), dim3(256), 0, h->st, g, R, A16, L.dinv.p, xin, r, \
+      hipLaunchKernelGGL((k_mg_cart<D, BS, MODE, _Float16>), dim3(grid), dim3(256), 0, h->st, g, R, A16, L.dinv.p, xin, r, \
                          d, xout, c1, c2, done, osc);                                                                \
     else                                                                                                             \
-      hipLaunchKernelGGL((k_mg_cart<D, MODE, float>), dim3(grid), dim3(256), 0, h->st, g, R, L.A.p, L.dinv.p, xin, r,  \
+      hipLaunchKernelGGL((k_mg_cart<D, BS, MODE, float>), dim3(grid), dim3(256), 0, h->st, g, R, L.A.p, L.dinv.p, xin, r,  \
                          d, xout, c1, c2, done, osc);                                                                \
   } while (0)
   if (mode == 0) GL_CART(0); else if (mode == 1) GL_CART(1); else GL_CART(2);
@@ -1080,10 +1078,9 @@ bool dense_spd_inverse_device(glims_ctx* h, double* A, int n, double* col, int* 
   return hb == 0;
 }
 
-template <int D>
-void mg_setup_t(glims_ctx* h) {
-  constexpr int BS = D, B2 = D * D;
-  MgHierarchy& mg = h->mg;
+template <int D, int BS>
+void mg_setup_t(glims_ctx* h, MgHierarchy& mg) {
+  constexpr int B2 = BS * BS;
   const MeshMetrics& mm = h->mm;
   const DevPattern& p = h->pat;
   const int64_t n = h->n_own;
@@ -1098,9 +1095,9 @@ void mg_setup_t(glims_ctx* h) {
     t_last = t;
   };
   mg.clear();
-  GL_REQUIRE(h->vKel.n != 0, "multigrid set-up before the elasticity operator was assembled");
+  GL_REQUIRE(mg.op_vals && mg.op_dinv && mg.bs == BS, "multigrid set-up without an operator");
   GL_REQUIRE(!mm.xyz.empty(), "mesh metrics missing");
-  const uint8_t* fx = h->have_fixed_u ? h->fixed_u.p : nullptr;
+  const uint8_t* fx = mg.op_fixed;
   const double hf = h->opt.mg_h_factor > 0.5 ? h->opt.mg_h_factor : 2.0;
   const int coarse_max = std::max(8, h->opt.mg_coarse_nodes);
 
@@ -1150,6 +1147,7 @@ void mg_setup_t(glims_ctx* h) {
   std::vector<int32_t> cell0(n_all);
   std::vector<int32_t> cgl((size_t)n_all * D);           // global cell index per node and axis
   std::vector<double> wgt((size_t)n_all * D);
+  int S_try = D == 3 ? 27 : 9, widenings = 0;
   for (int attempt = 0;; ++attempt) {
     for (int a = 0; a < D; ++a) {
       const int cells = std::max(1, (int)std::ceil((fhi[a] - flo[a]) / H[a] - 1e-9));
@@ -1160,9 +1158,14 @@ void mg_setup_t(glims_ctx* h) {
     if (framed) {   // replicated grids must fit: widen the spacing (the same decision on every rank: global numbers only)
       double nng = 1.0;
       for (int a = 0; a < D; ++a) nng *= ng1[a];
-      if (nng > (double)GL_MG_GLOBAL_NODES && attempt < 6) {
-        const double fac = 1.02 * std::pow(nng / (double)GL_MG_GLOBAL_NODES, 1.0 / D);
+      // the cap is a byte budget of the replicated first-grid operator: S_try = stencil entries assumed so far (27-point
+      // until a pass of k_mg_reach has asked for the 125-point stencil)
+      const double cap = (double)GL_MG_GLOBAL_BYTES / ((double)S_try * B2 * sizeof(float));
+      if (nng > cap && widenings < 8) {
+        const double fac = 1.02 * std::pow(nng / cap, 1.0 / D);
         for (int a = 0; a < D; ++a) H[a] *= fac;
+        ++widenings;
+        --attempt;   // not one of the (two) widenings for edges that reach too far
         continue;
       }
     }
@@ -1229,6 +1232,12 @@ void mg_setup_t(glims_ctx* h) {
     mg.dropped_fraction = fl[0] > 0.0 ? fl[2] / fl[0] : 0.0;
     if (mg.dropped_fraction <= 0.02 || attempt >= 2) {
       mg.R = fl[1] > 0.0 ? 2 : 1;
+      const int S_need = D == 3 ? (mg.R == 2 ? 125 : 27) : (mg.R == 2 ? 25 : 9);
+      if (framed && S_need > S_try) {   // the budget above was checked for the compact stencil: once more for the wide one
+        S_try = S_need;
+        --attempt;
+        continue;
+      }
       break;
     }
     for (int a = 0; a < D; ++a) H[a] *= 1.5;
@@ -1291,11 +1300,15 @@ void mg_setup_t(glims_ctx* h) {
   // replicate a level: sum of the ranks' partial operators (single precision planes summed in double)
   auto allreduce_operator = [&](MgLevel* L) {
     const size_t ne = (size_t)mg.S * B2 * L->g.nn;
+    const size_t piece = std::min<size_t>(ne, (size_t)64 << 20);   // bounded staging buffer (512 MB of doubles at most)
     dvec<double> tmp;
-    tmp.alloc(ne);
-    hipLaunchKernelGGL(k_mg_f2d, dim3(gridn((long long)ne)), dim3(256), 0, h->st, (int64_t)ne, L->A.p, tmp.p);
-    gl_allreduce_bulk(h, tmp.p, ne);
-    hipLaunchKernelGGL(k_mg_d2f, dim3(gridn((long long)ne)), dim3(256), 0, h->st, (int64_t)ne, tmp.p, L->A.p);
+    tmp.alloc(piece);
+    for (size_t o = 0; o < ne; o += piece) {
+      const size_t m = std::min(piece, ne - o);
+      hipLaunchKernelGGL(k_mg_f2d, dim3(gridn((long long)m)), dim3(256), 0, h->st, (int64_t)m, L->A.p + o, tmp.p);
+      gl_allreduce_bulk(h, tmp.p, m);
+      hipLaunchKernelGGL(k_mg_d2f, dim3(gridn((long long)m)), dim3(256), 0, h->st, (int64_t)m, tmp.p, L->A.p + o);
+    }
     GL_HIP(hipGetLastError());
     GL_HIP(hipStreamSynchronize(h->st));
   };
@@ -1303,9 +1316,9 @@ void mg_setup_t(glims_ctx* h) {
   MgLevel* L1 = new_level(g1, o1, ng1, g1_global);
   constexpr int BW0 = D == 3 ? 4 : 8;   // bricks of k_mg_rap0
   const int nbx0 = (g1.n[0] + BW0 - 1) / BW0, nby0 = (g1.n[1] + BW0 - 1) / BW0, nbz0 = D == 3 ? (g1.n[2] + BW0 - 1) / BW0 : 1;
-  hipLaunchKernelGGL(k_mg_rap0<D>, dim3(gridn((long long)nbx0 * nby0 * nbz0 * 64 * mg.S)), dim3(256), 0, h->st, gdev(g1),
+  hipLaunchKernelGGL((k_mg_rap0<D, BS>), dim3(gridn((long long)nbx0 * nby0 * nbz0 * 64 * mg.S)), dim3(256), 0, h->st, gdev(g1),
                      nbx0, nby0, mg.R, mg.S, n,
-                     n_all, mg.cell_ptr.p, mg.cell_nodes.p, mg.cell0.p, mg.wgt.p, p.slice_ptr.p, p.cols.p, h->vKel.p,
+                     n_all, mg.cell_ptr.p, mg.cell_nodes.p, mg.cell0.p, mg.wgt.p, p.slice_ptr.p, p.cols.p, mg.op_vals,
                      fxr, L1->A.p);
   GL_HIP(hipGetLastError());
   if (g1_global) allreduce_operator(L1);
@@ -1344,27 +1357,28 @@ void mg_setup_t(glims_ctx* h) {
     MgLevel* Lc = new_level(gc, oc, ngc, glob);
     Lf = mg.lv[mg.lv.size() - 2];
     Fac fc{{Lf->f[0], Lf->f[1], Lf->f[2]}, {Lf->o[0], Lf->o[1], Lf->o[2]}, {oc[0], oc[1], oc[2]}};
-    hipLaunchKernelGGL(k_mg_rap<D>, dim3(gridn((long long)gc.nn * mg.S)), dim3(256), 0, h->st, gdev(Lf->g), gdev(gc),
+    hipLaunchKernelGGL((k_mg_rap<D, BS>), dim3(gridn((long long)gc.nn * mg.S)), dim3(256), 0, h->st, gdev(Lf->g), gdev(gc),
                        fc, mg.R, mg.S, Lf->A.p, Lc->A.p);
     GL_HIP(hipGetLastError());
     if (glob && !Lf->global) allreduce_operator(Lc);   // first replicated level: sum of the ranks' parts
     mg.entries += (int64_t)mg.S * B2 * gc.nn;
   }
   for (MgLevel* L : mg.lv) {
-    hipLaunchKernelGGL(k_mg_dinv<D>, dim3(gridn(L->g.nn)), dim3(256), 0, h->st, gdev(L->g), mg.S, L->A.p, L->dinv.p);
+    hipLaunchKernelGGL((k_mg_dinv<D, BS>), dim3(gridn(L->g.nn)), dim3(256), 0, h->st, gdev(L->g), mg.S, L->A.p, L->dinv.p);
     GL_HIP(hipGetLastError());
   }
 
   lap("Galerkin products, diagonal inverses");
   // ---- lambda_max(Dinv A) per smoothed level: power iteration -----------------------------------------------------
-  gl_block_dinv(h);
   // measured (tools/run_c5.py, degree 3): config C5 (lattice) 13.0 ms per solve with lmax / 30 against 16.6 with lmax / 10
   // and 18.7 with lmax / 4; 1 M-point Delaunay mesh 75 ms with lmax / 10 against 83 with lmax / 30
+  mg.lattice = lattice;
   mg.cheb_ratio = h->opt.mg_cheb_ratio > 1.0 ? h->opt.mg_cheb_ratio : (lattice ? 30.0 : 10.0);
   mg.exact_level0 = framed;
-  mg.x32 = (h->opt.flags & GLIMS_FLAG_MG_FP64_VECTORS) == 0;
+  // (scalar hierarchy of a partitioned run: a float is half a double, the halo exchange moves whole doubles)
+  mg.x32 = (h->opt.flags & GLIMS_FLAG_MG_FP64_VECTORS) == 0 && !(BS == 1 && framed);
   mg.half_smoother = (h->opt.flags & GLIMS_FLAG_MG_FP32_SMOOTHER) == 0;
-  gl_make_smoother_copy(h, mg.half_smoother, mg.exact_level0);
+  gl_make_smoother_copy(h, mg, mg.half_smoother, mg.exact_level0);
   mg.rs.alloc_zero(nd0, h->st);
   const int pit = 25;   // 12 under-estimate lambda_max on meshes with slivers (localised top modes); a pass costs 0.1 ms
   {
@@ -1373,7 +1387,7 @@ void mg_setup_t(glims_ctx* h) {
     double lam = 1.0;
     for (int it = 0; it < pit; ++it) {
       if (mg.exact_level0) gl_halo_exchange(h, mg.x.p, BS);
-      gl_launch_mg_fine(h, 2, mg.x.p, nullptr, nullptr, mg.x2.p, 0.0, 0.0);
+      gl_launch_mg_fine(h, mg, 2, mg.x.p, nullptr, nullptr, mg.x2.p, 0.0, 0.0);
       // = |Dinv A x| / |x| once x is normalised (it > 0); one global value in the distributed-exact mode, so that
       // every rank smooths with the same polynomial
       lam = std::sqrt(gl_dot(h, mg.x2.p, mg.x2.p, nd, mg.exact_level0));
@@ -1391,7 +1405,7 @@ void mg_setup_t(glims_ctx* h) {
     hipLaunchKernelGGL(k_mg_fill, dim3(gridn(nd)), dim3(256), 0, h->st, nd, L.x.p, (const uint8_t*)nullptr);
     double lam = 1.0;
     for (int it = 0; it < pit; ++it) {
-      mg_apply_cart<D>(h, L, mg.R, 2, L.x.p, nullptr, nullptr, L.x2.p, 0.0, 0.0);
+      mg_apply_cart<D, BS>(h, mg, L, mg.R, 2, L.x.p, nullptr, nullptr, L.x2.p, 0.0, 0.0);
       lam = std::sqrt(gl_dot(h, L.x2.p, L.x2.p, nd, false));
       if (!(lam > 0.0) || !std::isfinite(lam)) break;
       hipLaunchKernelGGL(k_mg_scale, dim3(gridn(nd)), dim3(256), 0, h->st, nd, L.x2.p, 1.0 / lam);
@@ -1408,8 +1422,8 @@ void mg_setup_t(glims_ctx* h) {
     const GridDev g = gdev(L.g);
     L.sc.alloc((size_t)BS * L.g.nn);
     L.A16.alloc((size_t)mg.S * B2 * L.g.nn);
-    hipLaunchKernelGGL(k_mg_level_scale<D>, dim3(gridn(g.nn)), dim3(256), 0, h->st, g, mg.S, L.A.p, L.sc.p, L.dinv.p);
-    hipLaunchKernelGGL(k_mg_half_copy<D>, dim3(gridn((long long)g.nn * mg.S)), dim3(256), 0, h->st, g, mg.R, mg.S, L.A.p,
+    hipLaunchKernelGGL((k_mg_level_scale<D, BS>), dim3(gridn(g.nn)), dim3(256), 0, h->st, g, mg.S, L.A.p, L.sc.p, L.dinv.p);
+    hipLaunchKernelGGL((k_mg_half_copy<D, BS>), dim3(gridn((long long)g.nn * mg.S)), dim3(256), 0, h->st, g, mg.R, mg.S, L.A.p,
                        L.sc.p, (_Float16*)L.A16.p);
     GL_HIP(hipGetLastError());
     GL_HIP(hipStreamSynchronize(h->st));
@@ -1471,16 +1485,16 @@ void mg_setup_t(glims_ctx* h) {
   }
   lap("coarsest level: dense inverse");
   mg.ready = true;
-  h->stats.mg_levels = (int64_t)mg.lv.size() + 1;
-  h->stats.mg_complexity = 1.0 + (double)mg.entries / ((double)p.total_entries * B2);
-  h->stats.ms_mg_setup = 1e3 * (omp_get_wtime() - t_start);
+  mg.n_levels = (int)mg.lv.size() + 1;
+  mg.complexity = 1.0 + (double)mg.entries / ((double)p.total_entries * B2);
+  mg.ms_setup = 1e3 * (omp_get_wtime() - t_start);
   if (getenv("GLIMS_VERBOSE")) {
-    fprintf(stderr, "glims multigrid: %s mesh, H = (%.4g, %.4g, %.4g), stencil radius %d (%.3f %% of the entries reach further and stay on level 0), levels:",
-            lattice ? "lattice" : "general", mg.H[0], mg.H[1], D == 3 ? mg.H[2] : 0.0, mg.R, 100.0 * mg.dropped_fraction);
+    fprintf(stderr, "glims multigrid (%d dof / node): %s mesh, H = (%.4g, %.4g, %.4g), stencil radius %d (%.3f %% of the entries reach further and stay on level 0), levels:",
+            BS, lattice ? "lattice" : "general", mg.H[0], mg.H[1], D == 3 ? mg.H[2] : 0.0, mg.R, 100.0 * mg.dropped_fraction);
     fprintf(stderr, " mesh(%lld nodes, lam %.2f)", (long long)n, mg.lam0);
     for (MgLevel* L : mg.lv)
       fprintf(stderr, " %dx%dx%d%s(lam %.2f)", L->g.n[0], L->g.n[1], L->g.n[2], L->global ? "[replicated]" : "", L->lam);
-    fprintf(stderr, "; operator complexity %.2f; set-up %.1f ms\n", h->stats.mg_complexity, h->stats.ms_mg_setup);
+    fprintf(stderr, "; operator complexity %.2f; set-up %.1f ms\n", mg.complexity, mg.ms_setup);
   }
 }
 
@@ -1496,10 +1510,8 @@ inline double mg_fused_first_c2(const MgHierarchy& mg, size_t l, bool allreduce_
 }
 
 // `first_done`: the restriction that produced L.r has taken the first smoothing step as well (L.d, L.x are set)
-template <int D>
-void mg_cycle_cart(glims_ctx* h, size_t l, const int* done, bool first_done) {
-  constexpr int BS = D;
-  MgHierarchy& mg = h->mg;
+template <int D, int BS>
+void mg_cycle_cart(glims_ctx* h, MgHierarchy& mg, int deg, size_t l, const int* done, bool first_done) {
   MgLevel& L = *mg.lv[l];
   const GridDev g = gdev(L.g);
   if (l + 1 == mg.lv.size()) {
@@ -1508,50 +1520,50 @@ void mg_cycle_cart(glims_ctx* h, size_t l, const int* done, bool first_done) {
     GL_HIP(hipGetLastError());
     return;
   }
-  const int deg = std::max(1, std::min(8, h->opt.mg_smooth));
   Cheb ch(L.lam, mg.cheb_ratio);
   double c1, c2;
   ch.next(0, &c1, &c2);
   const double* sc = L.half ? L.sc.p : nullptr;   // this level works in scaled variables between first_cart and its last pass
   GL_REQUIRE(!(first_done && L.half), "internal: fused first step on a level with scaled variables");
   if (!first_done)
-    hipLaunchKernelGGL(k_mg_first_cart<D>, dim3(gridn(g.nn)), dim3(256), 0, h->st, g, L.dinv.p, L.r.p, L.d.p, L.x.p, c2, sc);
+    hipLaunchKernelGGL((k_mg_first_cart<D, BS>), dim3(gridn(g.nn)), dim3(256), 0, h->st, g, L.dinv.p, L.r.p, L.d.p, L.x.p, c2, sc);
   double *xa = L.x.p, *xb = L.x2.p;
   for (int m = 1; m < deg; ++m) {
     ch.next(m, &c1, &c2);
-    mg_apply_cart<D>(h, L, mg.R, 1, xa, L.r.p, L.d.p, xb, c1, c2, done);
+    mg_apply_cart<D, BS>(h, mg, L, mg.R, 1, xa, L.r.p, L.d.p, xb, c1, c2, done);
     std::swap(xa, xb);
   }
-  mg_apply_cart<D>(h, L, mg.R, 0, xa, L.r.p, nullptr, L.res.p, 0.0, 0.0, done, sc);
+  mg_apply_cart<D, BS>(h, mg, L, mg.R, 0, xa, L.r.p, nullptr, L.res.p, 0.0, 0.0, done, sc);
   MgLevel& C = *mg.lv[l + 1];
   const Fac fc{{L.f[0], L.f[1], L.f[2]}, {L.o[0], L.o[1], L.o[2]}, {C.o[0], C.o[1], C.o[2]}};
   const bool reduce_c = C.global && !L.global && h->world > 1;
   const double c2c = mg_fused_first_c2(mg, l + 1, reduce_c);
-  hipLaunchKernelGGL(k_mg_restrict<D>, dim3(gridn(C.g.nn, 4)), dim3(256), 0, h->st, g, gdev(C.g), fc, L.res.p, C.r.p,
+  hipLaunchKernelGGL((k_mg_restrict<D, BS>), dim3(gridn(C.g.nn, 4)), dim3(256), 0, h->st, g, gdev(C.g), fc, L.res.p, C.r.p,
                      c2c != 0.0 ? C.dinv.p : nullptr, C.d.p, C.x.p, c2c);
   GL_HIP(hipGetLastError());
   // first replicated level of a partitioned run: every rank has restricted the residual of its own rows -> sum
   if (reduce_c) gl_allreduce_bulk(h, C.r.p, (size_t)BS * C.g.nn);
-  mg_cycle_cart<D>(h, l + 1, done, c2c != 0.0);
-  hipLaunchKernelGGL(k_mg_prolong<D>, dim3(gridn(g.nn)), dim3(256), 0, h->st, g, gdev(C.g), fc, C.x.p, xa, xb, sc);
+  mg_cycle_cart<D, BS>(h, mg, deg, l + 1, done, c2c != 0.0);
+  hipLaunchKernelGGL((k_mg_prolong<D, BS>), dim3(gridn(g.nn)), dim3(256), 0, h->st, g, gdev(C.g), fc, C.x.p, xa, xb, sc);
   GL_HIP(hipGetLastError());
   std::swap(xa, xb);
   Cheb cp(L.lam, mg.cheb_ratio);
   for (int m = 0; m < deg; ++m) {
     cp.next(m, &c1, &c2);
-    mg_apply_cart<D>(h, L, mg.R, 1, xa, L.r.p, L.d.p, xb, c1, c2, done, m == deg - 1 ? sc : nullptr);
+    mg_apply_cart<D, BS>(h, mg, L, mg.R, 1, xa, L.r.p, L.d.p, xb, c1, c2, done, m == deg - 1 ? sc : nullptr);
     std::swap(xa, xb);
   }
   if (xa != L.x.p) std::swap(L.x.p, L.x2.p);   // the result is always handed up in L.x
 }
 
-template <int D>
-void mg_apply_t(glims_ctx* h, const double* r, double* u, const int* done) {
-  constexpr int BS = D;
-  MgHierarchy& mg = h->mg;
+template <int D, int BS>
+void mg_apply_t(glims_ctx* h, MgHierarchy& mg, int deg, const double* r, double* u, const int* done) {
   const int64_t n = h->n_own;
-  const uint8_t* fx = h->have_fixed_u ? h->fixed_u.p : nullptr;
-  const int deg = std::max(1, std::min(8, h->opt.mg_smooth));
+  const uint8_t* fx = mg.op_fixed;
+  // the smoothers' interval follows the options of the moment (no rebuild: the eigenvalue estimates do not depend on it)
+  // (defaults, measured: elasticity 30 on lattice meshes / 10 on general ones with degree 3; the scalar RD hierarchy 10
+  // with degree 1 -- tools/run_rd_precond.py)
+  mg.cheb_ratio = h->opt.mg_cheb_ratio > 1.0 ? h->opt.mg_cheb_ratio : (mg.bs == 1 ? 10.0 : mg.lattice ? 30.0 : 10.0);
   Cheb ch(mg.lam0, mg.cheb_ratio);
   double c1, c2;
   ch.next(0, &c1, &c2);
@@ -1569,11 +1581,11 @@ void mg_apply_t(glims_ctx* h, const double* r, double* u, const int* done) {
   for (int m = 1; m < deg; ++m) {
     ch.next(m, &c1, &c2);
     if (ex) gl_halo_exchange(h, xa, xrec);
-    gl_launch_mg_fine(h, 1, xa, r, mg.d.p, xb, c1, c2, done);
+    gl_launch_mg_fine(h, mg, 1, xa, r, mg.d.p, xb, c1, c2, done);
     std::swap(xa, xb);
   }
   if (ex) gl_halo_exchange(h, xa, xrec);
-  gl_launch_mg_fine(h, 0, xa, r, nullptr, mg.res.p, 0.0, 0.0, done);
+  gl_launch_mg_fine(h, mg, 0, xa, r, nullptr, mg.res.p, 0.0, 0.0, done);
   MgLevel& L1 = *mg.lv[0];
   const GridDev g1 = gdev(L1.g);
   // (the first smoothing step of the grid level is NOT fused into this restriction as it is between the Cartesian levels:
@@ -1582,19 +1594,19 @@ void mg_apply_t(glims_ctx* h, const double* r, double* u, const int* done) {
   const int nbx = (g1.n0 + BW - 1) / BW, nby = (g1.n1 + BW - 1) / BW, nbz = D == 3 ? (g1.n2 + BW - 1) / BW : 1;
   const unsigned gr0 = (unsigned)((long long)nbx * nby * nbz * 16);
   if (x32)
-    hipLaunchKernelGGL((k_mg_restrict0<D, float>), dim3(gr0), dim3(256), 0, h->st, g1, nbx, nby, mg.cell_ptr.p,
+    hipLaunchKernelGGL((k_mg_restrict0<D, BS, float>), dim3(gr0), dim3(256), 0, h->st, g1, nbx, nby, mg.cell_ptr.p,
                        mg.cell_nodes.p, mg.wgt.p, (const float*)mg.res.p, L1.r.p);
   else
-    hipLaunchKernelGGL((k_mg_restrict0<D, double>), dim3(gr0), dim3(256), 0, h->st, g1, nbx, nby, mg.cell_ptr.p,
+    hipLaunchKernelGGL((k_mg_restrict0<D, BS, double>), dim3(gr0), dim3(256), 0, h->st, g1, nbx, nby, mg.cell_ptr.p,
                        mg.cell_nodes.p, mg.wgt.p, (const double*)mg.res.p, L1.r.p);
   GL_HIP(hipGetLastError());
   if (L1.global) gl_allreduce_bulk(h, L1.r.p, (size_t)BS * L1.g.nn);
-  mg_cycle_cart<D>(h, 0, done, false);
+  mg_cycle_cart<D, BS>(h, mg, deg, 0, done, false);
   if (x32)
-    hipLaunchKernelGGL((k_mg_prolong0<D, float>), dim3(gridn(n)), dim3(256), 0, h->st, g1, n, mg.cell0.p, mg.wgt.p, fx,
+    hipLaunchKernelGGL((k_mg_prolong0<D, BS, float>), dim3(gridn(n)), dim3(256), 0, h->st, g1, n, mg.cell0.p, mg.wgt.p, fx,
                        mg.sc.p, L1.x.p, (const float*)xa, (float*)xb);
   else
-    hipLaunchKernelGGL((k_mg_prolong0<D, double>), dim3(gridn(n)), dim3(256), 0, h->st, g1, n, mg.cell0.p, mg.wgt.p, fx,
+    hipLaunchKernelGGL((k_mg_prolong0<D, BS, double>), dim3(gridn(n)), dim3(256), 0, h->st, g1, n, mg.cell0.p, mg.wgt.p, fx,
                        mg.sc.p, L1.x.p, (const double*)xa, xb);
   GL_HIP(hipGetLastError());
   std::swap(xa, xb);
@@ -1603,21 +1615,33 @@ void mg_apply_t(glims_ctx* h, const double* r, double* u, const int* done) {
     cp.next(m, &c1, &c2);
     // the last step leaves the scaled variables and writes the preconditioned residual where the solver wants it
     if (ex) gl_halo_exchange(h, xa, xrec);
-    gl_launch_mg_fine(h, 1, xa, r, mg.d.p, xb, c1, c2, done, m == deg - 1 ? u : nullptr);
+    gl_launch_mg_fine(h, mg, 1, xa, r, mg.d.p, xb, c1, c2, done, m == deg - 1 ? u : nullptr);
     std::swap(xa, xb);
   }
-  h->stats.mg_cycles++;
+  mg.cycles++;
 }
 
 }  // namespace
 
-void gl_mg_setup(glims_ctx* h) {
-  if (h->dim == 2) mg_setup_t<2>(h);
-  else mg_setup_t<3>(h);
+void gl_mg_setup(glims_ctx* h, MgHierarchy& mg) {
+  GL_REQUIRE(mg.bs == 1 || mg.bs == h->dim, "multigrid: block size must be 1 or the dimension");
+  if (h->dim == 2) {
+    if (mg.bs == 1) mg_setup_t<2, 1>(h, mg);
+    else mg_setup_t<2, 2>(h, mg);
+  } else {
+    if (mg.bs == 1) mg_setup_t<3, 1>(h, mg);
+    else mg_setup_t<3, 3>(h, mg);
+  }
 }
 
-void gl_mg_apply(glims_ctx* h, const double* r, double* u, const int* done) {
-  GL_REQUIRE(h->mg.ready, "multigrid hierarchy not built");
-  if (h->dim == 2) mg_apply_t<2>(h, r, u, done);
-  else mg_apply_t<3>(h, r, u, done);
+void gl_mg_apply(glims_ctx* h, MgHierarchy& mg, int degree, const double* r, double* u, const int* done) {
+  GL_REQUIRE(mg.ready, "multigrid hierarchy not built");
+  const int deg = std::max(1, std::min(8, degree));
+  if (h->dim == 2) {
+    if (mg.bs == 1) mg_apply_t<2, 1>(h, mg, deg, r, u, done);
+    else mg_apply_t<2, 2>(h, mg, deg, r, u, done);
+  } else {
+    if (mg.bs == 1) mg_apply_t<3, 1>(h, mg, deg, r, u, done);
+    else mg_apply_t<3, 3>(h, mg, deg, r, u, done);
+  }
 }

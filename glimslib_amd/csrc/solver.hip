@@ -498,7 +498,7 @@ __global__ void k_lincomb(int64_t n, int m, const LinComb lc, double* __restrict
   y[i] = v;
 }
 
-// inverse of the (Dirichlet-modified) diagonal BS x BS blocks of K_el
+// inverse of the (Dirichlet-modified) diagonal BS x BS blocks of K_el (BS = 1: of a scalar operator plane)
 template <int BS>
 __global__ void k_block_dinv(int64_t n_own, const int64_t* __restrict__ slice_ptr, const uint8_t* __restrict__ diag_k,
                              const double* __restrict__ vKel, const uint8_t* __restrict__ fixed,
@@ -518,7 +518,9 @@ __global__ void k_block_dinv(int64_t n_own, const int64_t* __restrict__ slice_pt
       A[a][b] = x;
     }
   double* o = dinv + row * BS * BS;
-  if constexpr (BS == 2) {
+  if constexpr (BS == 1) {
+    o[0] = 1.0 / A[0][0];
+  } else if constexpr (BS == 2) {
     const double inv = 1.0 / (A[0][0] * A[1][1] - A[0][1] * A[1][0]);
     o[0] = A[1][1] * inv;
     o[1] = -A[0][1] * inv;
@@ -623,8 +625,10 @@ static void allreduce_sum(glims_ctx* h, double* dev, int n) {
 void gl_allreduce_bulk(glims_ctx* h, double* dev, size_t n) {
   if (h->world <= 1 || n == 0) return;
   if (h->tr_allreduce) {
-    const int rc = h->tr_allreduce(h->tr_user, dev, (int)n, (void*)h->st);
-    if (rc != 0) throw glims_error(GLIMS_E_RCCL, "transport allreduce callback failed (" + std::to_string(rc) + ")");
+    for (size_t o = 0; o < n; o += (size_t)1 << 28) {   // the callback counts in int
+      const int rc = h->tr_allreduce(h->tr_user, dev + o, (int)std::min<size_t>(n - o, (size_t)1 << 28), (void*)h->st);
+      if (rc != 0) throw glims_error(GLIMS_E_RCCL, "transport allreduce callback failed (" + std::to_string(rc) + ")");
+    }
     return;
   }
   GL_REQUIRE(h->comm_red, "world > 1 but no communicator: call glims_comm_init or glims_set_transport");
@@ -724,6 +728,91 @@ void gl_block_dinv(glims_ctx* h) {
   GL_HIP(hipGetLastError());
 }
 
+// ---- the two multigrid hierarchies (mg.hip) -------------------------------------------------------------------------
+// elasticity: K_el with dim x dim blocks, Dirichlet dofs of the displacement eliminated
+void gl_mg_setup_mech(glims_ctx* h) {
+  GL_REQUIRE(h->vKel.n != 0, "multigrid set-up before the elasticity operator was assembled");
+  gl_block_dinv(h);
+  MgHierarchy& mg = h->mg;
+  mg.bs = h->dim;
+  mg.op_vals = h->vKel.p;
+  mg.op_fixed = h->have_fixed_u ? h->fixed_u.p : nullptr;
+  mg.op_dinv = h->m_dinv.p;
+  gl_mg_setup(h, mg);
+  h->stats.mg_levels = mg.n_levels;
+  h->stats.mg_complexity = mg.complexity;
+  h->stats.ms_mg_setup = mg.ms_setup;
+}
+
+// RD block: the hierarchy is built ONCE per glims_setup on the static part S = (1 - dt rho) M + dt K_D of the Newton
+// Jacobian A(c) = S + 2 dt N(c).  N(c) is a mass-like matrix weighted with rho c: 0 <= 2 dt N(c) <= 2 dt rho c_max M, while
+// S >= (1 - dt rho) M, so the spectrum of S^-1 A(c) lies in [1, 1 + 2 dt rho c_max / (1 - dt rho)] (= [1, 1.22] for the
+// reference's dt rho = 0.1 at c = 1): a V-cycle for S preconditions every A(c) of the run as well as it preconditions S.
+// The Krylov operator is the assembled fp64 A(c) as before.
+void gl_mg_setup_rd(glims_ctx* h) {
+  GL_REQUIRE(h->vS.n != 0, "multigrid set-up before the RD operators were assembled");
+  MgHierarchy& mg = h->mg_rd;
+  const uint8_t* fx = h->have_fixed_c ? h->fixed_c.p : nullptr;
+  mg.own_dinv.alloc((size_t)h->n_own);
+  hipLaunchKernelGGL(k_block_dinv<1>, dim3(grid_exact(h->n_own)), dim3(256), 0, h->st, h->n_own, h->pat.slice_ptr.p,
+                     h->pat.diag_k.p, h->vS.p, fx, mg.own_dinv.p);
+  GL_HIP(hipGetLastError());
+  mg.bs = 1;
+  mg.op_vals = h->vS.p;
+  mg.op_fixed = fx;
+  mg.op_dinv = mg.own_dinv.p;
+  gl_mg_setup(h, mg);
+  h->stats.rd_mg_levels = mg.n_levels;
+  h->stats.rd_mg_complexity = mg.complexity;
+  h->stats.ms_rd_mg_setup = mg.ms_setup;
+}
+
+// sum over the owned rows of S_ii / M_ii  (and the row count) -> partials of k_reduce, [blocks][2]
+__global__ __launch_bounds__(256) void k_diag_ratio(int64_t n_own, const int64_t* __restrict__ slice_ptr,
+                                                     const uint8_t* __restrict__ diag_k, const double* __restrict__ vS,
+                                                     const double* __restrict__ vM, double* __restrict__ pv) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double q = 0.0, cnt = 0.0;
+  for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < n_own; row += stride) {
+    const int64_t e = slice_ptr[row >> 6] + (int64_t)diag_k[row] * GL_WAVE + (row & 63);
+    q += vS[e] / vM[e];
+    cnt += 1.0;
+  }
+  block_sum2(q, cnt, pv);
+}
+
+// Which preconditioner the RD solves use.  The reference's sparse LU (simulation_tumor_growth.py:126-130) does not care
+// how stiff a step is; Jacobi-PCG does: with q = mean_i S_ii / M_ii ~ 1 + C dt D / h^2 its iteration count per Newton
+// solve grows like sqrt(2 q) (measured: 4-5 on the brain-extent configs C3 / C4 with q = 1.0-1.1, 66 / 129 on the unit
+// cube with D = 0.1, dt = 1 at n = 32 / 64).  A multigrid-preconditioned iteration costs as much as ~5 Jacobi ones where
+// the kernels are bandwidth-bound (>= ~0.5 M rows) and more where they are launch-bound, and needs 3-4 of them per solve:
+// `auto` takes the hierarchy when the predicted Jacobi count exceeds that.  The decision uses all-reduced numbers, so
+// every rank of a partitioned run takes the same one.
+void gl_rd_choose_precond(glims_ctx* h) {
+  const unsigned g = grid_for(h->n_own, 256, 1024);
+  hipLaunchKernelGGL(k_diag_ratio, dim3(g), dim3(256), 0, h->st, h->n_own, h->pat.slice_ptr.p, h->pat.diag_k.p,
+                     h->vS.p, h->vM.p, h->partials.p);
+  GL_HIP(hipGetLastError());
+  reduce_partials(h, (int)g, 2, nullptr);
+  allreduce_sum(h, h->red.p, 2);
+  double out[2];
+  read_red(h, 2, out);
+  const double rows = std::max(1.0, out[1]);
+  h->rd_stiffness_ratio = out[0] / rows;
+  const double jacobi_its = std::sqrt(2.0 * std::max(0.0, h->rd_stiffness_ratio));
+  const double break_even = rows >= 4.0e6 ? 20.0 : rows >= 4.0e5 ? 45.0 : rows >= 5.0e4 ? 75.0 : 120.0;
+  int pick = h->opt.rd_precond;
+  if (pick == GLIMS_RD_PRECOND_AUTO)
+    pick = jacobi_its > break_even ? GLIMS_RD_PRECOND_MULTIGRID : GLIMS_RD_PRECOND_JACOBI;
+  h->rd_precond_active = pick;
+  h->stats.rd_precond_used = pick;
+  h->stats.rd_stiffness_ratio = h->rd_stiffness_ratio;
+  if (getenv("GLIMS_VERBOSE"))
+    fprintf(stderr, "glims RD preconditioner: mean S_ii / M_ii = %.4g over %.0f rows -> predicted Jacobi-PCG iterations per "
+            "solve %.0f (break-even %.0f): %s\n", h->rd_stiffness_ratio, rows, jacobi_its, break_even,
+            pick == GLIMS_RD_PRECOND_MULTIGRID ? "multigrid V-cycle" : "Jacobi");
+}
+
 // c = Dirichlet value on the constrained nodes (owned and ghost alike: every rank lists the constrained nodes of its
 // whole sub-mesh), then the state-dependent caches are stale
 void gl_apply_dirichlet_c(glims_ctx* h) {
@@ -746,7 +835,8 @@ struct CgVecs {
   int bs;
   bool k32 = false;         // block operator: stream the single-precision copy of K_el
   const float* vals32 = nullptr;   // scalar operator in single precision (optional; streamed instead of vals)
-  bool mg = false;          // u = V-cycle(r) (elasticity multigrid) instead of the (block-)Jacobi scaling
+  MgHierarchy* mg = nullptr;   // u = V-cycle(r) of this hierarchy instead of the (block-)Jacobi scaling
+  int mg_degree = 3;           // Chebyshev degree of its smoothers
 };
 
 // w = A u with the fused dot product: one delta partial per SpMV block, interior launch first (slots [0, nbi)), then the
@@ -764,7 +854,7 @@ static void apply_with_halo(glims_ctx* h, const CgVecs& v) {
     return;
   }
   // interior slices overlap with the xGMI transfer; boundary slices run once the ghosts have landed
-  halo_start(h, v.u, v.bs, /*prepacked=*/!v.mg);
+  halo_start(h, v.u, v.bs, /*prepacked=*/v.mg == nullptr);
   const int nbi = p.n_interior > 0 ? gl_spmv_grid(p.n_interior) : 0;   // partial-sum slots of the interior launch
   if (v.vals)
     gl_launch_spmv(h, h->st, p.n_interior, p.interior_slices.p, v.vals, v.u, v.w, v.fixed, nullptr, v.r,
@@ -817,7 +907,7 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
   if (ext) pm = PackMap();   // the cycle's last kernel produces u: the halo payload is packed by k_pack
   auto precondition = [&]() {
     if (!ext) return;
-    gl_mg_apply(h, v.r, v.u, h->done.p);
+    gl_mg_apply(h, *v.mg, v.mg_degree, v.r, v.u, h->done.p);
     hipLaunchKernelGGL(k_dot2, dim3(g), dim3(256), 0, h->st, n * v.bs, v.r, v.u, h->partials_v.p, h->done.p);
     GL_HIP(hipGetLastError());
   };
@@ -923,6 +1013,10 @@ int gl_step(glims_ctx* h, int n_steps) {
     for (hipEvent_t& e : h->tev) GL_HIP(hipEventCreate(&e));
   }
   h->tev_used = 0;
+  if (h->rd_precond_active == 0) gl_rd_choose_precond(h);
+  const bool rd_mg = h->rd_precond_active == GLIMS_RD_PRECOND_MULTIGRID;
+  if (rd_mg && !h->mg_rd.ready) gl_mg_setup_rd(h);
+  const int64_t rd_cycles0 = h->mg_rd.cycles;
   GL_HIP(hipEventRecord(h->ev_a, h->st));
   for (int step = 0; step < n_steps && status == GLIMS_OK; ++step) {
     double norms[2] = {0.0, 0.0};
@@ -980,6 +1074,10 @@ int gl_step(glims_ctx* h, int n_steps) {
       CgVecs v{h->c.p, h->cg_r.p, h->cg_u.p, h->cg_w.p, h->cg_p.p, h->cg_s.p,
                h->dinv.p, h->vA.p, h->have_fixed_c ? h->fixed_c.p : nullptr, 1};
       if (h->jac32) v.vals32 = h->vA32.p;
+      if (rd_mg) {
+        v.mg = &h->mg_rd;
+        v.mg_degree = o.rd_mg_smooth;
+      }
       int64_t its = 0;
       double res = 0.0;
       const int slot = std::min(it, 7);
@@ -1034,6 +1132,7 @@ int gl_step(glims_ctx* h, int n_steps) {
   float ms = 0.f;
   GL_HIP(hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
   h->stats.ms_steps += ms;
+  h->stats.rd_mg_cycles += h->mg_rd.cycles - rd_cycles0;
   if (h->tev_used >= 2) {
     // launches that the decision word turned into no-ops last a few microseconds: leave them out of sums and medians
     std::vector<float> d[3];
@@ -1113,8 +1212,8 @@ int gl_solve_mechanics(glims_ctx* h, const double* c_dev) {
   // preconditioner of the constrained operator: one multigrid V-cycle (built on first use, K_el does not change in
   // time) or block-Jacobi
   const bool use_mg = h->opt.mech_precond == GLIMS_PRECOND_MULTIGRID;
-  if (use_mg && !h->mg.ready) gl_mg_setup(h);
-  else gl_block_dinv(h);
+  if (use_mg && !h->mg.ready) gl_mg_setup_mech(h);
+  else if (!use_mg) gl_block_dinv(h);
   // rhs = G c + f - K u_D, zero on constrained dofs
   gl_apply_G(h, c_dev ? c_dev : h->c.p, h->m_rhs.p);
   if (fx) {
@@ -1226,7 +1325,9 @@ int gl_solve_mechanics(glims_ctx* h, const double* c_dev) {
   hipLaunchKernelGGL(k_sub, dim3(grid_exact(nd)), dim3(256), 0, h->st, nd, h->m_r.p, h->m_rhs.p, h->m_w.p, fx);
   GL_HIP(hipGetLastError());
   CgVecs v{h->U.p, h->m_r.p, h->m_u.p, h->m_w.p, h->m_p.p, h->m_s.p, h->m_dinv.p, nullptr, fx, bs};
-  v.mg = use_mg;
+  v.mg = use_mg ? &h->mg : nullptr;
+  v.mg_degree = h->opt.mg_smooth;
+  const int64_t cycles0 = h->mg.cycles;
   int64_t its = 0;
   double res = 0.0;
   int cs = GLIMS_OK;
@@ -1239,21 +1340,43 @@ int gl_solve_mechanics(glims_ctx* h, const double* c_dev) {
   const bool big = (size_t)p.total_entries * bs * bs * sizeof(double) > ((size_t)256 << 20);
   const bool mixed = h->opt.mech_mixed == 2 || (h->opt.mech_mixed == 1 && big && !use_mg);
   if (mixed) gl_make_kel32(h);
+  auto norm_of_m_r = [&]() {
+    hipLaunchKernelGGL(k_dot_partials, dim3(gd), dim3(256), 0, h->st, nd, h->m_r.p, h->m_r.p, h->partials.p);
+    reduce_partials(h, (int)gd, 1, nullptr);
+    allreduce_sum(h, h->red.p, 1);
+    return std::sqrt(read_red0(h));
+  };
   if (!mixed) {
     cs = cg_solve(h, v, tol, h->opt.mech_maxit, h->mech_hint, &its, &res);
     h->mech_hint = (int)its;
+    // Verification pass with the fp64 operator: m_w = K U, m_r = rhs - K U.  The recurrence residual the Krylov iteration
+    // stops on drifts away from the true one by rounding, and the solve history below keeps K x_k for the next solves'
+    // initial residuals -- it must be the product itself, not "rhs minus what the recurrence believes", or the gap of one
+    // solve enters every later one through the (sign-alternating) least-squares coefficients and is never seen again.
+    // One operator pass per solve (0.23 ms of ~10 at config C5).  If the true residual misses the tolerance by more than
+    // the drift one expects, the iteration continues from it.
+    for (int round = 0; cs == GLIMS_OK; ++round) {
+      gl_halo_exchange(h, h->U.p, bs);
+      gl_launch_spmv_block(h, h->st, p.n_slices, nullptr, h->U.p, h->m_w.p, fx, nullptr, nullptr, 0, nullptr);
+      hipLaunchKernelGGL(k_sub, dim3(grid_exact(nd)), dim3(256), 0, h->st, nd, h->m_r.p, h->m_rhs.p, h->m_w.p, fx);
+      GL_HIP(hipGetLastError());
+      res = norm_of_m_r();
+      if (!std::isfinite(res)) {
+        cs = GLIMS_NAN;
+        break;
+      }
+      if (res <= 4.0 * tol || round >= 2) break;
+      int64_t more = 0;
+      double r2 = 0.0;
+      cs = cg_solve(h, v, tol, h->opt.mech_maxit, 0, &more, &r2);
+      its += more;
+    }
   } else {
     // Mixed precision: the inner PCG streams a single-precision copy of K_el (40 instead of 76 bytes per block entry;
     // products and sums in fp64) and reduces the residual by 1e-3; the outer loop recomputes the true residual with
     // the fp64 operator and repeats.  The answer converges to the fp64 tolerance like the plain solver's (iterative
     // refinement); if a cycle gains less than a factor 2 the remaining ones use the fp64 operator.
-    auto true_residual = [&]() {
-      hipLaunchKernelGGL(k_dot_partials, dim3(gd), dim3(256), 0, h->st, nd, h->m_r.p, h->m_r.p, h->partials.p);
-      reduce_partials(h, (int)gd, 1, nullptr);
-      allreduce_sum(h, h->red.p, 1);
-      return std::sqrt(read_red0(h));
-    };
-    double nr = true_residual();
+    double nr = norm_of_m_r();
     v.k32 = true;
     for (int outer = 0; outer < 12; ++outer) {
       res = nr;
@@ -1282,12 +1405,13 @@ int gl_solve_mechanics(glims_ctx* h, const double* c_dev) {
       gl_launch_spmv_block(h, h->st, p.n_slices, nullptr, h->U.p, h->m_w.p, fx, nullptr, nullptr, 0, nullptr);
       hipLaunchKernelGGL(k_sub, dim3(grid_exact(nd)), dim3(256), 0, h->st, nd, h->m_r.p, h->m_rhs.p, h->m_w.p, fx);
       GL_HIP(hipGetLastError());
-      const double nr_new = true_residual();
+      const double nr_new = norm_of_m_r();
       if (!(nr_new < 0.5 * nr)) v.k32 = false;   // single precision has given what it can
       nr = nr_new;
     }
   }
   h->stats.mech_cg_its += its;
+  h->stats.mg_cycles += h->mg.cycles - cycles0;
   h->stats.mech_solves++;
   h->stats.last_mech_res = res;
   if (cs == GLIMS_OK && mh_depth > 0) {   // remember (rhs, free-dof solution) for the next initial guess
@@ -1296,10 +1420,9 @@ int gl_solve_mechanics(glims_ctx* h, const double* c_dev) {
     h->mh_x[slot].alloc((size_t)h->n_nodes * bs);
     GL_HIP(hipMemcpyAsync(h->mh_rhs[slot].p, h->m_rhs.p, (size_t)nd * sizeof(double), hipMemcpyDeviceToDevice, h->st));
     GL_HIP(hipMemcpyAsync(h->mh_x[slot].p, h->U.p, (size_t)nd * sizeof(double), hipMemcpyDeviceToDevice, h->st));
-    // m_r = rhs - K U on the free dofs (true residual of the verification pass, or the recurrence's): K U = rhs - m_r
+    // m_w = K U on the free dofs: the product of the verification pass itself (see above), never "rhs - recurrence residual"
     h->mh_w[slot].alloc((size_t)h->n_nodes * bs);
-    hipLaunchKernelGGL(k_sub, dim3(grid_exact(nd)), dim3(256), 0, h->st, nd, h->mh_w[slot].p, h->m_rhs.p, h->m_r.p, fx);
-    GL_HIP(hipGetLastError());
+    GL_HIP(hipMemcpyAsync(h->mh_w[slot].p, h->m_w.p, (size_t)nd * sizeof(double), hipMemcpyDeviceToDevice, h->st));
     for (int l = 0; l < m_hist; ++l) h->mh_G[slot][l] = h->mh_G[l][slot] = g[l];   // g against the slots that stay
     h->mh_G[slot][slot] = nb2;
     h->mh_next = (slot + 1) % mh_depth;

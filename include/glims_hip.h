@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GLIMS_ABI_VERSION 2
+#define GLIMS_ABI_VERSION 3
 
 enum {
   GLIMS_OK = 0,
@@ -90,10 +90,28 @@ typedef struct glims_options {
   int    time_kernels;    /* HIP-event pairs on the handle's stream around hot kernels of glims_step: 1 = the Krylov
                              SpMV, 2 = also the assembly sweep and the PCG vector update; results in
                              glims_stats.*_steps / us_*_median (bench.py's in-step roofline figures)  default 0     */
+  /* ---- ABI 3: preconditioner of the RD linear solves.  The reference's LU does not care how stiff a step is
+   * (simulation_tumor_growth.py:126-130); Jacobi-PCG needs ~sqrt(2 dt D / h^2 ...) iterations per Newton solve, e.g.
+   * 66 / 129 on the unit cube with D = 0.1, dt = 1 at n = 32 / 64 (BASELINE config C2 is such a case), 4-5 on the
+   * mass-dominated brain-extent configs C3 / C4. */
+  int    rd_precond;      /* GLIMS_RD_PRECOND_AUTO | _JACOBI | _MULTIGRID.  MULTIGRID: one V-cycle of the same auxiliary-grid
+                             hierarchy as the elasticity solver's, with 1 x 1 blocks, built once per glims_setup on the
+                             static part S = (1 - dt rho) M + dt K_D of the Jacobian (S^-1 A(c) has its spectrum in
+                             [1, 1 + 2 dt rho c / (1 - dt rho)]).  AUTO decides at the first glims_step after glims_setup
+                             from q = mean_i S_ii / M_ii: multigrid when the predicted Jacobi count sqrt(2 q) exceeds the
+                             break-even (20 for >= 400 k rows, 45 for >= 50 k, 90 below); the choice and q are in
+                             glims_stats.rd_precond_used / rd_stiffness_ratio                            default AUTO  */
+  int    rd_mg_smooth;    /* Chebyshev degree of the RD hierarchy's smoothers (1 = damped Jacobi).  Measured on the unit
+                             cube with D = 0.1, dt = 1 at 0.1 / 1 / 10 M rows: degree 1 on [lambda/10, lambda] 2.6 / 5.2 /
+                             36.7 ms per step, degree 3 on [lambda/30, lambda] 2.9 / 7.4 / 46.2 (Jacobi-PCG: 4.4 / 26.5 /
+                             486); mg_cheb_ratio = 0 means 10 for this hierarchy                          default 1     */
 } glims_options;
 
 #define GLIMS_PRECOND_BLOCK_JACOBI 0
 #define GLIMS_PRECOND_MULTIGRID 1
+#define GLIMS_RD_PRECOND_AUTO 0
+#define GLIMS_RD_PRECOND_JACOBI 1
+#define GLIMS_RD_PRECOND_MULTIGRID 2
 
 #define GLIMS_FLAG_EXTRAPOLATE_GUESS 1  /* Newton guess c^n + (c^n - c^{n-1}) instead of c^n (reference: c^n) */
 #define GLIMS_FLAG_FP32_JACOBIAN 4       /* OFF by default.  The Newton Jacobian A(c) is stored and streamed in single
@@ -146,6 +164,13 @@ typedef struct glims_stats {
   double  us_spmv_median;   /* medians over the last glims_step call */
   double  us_sweep_median;
   double  us_update_median;
+  /* ---- ABI 3 */
+  int64_t rd_precond_used;  /* GLIMS_RD_PRECOND_JACOBI | _MULTIGRID: what the RD solves really use (0 = not decided yet) */
+  double  rd_stiffness_ratio; /* q = mean over the rows of S_ii / M_ii, the number `auto` decides on */
+  int64_t rd_mg_levels;     /* levels of the RD hierarchy incl. the mesh (0 = not built) */
+  int64_t rd_mg_cycles;     /* V-cycles applied inside glims_step */
+  double  rd_mg_complexity; /* stored operator entries of all levels / entries of S */
+  double  ms_rd_mg_setup;   /* wall time of the last set-up of the RD hierarchy */
 } glims_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------------------- */
@@ -209,7 +234,9 @@ int glims_get_state(glims_ctx* h, double* c, double* u);   /* either may be NULL
 int glims_step(glims_ctx* h, int n_steps);
 
 /* Solves K_el u = G c + f for the current concentration (the F_m block; it is linear in u and does not
- * feed back into c, simulation_tumor_growth.py:110-120, so it is only needed at recorded steps). */
+ * feed back into c, simulation_tumor_growth.py:110-120, so it is only needed at recorded steps).
+ * After the Krylov iteration the residual is recomputed with the fp64 operator (one pass) and the iteration continues
+ * from it should it miss the tolerance; glims_stats.last_mech_res is that true residual. */
 int glims_solve_mechanics(glims_ctx* h);
 
 int glims_get_stats(const glims_ctx* h, glims_stats* st);

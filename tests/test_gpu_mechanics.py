@@ -333,3 +333,68 @@ def test_multigrid_on_a_larger_delaunay_mesh_with_slivers(backend):
     assert abs(its["half"] - its["double-vectors"]) <= 2 and rel_l2(us["half"], us["double-vectors"]) < 1e-6
     assert its["half"] < 0.25 * its["block-jacobi"] and its["half"] < 200
     assert rel_l2(us["half"], us["single"]) < 1e-6 and rel_l2(us["half"], us["block-jacobi"]) < 1e-5
+
+
+def test_default_options_over_fifty_coupled_steps(backend):
+    """The DEFAULT configuration (multigrid preconditioner, solve-history initial guess of depth 8, no mixed precision) over
+    50 consecutive step + solve_mechanics calls: the history keeps K x_k of every stored solve and later solves build
+    their initial residual from those products without an operator pass -- so the products must be the operator's own
+    (verification pass), not "right-hand side minus recurrence residual".  At the end the TRUE residual, through the
+    operator hooks, is at the tolerance and the displacement equals the one of a run without any history."""
+    w = _c5_reduced(24)
+    h, dofs = _c5_handle(backend, w)                         # defaults
+    h0, _ = _c5_handle(backend, w, mech_history=0)
+    for _ in range(50):
+        assert h.step(1) == 0 and h.solve_mechanics() == 0
+        assert h0.step(1) == 0
+    assert h0.solve_mechanics() == 0
+    c, u = h.get_state()
+    c0_, u0_ = h0.get_state()
+    st, st0 = h.stats(), h0.stats()
+    res = _free_residual(h, c, u, dofs)
+    print("50 coupled steps, defaults: true residual %.2e (stats: %.2e), %.1f PCG its per solve with the history, "
+          "%d from a zero guess; u vs no-history run %.2e" %
+          (res, st['last_mech_res'], st['mech_cg_its'] / 50.0, st0['mech_cg_its'], rel_l2(u, u0_)))
+    assert np.array_equal(c, c0_)
+    assert res < 10 * 1e-10                                  # mech_rtol = 1e-10
+    assert rel_l2(u, u0_) < 1e-8
+    assert st['mech_cg_its'] / 50.0 < 0.7 * st0['mech_cg_its']   # the history still pays
+    h.close()
+    h0.close()
+
+
+def test_changing_the_history_depth_restarts_the_ring(backend):
+    """mech_history 2 -> 8 after three solves: the ring of stored solves restarts empty (a deeper ring over a full shallow
+    one would count slots that were never written)."""
+    w = _c5_reduced(16)
+    h, dofs = _c5_handle(backend, w, mech_history=2)
+    for _ in range(3):
+        assert h.step(1) == 0 and h.solve_mechanics() == 0
+    h.set_options(mech_history=8)
+    for _ in range(4):
+        assert h.step(1) == 0 and h.solve_mechanics() == 0
+    h.set_options(mech_history=3)                            # and shrinking
+    for _ in range(2):
+        assert h.step(1) == 0 and h.solve_mechanics() == 0
+    c, u = h.get_state()
+    assert _free_residual(h, c, u, dofs) < 1e-9
+    h.close()
+
+
+def test_cheb_ratio_is_read_by_every_cycle_and_degenerate_frames_are_refused(backend):
+    """mg_cheb_ratio on a handle that has already solved takes effect (the A/B sweeps of tools/run_c5.py rely on it) and
+    does not rebuild the hierarchy; a global frame without extent on some axis is a usage error."""
+    w = _c5_reduced(20)
+    h, dofs = _c5_handle(backend, w, mech_history=0)
+    assert h.solve_mechanics() == 0
+    s1 = h.stats()
+    h.set_options(mg_cheb_ratio=4.0)
+    h.set_state(w.c0)
+    assert h.solve_mechanics() == 0
+    s2 = h.stats()
+    its1, its2 = s1['mech_cg_its'], s2['mech_cg_its'] - s1['mech_cg_its']
+    print("PCG iterations with the default interval %d, with lambda / 4: %d" % (its1, its2))
+    assert s2['ms_mg_setup'] == s1['ms_mg_setup'] and its2 > its1
+    with pytest.raises(backend.BackendError):
+        h.set_mg_frame([0.0, 0.0, 0.0], [1.0, 0.0, 1.0])
+    h.close()

@@ -394,3 +394,85 @@ def test_time_dependent_dirichlet_concentration_in_a_partitioned_run(tmp_path):
     sim.close()
     assert np.allclose(z[0][left], 0.3, rtol=0, atol=1e-15) and ref.max() <= 0.3 + 1e-12
     assert rel_l2(z[0], ref) < 1e-10
+
+
+# ---- framed multigrid + solve history (the defaults of DistributedHandle / bench.py) over several solves --------------------
+def _mech_history_worker(rank, world, port, out_dir, n):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["GLIMS_TRANSPORT"] = "gloo"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from glimslib_amd import _backend, workloads
+        from glimslib_amd.parallel import HostStagedTransport
+        from glimslib_amd.partition import partition_mesh
+        w = workloads.config_c5(n)
+        hx = 240.0 / n
+        c0 = np.exp(-((w.mesh.points - np.array([118.0, -109.0, 72.0])) ** 2).sum(axis=1) / (2.0 * (2.5 * hx) ** 2))
+        part = partition_mesh(w.mesh.points, w.mesh.cells, world, rank)
+        h = _backend.Handle(part.points, part.cells, w.cell_label[part.cell_ids], n_own=part.n_own, device=0)
+        tr = HostStagedTransport(dist)
+        h.set_transport(rank, world, tr.halo_cb, tr.allreduce_cb)
+        h.set_halo(part.peer_rank, part.send_ptr, part.send_idx, part.recv_count)
+        h.set_mg_frame(w.mesh.points.min(axis=0), w.mesh.points.max(axis=0))
+        t = w.tables
+        h.set_materials(t['D'], t['rho'], t['gamma'], t['E'], t['nu'])
+        h.set_options(dt=w.dt)                                # defaults: multigrid, history depth 8
+        g2l = np.full(w.mesh.num_vertices(), -1, dtype=np.int64)
+        g2l[part.global_ids[:part.n_own]] = np.arange(part.n_own)
+        nodes = g2l[np.asarray(w.dirichlet_nodes)]
+        nodes = nodes[nodes >= 0]
+        dofs = (nodes[:, None] * 3 + np.arange(3)).ravel()
+        h.set_dirichlet_u(dofs, np.zeros(len(dofs)))
+        h.setup(True)
+        h.set_state(c0[part.global_ids])
+        status, its = 0, []
+        for _ in range(5):
+            status |= h.step(1) | h.solve_mechanics()
+            its.append(h.stats()['mech_cg_its'])
+        c, u = h.get_state()
+        np.savez(os.path.join(out_dir, "mh_rank%d.npz" % rank), gid=part.global_ids, n_own=part.n_own,
+                 u=u.reshape(-1, 3), c=c, status=status, its=np.diff([0] + its))
+        h.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_framed_multigrid_with_the_solve_history_over_five_solves(tmp_path, backend):
+    """Every rank must derive the same least-squares coefficients from all-reduced Gram entries, solve after solve: two
+    ranks with the global frame and the default history against the single-rank run -- same displacement, same iteration
+    counts per solve (+-1)."""
+    from glimslib_amd import workloads
+    n, world = 24, 2
+    w = workloads.config_c5(n)
+    hx = 240.0 / n
+    c0 = np.exp(-((w.mesh.points - np.array([118.0, -109.0, 72.0])) ** 2).sum(axis=1) / (2.0 * (2.5 * hx) ** 2))
+    h = backend.Handle(w.mesh.points, w.mesh.cells, w.cell_label)
+    t = w.tables
+    h.set_materials(t['D'], t['rho'], t['gamma'], t['E'], t['nu'])
+    h.set_options(dt=w.dt)
+    dofs = (np.asarray(w.dirichlet_nodes)[:, None] * 3 + np.arange(3)).ravel()
+    h.set_dirichlet_u(dofs, np.zeros(len(dofs)))
+    h.setup(True)
+    h.set_state(c0)
+    its1 = []
+    for _ in range(5):
+        assert h.step(1) == 0 and h.solve_mechanics() == 0
+        its1.append(h.stats()['mech_cg_its'])
+    its1 = np.diff([0] + its1)
+    c1, u1 = h.get_state()
+    h.close()
+    mp.spawn(_mech_history_worker, args=(world, _free_port(), str(tmp_path), n), nprocs=world, join=True)
+    N = w.mesh.num_vertices()
+    u = np.full((N, 3), np.nan)
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), "mh_rank%d.npz" % r))
+        assert int(z['status']) == 0
+        own = int(z['n_own'])
+        u[z['gid'][:own]] = z['u'][:own]
+        its2 = z['its']
+    print("PCG iterations per solve: single rank %s, two ranks %s" % (list(its1), list(its2)))
+    assert not np.isnan(u).any() and rel_l2(u.reshape(-1), u1) < 1e-7
+    assert np.all(np.abs(its2 - its1) <= 1)
+    assert its1[-1] < its1[0]                                  # the history pays
