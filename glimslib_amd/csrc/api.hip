@@ -102,7 +102,7 @@ int glims_options_default(glims_options* o) {
   o->mg_cheb_ratio = 0.0;
   o->time_kernels = 0;
   o->rd_precond = GLIMS_RD_PRECOND_AUTO;
-  o->rd_mg_smooth = 1;
+  o->rd_mg_smooth = 0;
   return GLIMS_OK;
 }
 
@@ -233,7 +233,8 @@ int glims_create(glims_ctx** out, int dim, int64_t n_nodes, int64_t n_own, int64
     h->mat.alloc_zero(5 * GL_MAX_LABELS, h->st);
     h->partials.alloc_zero((size_t)p.n_slices * 3 + 4096, h->st);
     h->partials2.alloc_zero((size_t)(p.n_slices * 3 + 4096) / 1024 * 3 + 64, h->st);
-    h->partials_v.alloc_zero(2 * 4096 + 64, h->st);   // block pairs of the vector kernels (grid_for caps at 4096 blocks)
+    // block pairs of the vector kernels (grid_for caps at 4096 blocks) or of the multigrid cycle's last level-0 pass
+    h->partials_v.alloc_zero((size_t)std::max(2 * 4096, 2 * (p.n_slices / 4 + 1)) + 64, h->st);
     h->red.alloc_zero(4, h->st);
     h->scal.alloc_zero(2 * SC_COUNT + 8, h->st);
     h->done.alloc_zero(1, h->st);
@@ -330,7 +331,7 @@ int glims_set_options(glims_ctx* h, const glims_options* opt) {
                    opt->mg_coarse_nodes >= 1 && opt->mg_h_factor > 0.0 && (opt->mg_cheb_ratio == 0.0 || opt->mg_cheb_ratio > 1.0),
                "bad elasticity solver options");
     GL_REQUIRE(opt->rd_precond >= GLIMS_RD_PRECOND_AUTO && opt->rd_precond <= GLIMS_RD_PRECOND_MULTIGRID &&
-                   opt->rd_mg_smooth >= 1 && opt->rd_mg_smooth <= 8,
+                   opt->rd_mg_smooth >= 0 && opt->rd_mg_smooth <= 8,
                "bad RD preconditioner options");
     // mg_smooth and mg_cheb_ratio are read by every cycle (no rebuild); the grids depend on the other two
     if (opt->mg_coarse_nodes != h->opt.mg_coarse_nodes || opt->mg_h_factor != h->opt.mg_h_factor)

@@ -196,6 +196,17 @@ struct MgHierarchy {
   dvec<int32_t> cell0;                     // [n_own] lower-corner grid node of the level-1 cell that holds a mesh node
   dvec<double> wgt;                        // [n_own][dim] interpolation weight towards the upper node, per axis
   dvec<int32_t> cell_ptr, cell_nodes;      // mesh nodes sorted by level-1 cell (children lists of the grid nodes)
+  // restriction mesh -> grid as an explicit operator, SELL-64 over the grid nodes: (child, weight) pairs
+  dvec<int64_t> pt_ptr;                    // [ceil(nn / 64) + 1]
+  dvec<int32_t> pt_idx;
+  dvec<float> pt_w;
+  // captured applications (mg.hip, mg_apply_graphed): one executable graph per (r, u, done, pv, degree, interval)
+  struct Graph {
+    unsigned char key[64];
+    hipGraphExec_t exec;
+  };
+  std::vector<Graph> graphs;
+  void drop_graphs();
   dvec<double> x, x2, d, res;              // level-0 work vectors [n_nodes*bs] (ghost slots stay zero)
   double lam0 = 1.0;
   double cheb_ratio = 30.0;                // the smoothers' interval is [lambda_max / cheb_ratio, lambda_max]
@@ -211,6 +222,7 @@ struct MgHierarchy {
   dvec<double> coarse_inv;                 // dense inverse of the coarsest operator [nc][nc], nc = lv.back()->g.nn * bs
   int64_t entries = 0;                     // stored operator entries of the coarse levels (scalars)
   void clear() {
+    drop_graphs();   // they hold the addresses of the levels' buffers
     for (auto* l : lv) delete l;
     lv.clear();
     ready = false;
@@ -402,6 +414,7 @@ struct glims_ctx {
   MgHierarchy mg_rd;                        // RD Jacobian: built on its static part S = (1 - dt rho) M + dt K_D, scalar
   int rd_precond_active = 0;                // what the RD solves use: GLIMS_RD_PRECOND_JACOBI | _MULTIGRID (decided at glims_setup)
   double rd_stiffness_ratio = 0.0;          // mean over the rows of S_ii / M_ii (the quantity `auto` decides on)
+  double rd_break_even = 1e300;             // Jacobi-PCG iterations per Newton solve above which the hierarchy pays
   std::vector<uint8_t> fixed_c_host;        // host copy of the concentration's Dirichlet mask (did the SET of nodes change?)
   bool mg_frame_set = false;               // glims_set_mg_frame: global bounding box of a partitioned mesh
   double mg_frame_lo[3] = {0, 0, 0}, mg_frame_hi[3] = {0, 0, 0};
@@ -482,11 +495,15 @@ void gl_mesh_metrics(glims_ctx* h, const HostPattern& hp, const double* xyz_old)
 void gl_mg_setup(glims_ctx* h, MgHierarchy& mg);   // mg.bs / op_vals / op_fixed / op_dinv set by the caller
 void gl_make_smoother_copy(glims_ctx* h, MgHierarchy& mg, bool half, bool exchange_scale);
 // u = V-cycle(r) with Chebyshev smoothers of the given degree; r zero on constrained dofs
-void gl_mg_apply(glims_ctx* h, MgHierarchy& mg, int degree, const double* r, double* u, const int* done = nullptr);
+// pv (optional): the cycle's last kernel also leaves the per-block partial sums of (r, u) and (r, r), gl_spmv_grid(n_slices)
+// pairs -- what the single-reduction PCG wants next
+void gl_mg_apply(glims_ctx* h, MgHierarchy& mg, int degree, const double* r, double* u, const int* done = nullptr,
+                 double* pv = nullptr);
 void gl_make_kel32(glims_ctx* h);
 // level-0 operator pass of the multigrid (kernels.hip): mode 0 out = r - A x, 1 Chebyshev step, 2 out = Dinv A x
 void gl_launch_mg_fine(glims_ctx* h, MgHierarchy& mg, int mode, const double* xin, const double* r, double* d,
-                       double* xout, double c1, double c2, const int* done = nullptr, double* uout = nullptr);
+                       double* xout, double c1, double c2, const int* done = nullptr, double* uout = nullptr,
+                       const double* r_full = nullptr, double* pv = nullptr);
 // solver.hip: the two hierarchies
 void gl_mg_setup_mech(glims_ctx* h);
 void gl_mg_setup_rd(glims_ctx* h);

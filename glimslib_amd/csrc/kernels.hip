@@ -729,13 +729,15 @@ __global__ __launch_bounds__(256) void k_mg_fine(int n_launch, int chunk, int64_
                                                   const uint8_t* __restrict__ fixed, const XT* __restrict__ xin,
                                                   const XT* __restrict__ r, XT* __restrict__ d,
                                                   XT* __restrict__ xout, double* __restrict__ uout, double c1,
-                                                  double c2, int remap, const int* __restrict__ done) {
+                                                  double c2, int remap, const int* __restrict__ done,
+                                                  const double* __restrict__ r_full, double* __restrict__ pv) {
   constexpr int B2 = BS * BS;
   using XN = XNode<BS, XT>;   // layout of the iterate (xin; xout of MODE 1 / 2); r, d and the MODE 0 result are packed
   if (done && *done) return;   // enqueued past the Krylov solver's convergence: nobody reads the result
   const int b = remap > 1 ? xcd_chunk_remap(blockIdx.x, gridDim.x, remap) : blockIdx.x;
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int s_end = min(n_launch, (b + 1) * chunk);
+  double pg = 0.0, pr = 0.0;   // last pass of a cycle inside the Krylov solver: partials of (r, u) and (r, r)
   for (int s = b * chunk + wid; s < s_end; s += 4) {
     const int64_t row = (int64_t)s * GL_WAVE + lane;
     const int64_t base = slice_ptr[s];
@@ -813,12 +815,32 @@ __global__ __launch_bounds__(256) void k_mg_fine(int n_launch, int chunk, int64_
         }
         if (uout) {   // last step of the cycle: back to x = S x~, in double precision, where the Krylov solver wants it
 #pragma unroll
-          for (int a = 0; a < BS; ++a) uout[row * BS + a] = sc[row * BS + a] * xn[a];
+          for (int a = 0; a < BS; ++a) {
+            const double ua = sc[row * BS + a] * xn[a];
+            uout[row * BS + a] = ua;
+            if (pv) {
+              const double ra = r_full[row * BS + a];
+              pg += ra * ua;
+              pr += ra * ra;
+            }
+          }
         } else {
           XN::store(xout, row, xn);
         }
       }
     }
+  }
+  if (MODE == 1 && pv) {   // (uniform over the launch) one pair per block, summed over its 4 waves in a fixed order
+    __shared__ double smp[4][2];
+    pg = wave_sum(pg);
+    pr = wave_sum(pr);
+    if (lane == 0) {
+      smp[wid][0] = pg;
+      smp[wid][1] = pr;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2)
+      pv[(size_t)b * 2 + threadIdx.x] = (smp[0][threadIdx.x] + smp[1][threadIdx.x]) + (smp[2][threadIdx.x] + smp[3][threadIdx.x]);
   }
 }
 
@@ -1158,7 +1180,8 @@ void gl_apply_G(glims_ctx* h, const double* c, double* y) {
 }
 
 void gl_launch_mg_fine(glims_ctx* h, MgHierarchy& mg, int mode, const double* xin, const double* r, double* d,
-                       double* xout, double c1, double c2, const int* done, double* uout) {
+                       double* xout, double c1, double c2, const int* done, double* uout, const double* r_full,
+                       double* pv) {
   const DevPattern& p = h->pat;
   const int grid = gl_spmv_grid(p.n_slices);
   const int chunk = (p.n_slices + grid - 1) / grid;
@@ -1170,7 +1193,7 @@ void gl_launch_mg_fine(glims_ctx* h, MgHierarchy& mg, int mode, const double* xi
 #define GL_MGF4(BS, KB, MODE, VT, VPTR, CIDX, XT)                                                                    \
   hipLaunchKernelGGL((k_mg_fine<BS, MODE, KB, VT, CIDX, XT>), dim3(grid), dim3(256), 0, h->st, p.n_slices, chunk,     \
                      h->n_own, p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, VPTR, mg.dinv0.p, mg.sc.p,         \
-                     fx, (const XT*)xin, (const XT*)r, (XT*)d, (XT*)xout, uout, c1, c2, GL_XCD_CHUNK, done)
+                     fx, (const XT*)xin, (const XT*)r, (XT*)d, (XT*)xout, uout, c1, c2, GL_XCD_CHUNK, done, r_full, pv)
 #define GL_MGF3(BS, KB, MODE, VT, VPTR, CIDX)                                                                        \
   do {                                                                                                               \
     if (MODE != 2 && x32) GL_MGF4(BS, KB, MODE, VT, VPTR, CIDX, float);                                              \

@@ -539,7 +539,8 @@ __global__ __launch_bounds__(256) void k_mg_cart_g(GridDev g, int R, int S, cons
 template <int D, int BS>
 __global__ void k_mg_first_cart(GridDev g, const double* __restrict__ dinv, double* __restrict__ r,
                                 double* __restrict__ d, double* __restrict__ x, double c2,
-                                const double* __restrict__ sc) {
+                                const double* __restrict__ sc, const int* __restrict__ done) {
+  if (done && *done) return;
   const long long I = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (I >= g.nn) return;
   double rv[BS];
@@ -564,7 +565,8 @@ __global__ void k_mg_first_cart(GridDev g, const double* __restrict__ dinv, doub
 template <int BS, class XT>
 __global__ void k_mg_first_fine(int64_t n_own, const float* __restrict__ dinv, const double* __restrict__ sc,
                                 const double* __restrict__ r, XT* __restrict__ rs, XT* __restrict__ d,
-                                XT* __restrict__ x, double c2) {
+                                XT* __restrict__ x, double c2, const int* __restrict__ done) {
+  if (done && *done) return;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_own) return;
   double rv[BS], xv[BS];
@@ -584,64 +586,142 @@ __global__ void k_mg_first_fine(int64_t n_own, const float* __restrict__ dinv, c
   XNode<BS, XT>::store(x, i, xv);
 }
 
-// restriction mesh -> grid: r1[I] = sum_{children i} w_iI res_i.  One WAVE per grid node: the 2^D cells around the node
-// are dealt to groups of 64 / 2^D lanes, each lane takes the children of its cell with that stride; fixed lane -> child
-// assignment and a fixed shuffle tree, i.e. a gather in a reproducible order (a thread per grid node walked ~64
-// children one after the other: 232 us at 1 M mesh nodes against 134 us for a whole operator pass).
-template <int D, int BS, class XT>
-__global__ __launch_bounds__(256) void k_mg_restrict0(GridDev g1, int nbx, int nby, const int32_t* __restrict__ cell_ptr,
-                                                       const int32_t* __restrict__ cell_nodes,
-                                                       const double* __restrict__ wgt, const XT* __restrict__ res,
-                                                       double* __restrict__ r1) {
-  constexpr int NC = 1 << D, LPC = GL_WAVE / NC;   // lanes per cell
-  // Grid nodes are dealt to the waves in BRICKS of 4^3 (8^2) nodes = 16 blocks, four bricks in a row per XCD chunk: the
-  // 2^D grid nodes around a cell all read its children, and with the nodes in plain x-fastest order those eight reads
-  // came from eight different L2s (PMC: 296 MB per launch at 1 M mesh nodes for 50 MB of operands).
-  constexpr int BW = D == 3 ? 4 : 8;
-  const int b = xcd_chunk_remap(blockIdx.x, gridDim.x, 64);
-  const long long w = (long long)b * 4 + (threadIdx.x >> 6);
-  const long long brick = w >> 6;
-  const int q = (int)(w & 63);
-  const int lane = threadIdx.x & 63;
-  int Iv[3] = {0, 0, 0};
-  Iv[0] = (int)(brick % nbx) * BW + (D == 3 ? (q & 3) : (q & 7));
-  Iv[1] = (int)((brick / nbx) % nby) * BW + (D == 3 ? ((q >> 2) & 3) : (q >> 3));
-  if (D == 3) Iv[2] = (int)(brick / ((long long)nbx * nby)) * BW + (q >> 4);
-  if (Iv[0] >= g1.n0 || Iv[1] >= g1.n1 || (D == 3 && Iv[2] >= g1.n2)) return;   // wave-uniform
-  const long long I = v2lin(Iv, g1);
-  const int corner = lane / LPC, sub = lane % LPC;
-  int cv[3] = {0, 0, 0};
-  bool ok = true;
+// Interpolation weight of a mesh node towards corner `corner` of its grid cell, from the per-axis weights.  Rounded to
+// single precision ONCE here: the explicit restriction operator stores these values and the prolongation evaluates the
+// same expression, so that R = P^T holds bit for bit (on lattice meshes the factors are 0, 1/2, 1: nothing is rounded).
+template <int D>
+__device__ __forceinline__ double corner_weight(const double* __restrict__ w3, int corner) {
+  double w = 1.0;
 #pragma unroll
-  for (int a = 0; a < D; ++a) {
-    cv[a] = Iv[a] - ((corner >> a) & 1);
-    ok = ok && cv[a] >= 0 && cv[a] <= gn(g1, a) - 2;
+  for (int a = 0; a < D; ++a) w *= ((corner >> a) & 1) ? w3[a] : 1.0 - w3[a];
+  return (double)(float)w;
+}
+
+// Restriction mesh -> grid as an EXPLICIT sparse operator, SELL-64 over the grid nodes (x fastest): entry k of grid node I
+// = (child mesh node, weight) at pt_ptr[I / 64] + k * 64 + I % 64.  Until round 3 the restriction walked the children
+// lists of the 2^D cells around a node and rebuilt every weight from the children's per-axis weights (24 B per child and
+// visit, each child visited by its 8 parents): 462 us at 10 M mesh nodes with scalar unknowns, more than two operator
+// passes of level 0.  The operator costs 8 B per (child, parent) pair with a non-zero weight -- 27 per grid node on a
+// lattice mesh with H = 2 h, i.e. 3.4 per mesh node -- read in unit stride.
+// set-up, pass 1: number of children with a non-zero weight
+template <int D>
+__global__ void k_mg_pt_count(GridDev g1, const int32_t* __restrict__ cell_ptr, const int32_t* __restrict__ cell_nodes,
+                              const double* __restrict__ wgt, int32_t* __restrict__ cnt) {
+  const long long I = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (I >= g1.nn) return;
+  int Iv[3];
+  lin2v(I, g1, Iv);
+  int n = 0;
+  for (int corner = 0; corner < (1 << D); ++corner) {
+    int cv[3] = {0, 0, 0};
+    bool ok = true;
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      cv[a] = Iv[a] - ((corner >> a) & 1);
+      ok = ok && cv[a] >= 0 && cv[a] <= gn(g1, a) - 2;
+    }
+    if (!ok) continue;
+    const long long c = v2lin(cv, g1);
+    for (int32_t q = cell_ptr[c]; q < cell_ptr[c + 1]; ++q)
+      n += corner_weight<D>(wgt + (int64_t)cell_nodes[q] * D, corner) != 0.0;
   }
+  cnt[I] = n;
+}
+// set-up, pass 2: the entries, corner after corner and child after child (a fixed order); slots past a node's own count
+// repeat a valid child index with weight 0
+template <int D>
+__global__ void k_mg_pt_fill(GridDev g1, const int32_t* __restrict__ cell_ptr, const int32_t* __restrict__ cell_nodes,
+                             const double* __restrict__ wgt, const int64_t* __restrict__ pt_ptr,
+                             int32_t* __restrict__ idx, float* __restrict__ wv) {
+  const long long I = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // padded to whole slices
+  const long long s = I >> 6;
+  if (s >= (g1.nn + GL_WAVE - 1) / GL_WAVE) return;
+  const int lane = (int)(I & 63);
+  const int64_t base = pt_ptr[s];
+  const int len = (int)((pt_ptr[s + 1] - base) >> 6);
+  int k = 0;
+  if (I < g1.nn) {
+    int Iv[3];
+    lin2v(I, g1, Iv);
+    for (int corner = 0; corner < (1 << D); ++corner) {
+      int cv[3] = {0, 0, 0};
+      bool ok = true;
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        cv[a] = Iv[a] - ((corner >> a) & 1);
+        ok = ok && cv[a] >= 0 && cv[a] <= gn(g1, a) - 2;
+      }
+      if (!ok) continue;
+      const long long c = v2lin(cv, g1);
+      for (int32_t q = cell_ptr[c]; q < cell_ptr[c + 1]; ++q) {
+        const int32_t i = cell_nodes[q];
+        const double w = corner_weight<D>(wgt + (int64_t)i * D, corner);
+        if (w == 0.0) continue;
+        idx[base + (int64_t)k * GL_WAVE + lane] = i;
+        wv[base + (int64_t)k * GL_WAVE + lane] = (float)w;
+        ++k;
+      }
+    }
+  }
+  for (; k < len; ++k) {
+    idx[base + (int64_t)k * GL_WAVE + lane] = 0;
+    wv[base + (int64_t)k * GL_WAVE + lane] = 0.0f;
+  }
+}
+// r1[I] = sum_k w_k res[child_k]: one thread per grid node, 8 (index, weight, gather) triples in flight
+// With dinv1 the first smoothing step of the grid level (from a zero iterate: k_mg_first_cart) rides along: the thread
+// has its node's restricted residual in registers.
+template <int BS, class XT>
+__global__ __launch_bounds__(256) void k_mg_restrict0(long long nn, const int64_t* __restrict__ pt_ptr,
+                                                       const int32_t* __restrict__ idx, const float* __restrict__ wv,
+                                                       const XT* __restrict__ res, double* __restrict__ r1,
+                                                       const double* __restrict__ dinv1, const double* __restrict__ sc1,
+                                                       double* __restrict__ d1, double* __restrict__ x1, double c2,
+                                                       const int* __restrict__ done) {
+  if (done && *done) return;
+  const long long I = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // grid covers whole slices
+  const long long s = I >> 6;
+  if (s >= (nn + GL_WAVE - 1) / GL_WAVE) return;
+  const int64_t base = pt_ptr[s] + (I & 63);
+  const int len = (int)((pt_ptr[s + 1] - pt_ptr[s]) >> 6);
   double acc[BS];
 #pragma unroll
   for (int a = 0; a < BS; ++a) acc[a] = 0.0;
-  if (ok) {
-    const long long c = v2lin(cv, g1);
-    for (int32_t p = cell_ptr[c] + sub; p < cell_ptr[c + 1]; p += LPC) {
-      const int64_t i = cell_nodes[p];
-      double wi = 1.0;
+  for (int k = 0; k < len; k += 8) {
+    int32_t ci[8];
+    float wk[8];
 #pragma unroll
-      for (int a = 0; a < D; ++a) {
-        const double wa = wgt[i * D + a];
-        wi *= ((corner >> a) & 1) ? wa : 1.0 - wa;
-      }
-#pragma unroll
-      for (int a = 0; a < BS; ++a) acc[a] += wi * (double)res[i * BS + a];
+    for (int j = 0; j < 8; ++j) {
+      const int64_t e = base + (int64_t)min(k + j, len - 1) * GL_WAVE;
+      ci[j] = __builtin_nontemporal_load(idx + e);
+      wk[j] = k + j < len ? __builtin_nontemporal_load(wv + e) : 0.0f;
     }
+    double rv[8][BS];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int a = 0; a < BS; ++a) rv[j][a] = (double)res[(int64_t)ci[j] * BS + a];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int a = 0; a < BS; ++a) acc[a] += (double)wk[j] * rv[j][a];
+  }
+  if (I >= nn) return;
+  if (dinv1 && sc1) {   // the level works in scaled variables from here on: r~ = s r
+#pragma unroll
+    for (int a = 0; a < BS; ++a) acc[a] *= sc1[(long long)a * nn + I];
   }
 #pragma unroll
-  for (int a = 0; a < BS; ++a) {
+  for (int a = 0; a < BS; ++a) r1[(long long)a * nn + I] = acc[a];
+  if (dinv1) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc[a] += __shfl_down(acc[a], o, 64);
-  }
-  if (lane == 0) {
+    for (int a = 0; a < BS; ++a) {
+      double z = 0.0;
 #pragma unroll
-    for (int a = 0; a < BS; ++a) r1[(long long)a * g1.nn + I] = acc[a];
+      for (int b = 0; b < BS; ++b) z += dinv1[(long long)(a * BS + b) * nn + I] * acc[b];
+      d1[(long long)a * nn + I] = c2 * z;
+      x1[(long long)a * nn + I] = c2 * z;
+    }
   }
 }
 
@@ -650,7 +730,8 @@ template <int D, int BS, class XT>
 __global__ void k_mg_prolong0(GridDev g1, int64_t n_own, const int32_t* __restrict__ cell0,
                               const double* __restrict__ wgt, const uint8_t* __restrict__ fixed,
                               const double* __restrict__ sc, const double* __restrict__ e1,
-                              const XT* __restrict__ xin, XT* __restrict__ xout) {
+                              const XT* __restrict__ xin, XT* __restrict__ xout, const int* __restrict__ done) {
+  if (done && *done) return;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_own) return;
   int cv[3];
@@ -660,14 +741,9 @@ __global__ void k_mg_prolong0(GridDev g1, int64_t n_own, const int32_t* __restri
   for (int a = 0; a < BS; ++a) acc[a] = 0.0;
   for (int corner = 0; corner < (1 << D); ++corner) {
     int pv[3] = {0, 0, 0};
-    double w = 1.0;
 #pragma unroll
-    for (int a = 0; a < D; ++a) {
-      const int up = (corner >> a) & 1;
-      pv[a] = cv[a] + up;
-      const double wa = wgt[i * D + a];
-      w *= up ? wa : 1.0 - wa;
-    }
+    for (int a = 0; a < D; ++a) pv[a] = cv[a] + ((corner >> a) & 1);
+    const double w = corner_weight<D>(wgt + i * D, corner);   // the value the restriction operator stores
     if (w == 0.0) continue;
     const long long J = v2lin(pv, g1);
 #pragma unroll
@@ -684,7 +760,9 @@ __global__ void k_mg_prolong0(GridDev g1, int64_t n_own, const int32_t* __restri
 template <int D, int BS>
 __global__ __launch_bounds__(256) void k_mg_restrict(GridDev gf, GridDev gc, Fac fc, const double* __restrict__ res,
                                                       double* __restrict__ rc, const double* __restrict__ dinv_c,
-                                                      double* __restrict__ d_c, double* __restrict__ x_c, double c2) {
+                                                      double* __restrict__ d_c, double* __restrict__ x_c, double c2,
+                                                      const int* __restrict__ done) {
+  if (done && *done) return;
   // one wave per coarse node, its (up to) 3^D children dealt to the lanes, fixed shuffle tree.  With dinv_c the first
   // smoothing step of the coarse level (from a zero iterate: d = x = c2 Dinv r, k_mg_first_cart) rides along.
   const long long I = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -743,7 +821,8 @@ __global__ __launch_bounds__(256) void k_mg_restrict(GridDev gf, GridDev gc, Fac
 template <int D, int BS>
 __global__ void k_mg_prolong(GridDev gf, GridDev gc, Fac fc, const double* __restrict__ ec,
                              const double* __restrict__ xin, double* __restrict__ xout,
-                             const double* __restrict__ isc) {
+                             const double* __restrict__ isc, const int* __restrict__ done) {
+  if (done && *done) return;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= gf.nn) return;
   int iv[3];
@@ -783,7 +862,8 @@ __global__ void k_mg_prolong(GridDev gf, GridDev gc, Fac fc, const double* __res
 
 // coarsest level: x = Ainv r, one wave per row of the dense inverse
 __global__ __launch_bounds__(256) void k_mg_dense(int n, const double* __restrict__ Ainv, const double* __restrict__ r,
-                                                   double* __restrict__ x) {
+                                                   double* __restrict__ x, const int* __restrict__ done) {
+  if (done && *done) return;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= n) return;
   double v = 0.0;
@@ -1256,6 +1336,31 @@ void mg_setup_t(glims_ctx* h, MgHierarchy& mg) {
     GL_HIP(hipStreamSynchronize(h->st));
   }
   lap("children lists (counting sort, upload)");
+  {   // explicit restriction operator mesh -> grid (k_mg_restrict0): count, slice lengths on the host, fill
+    dvec<int32_t> cnt;
+    cnt.alloc((size_t)g1.nn);
+    hipLaunchKernelGGL(k_mg_pt_count<D>, dim3(gridn(g1.nn)), dim3(256), 0, h->st, gdev(g1), mg.cell_ptr.p, mg.cell_nodes.p,
+                       mg.wgt.p, cnt.p);
+    GL_HIP(hipGetLastError());
+    std::vector<int32_t> hc((size_t)g1.nn);
+    GL_HIP(hipMemcpyAsync(hc.data(), cnt.p, hc.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->st));
+    GL_HIP(hipStreamSynchronize(h->st));
+    const int64_t ns = (g1.nn + GL_WAVE - 1) / GL_WAVE;
+    std::vector<int64_t> ptr((size_t)ns + 1, 0);
+    for (int64_t sl = 0; sl < ns; ++sl) {
+      int m = 1;   // at least one (zero-weight) entry: the kernel clamps its slot index to len - 1
+      for (int64_t I = sl * GL_WAVE; I < std::min<int64_t>(g1.nn, (sl + 1) * GL_WAVE); ++I) m = std::max(m, hc[I]);
+      ptr[sl + 1] = ptr[sl] + (int64_t)m * GL_WAVE;
+    }
+    mg.pt_ptr.upload(ptr, h->st);
+    mg.pt_idx.alloc((size_t)ptr[ns]);
+    mg.pt_w.alloc((size_t)ptr[ns]);
+    hipLaunchKernelGGL(k_mg_pt_fill<D>, dim3(gridn(ns * GL_WAVE)), dim3(256), 0, h->st, gdev(g1), mg.cell_ptr.p,
+                       mg.cell_nodes.p, mg.wgt.p, mg.pt_ptr.p, mg.pt_idx.p, mg.pt_w.p);
+    GL_HIP(hipGetLastError());
+    GL_HIP(hipStreamSynchronize(h->st));
+  }
+  lap("restriction operator (count, fill)");
   const size_t nd0 = (size_t)h->n_nodes * BS;
   mg.x.alloc_zero(nd0, h->st);
   mg.x2.alloc_zero(nd0, h->st);
@@ -1516,7 +1621,7 @@ void mg_cycle_cart(glims_ctx* h, MgHierarchy& mg, int deg, size_t l, const int* 
   const GridDev g = gdev(L.g);
   if (l + 1 == mg.lv.size()) {
     const int nc = (int)(L.g.nn * BS);
-    hipLaunchKernelGGL(k_mg_dense, dim3((nc + 3) / 4), dim3(256), 0, h->st, nc, mg.coarse_inv.p, L.r.p, L.x.p);
+    hipLaunchKernelGGL(k_mg_dense, dim3((nc + 3) / 4), dim3(256), 0, h->st, nc, mg.coarse_inv.p, L.r.p, L.x.p, done);
     GL_HIP(hipGetLastError());
     return;
   }
@@ -1524,9 +1629,10 @@ void mg_cycle_cart(glims_ctx* h, MgHierarchy& mg, int deg, size_t l, const int* 
   double c1, c2;
   ch.next(0, &c1, &c2);
   const double* sc = L.half ? L.sc.p : nullptr;   // this level works in scaled variables between first_cart and its last pass
-  GL_REQUIRE(!(first_done && L.half), "internal: fused first step on a level with scaled variables");
+  // (first_done on a level with scaled variables: only the mesh -> grid restriction does that, and it applies the scaling)
+  GL_REQUIRE(!(first_done && L.half && l > 0), "internal: fused first step on a level with scaled variables");
   if (!first_done)
-    hipLaunchKernelGGL((k_mg_first_cart<D, BS>), dim3(gridn(g.nn)), dim3(256), 0, h->st, g, L.dinv.p, L.r.p, L.d.p, L.x.p, c2, sc);
+    hipLaunchKernelGGL((k_mg_first_cart<D, BS>), dim3(gridn(g.nn)), dim3(256), 0, h->st, g, L.dinv.p, L.r.p, L.d.p, L.x.p, c2, sc, done);
   double *xa = L.x.p, *xb = L.x2.p;
   for (int m = 1; m < deg; ++m) {
     ch.next(m, &c1, &c2);
@@ -1539,12 +1645,12 @@ void mg_cycle_cart(glims_ctx* h, MgHierarchy& mg, int deg, size_t l, const int* 
   const bool reduce_c = C.global && !L.global && h->world > 1;
   const double c2c = mg_fused_first_c2(mg, l + 1, reduce_c);
   hipLaunchKernelGGL((k_mg_restrict<D, BS>), dim3(gridn(C.g.nn, 4)), dim3(256), 0, h->st, g, gdev(C.g), fc, L.res.p, C.r.p,
-                     c2c != 0.0 ? C.dinv.p : nullptr, C.d.p, C.x.p, c2c);
+                     c2c != 0.0 ? C.dinv.p : nullptr, C.d.p, C.x.p, c2c, done);
   GL_HIP(hipGetLastError());
   // first replicated level of a partitioned run: every rank has restricted the residual of its own rows -> sum
   if (reduce_c) gl_allreduce_bulk(h, C.r.p, (size_t)BS * C.g.nn);
   mg_cycle_cart<D, BS>(h, mg, deg, l + 1, done, c2c != 0.0);
-  hipLaunchKernelGGL((k_mg_prolong<D, BS>), dim3(gridn(g.nn)), dim3(256), 0, h->st, g, gdev(C.g), fc, C.x.p, xa, xb, sc);
+  hipLaunchKernelGGL((k_mg_prolong<D, BS>), dim3(gridn(g.nn)), dim3(256), 0, h->st, g, gdev(C.g), fc, C.x.p, xa, xb, sc, done);
   GL_HIP(hipGetLastError());
   std::swap(xa, xb);
   Cheb cp(L.lam, mg.cheb_ratio);
@@ -1557,13 +1663,10 @@ void mg_cycle_cart(glims_ctx* h, MgHierarchy& mg, int deg, size_t l, const int* 
 }
 
 template <int D, int BS>
-void mg_apply_t(glims_ctx* h, MgHierarchy& mg, int deg, const double* r, double* u, const int* done) {
+void mg_apply_t(glims_ctx* h, MgHierarchy& mg, int deg, const double* r, double* u, const int* done, double* pv) {
   const int64_t n = h->n_own;
   const uint8_t* fx = mg.op_fixed;
-  // the smoothers' interval follows the options of the moment (no rebuild: the eigenvalue estimates do not depend on it)
-  // (defaults, measured: elasticity 30 on lattice meshes / 10 on general ones with degree 3; the scalar RD hierarchy 10
-  // with degree 1 -- tools/run_rd_precond.py, DESIGN.md section 9)
-  mg.cheb_ratio = h->opt.mg_cheb_ratio > 1.0 ? h->opt.mg_cheb_ratio : (mg.bs == 1 ? 10.0 : mg.lattice ? 30.0 : 10.0);
+  const double* r_full = r;
   Cheb ch(mg.lam0, mg.cheb_ratio);
   double c1, c2;
   ch.next(0, &c1, &c2);
@@ -1571,10 +1674,10 @@ void mg_apply_t(glims_ctx* h, MgHierarchy& mg, int deg, const double* r, double*
   const int xrec = gl_xrec_doubles(BS, x32);   // length of an iterate's node record in doubles (halo exchange)
   if (x32)
     hipLaunchKernelGGL((k_mg_first_fine<BS, float>), dim3(gridn(n)), dim3(256), 0, h->st, n, mg.dinv0.p, mg.sc.p, r,
-                       (float*)mg.rs.p, (float*)mg.d.p, (float*)mg.x.p, c2);
+                       (float*)mg.rs.p, (float*)mg.d.p, (float*)mg.x.p, c2, done);
   else
     hipLaunchKernelGGL((k_mg_first_fine<BS, double>), dim3(gridn(n)), dim3(256), 0, h->st, n, mg.dinv0.p, mg.sc.p, r,
-                       mg.rs.p, mg.d.p, mg.x.p, c2);
+                       mg.rs.p, mg.d.p, mg.x.p, c2, done);
   r = mg.rs.p;   // from here on the level-0 passes work in the scaled variables
   double *xa = mg.x.p, *xb = mg.x2.p;
   const bool ex = mg.exact_level0;   // the passes read ghost columns: bring them in (iterates are owned-row vectors)
@@ -1588,37 +1691,102 @@ void mg_apply_t(glims_ctx* h, MgHierarchy& mg, int deg, const double* r, double*
   gl_launch_mg_fine(h, mg, 0, xa, r, nullptr, mg.res.p, 0.0, 0.0, done);
   MgLevel& L1 = *mg.lv[0];
   const GridDev g1 = gdev(L1.g);
-  // (the first smoothing step of the grid level is NOT fused into this restriction as it is between the Cartesian levels:
-  // one active lane per wave fetching Dinv made the kernel 33 us slower at 125 k grid nodes, the separate pass costs 5)
-  constexpr int BW = D == 3 ? 4 : 8;   // brick edge of k_mg_restrict0: 64 grid nodes = 16 blocks per brick
-  const int nbx = (g1.n0 + BW - 1) / BW, nby = (g1.n1 + BW - 1) / BW, nbz = D == 3 ? (g1.n2 + BW - 1) / BW : 1;
-  const unsigned gr0 = (unsigned)((long long)nbx * nby * nbz * 16);
+  // restriction through the explicit operator (a thread per grid node); the grid level's first smoothing step rides along
+  // unless an all-reduce of the restricted residual comes first (replicated grid of a partitioned run) or the level is the
+  // dense-solved one
+  const bool reduce1 = L1.global && h->world > 1;
+  const double c2_1 = mg_fused_first_c2(mg, 0, reduce1);
+  const unsigned gr0 = (unsigned)(((g1.nn + 63) / 64 * 64 + 255) / 256);
+  const double* sc1 = L1.half ? L1.sc.p : nullptr;
   if (x32)
-    hipLaunchKernelGGL((k_mg_restrict0<D, BS, float>), dim3(gr0), dim3(256), 0, h->st, g1, nbx, nby, mg.cell_ptr.p,
-                       mg.cell_nodes.p, mg.wgt.p, (const float*)mg.res.p, L1.r.p);
+    hipLaunchKernelGGL((k_mg_restrict0<BS, float>), dim3(gr0), dim3(256), 0, h->st, g1.nn, mg.pt_ptr.p, mg.pt_idx.p,
+                       mg.pt_w.p, (const float*)mg.res.p, L1.r.p, c2_1 != 0.0 ? L1.dinv.p : nullptr, sc1, L1.d.p,
+                       L1.x.p, c2_1, done);
   else
-    hipLaunchKernelGGL((k_mg_restrict0<D, BS, double>), dim3(gr0), dim3(256), 0, h->st, g1, nbx, nby, mg.cell_ptr.p,
-                       mg.cell_nodes.p, mg.wgt.p, (const double*)mg.res.p, L1.r.p);
+    hipLaunchKernelGGL((k_mg_restrict0<BS, double>), dim3(gr0), dim3(256), 0, h->st, g1.nn, mg.pt_ptr.p, mg.pt_idx.p,
+                       mg.pt_w.p, (const double*)mg.res.p, L1.r.p, c2_1 != 0.0 ? L1.dinv.p : nullptr, sc1, L1.d.p,
+                       L1.x.p, c2_1, done);
   GL_HIP(hipGetLastError());
-  if (L1.global) gl_allreduce_bulk(h, L1.r.p, (size_t)BS * L1.g.nn);
-  mg_cycle_cart<D, BS>(h, mg, deg, 0, done, false);
+  if (reduce1) gl_allreduce_bulk(h, L1.r.p, (size_t)BS * L1.g.nn);
+  mg_cycle_cart<D, BS>(h, mg, deg, 0, done, c2_1 != 0.0);
   if (x32)
     hipLaunchKernelGGL((k_mg_prolong0<D, BS, float>), dim3(gridn(n)), dim3(256), 0, h->st, g1, n, mg.cell0.p, mg.wgt.p, fx,
-                       mg.sc.p, L1.x.p, (const float*)xa, (float*)xb);
+                       mg.sc.p, L1.x.p, (const float*)xa, (float*)xb, done);
   else
     hipLaunchKernelGGL((k_mg_prolong0<D, BS, double>), dim3(gridn(n)), dim3(256), 0, h->st, g1, n, mg.cell0.p, mg.wgt.p, fx,
-                       mg.sc.p, L1.x.p, (const double*)xa, xb);
+                       mg.sc.p, L1.x.p, (const double*)xa, xb, done);
   GL_HIP(hipGetLastError());
   std::swap(xa, xb);
   Cheb cp(mg.lam0, mg.cheb_ratio);
   for (int m = 0; m < deg; ++m) {
     cp.next(m, &c1, &c2);
-    // the last step leaves the scaled variables and writes the preconditioned residual where the solver wants it
+    // the last step leaves the scaled variables and writes the preconditioned residual where the solver wants it -- and,
+    // for the Krylov solver, the partial sums of (r, u) and (r, r) over its blocks (pv)
     if (ex) gl_halo_exchange(h, xa, xrec);
-    gl_launch_mg_fine(h, mg, 1, xa, r, mg.d.p, xb, c1, c2, done, m == deg - 1 ? u : nullptr);
+    const bool last = m == deg - 1;
+    gl_launch_mg_fine(h, mg, 1, xa, r, mg.d.p, xb, c1, c2, done, last ? u : nullptr, last ? r_full : nullptr,
+                      last ? pv : nullptr);
     std::swap(xa, xb);
   }
+}
+
+// One application = a fixed sequence of launches with fixed arguments (given r, u, the degree and the smoothers' interval):
+// captured once into a hipGraph and replayed.  The small grids' kernels run 3-9 us each, and launched one by one the host
+// cannot enqueue them as fast as the device retires them (5-6 us of idle device between two of them, more than their own
+// run time: profiles/r03_rdmg46_gaps.txt); replayed from a graph the dependent launches follow each other at the
+// device's own pace.  Not in partitioned runs whose cycle contains host callbacks or collectives.
+struct MgGraphKey {
+  const void *r, *u, *done, *pv;
+  int deg;
+  double ratio;
+  bool operator==(const MgGraphKey& o) const {
+    return r == o.r && u == o.u && done == o.done && pv == o.pv && deg == o.deg && ratio == o.ratio;
+  }
+};
+
+template <int D, int BS>
+void mg_apply_graphed(glims_ctx* h, MgHierarchy& mg, int deg, const double* r, double* u, const int* done, double* pv) {
+  // the smoothers' interval follows the options of the moment (no rebuild: the eigenvalue estimates do not depend on it)
+  // (defaults, measured: elasticity 30 on lattice meshes / 10 on general ones with degree 3; the scalar RD hierarchy 10
+  // with degree 1 -- tools/run_rd_precond.py, DESIGN.md section 9)
+  mg.cheb_ratio = h->opt.mg_cheb_ratio > 1.0 ? h->opt.mg_cheb_ratio : (mg.bs == 1 ? 10.0 : mg.lattice ? 30.0 : 10.0);
   mg.cycles++;
+  const bool graphable = h->world <= 1 && (h->opt.flags & GLIMS_FLAG_NO_GRAPHS) == 0;
+  if (!graphable) {
+    mg_apply_t<D, BS>(h, mg, deg, r, u, done, pv);
+    return;
+  }
+  const MgGraphKey key{r, u, done, pv, deg, mg.cheb_ratio};
+  for (const MgHierarchy::Graph& g : mg.graphs)
+    if (std::memcmp(&g.key, &key, sizeof(key)) == 0) {
+      GL_HIP(hipGraphLaunch((hipGraphExec_t)g.exec, h->st));
+      return;
+    }
+  static_assert(sizeof(MgGraphKey) <= sizeof(MgHierarchy::Graph::key), "graph key does not fit");
+  hipGraph_t graph = nullptr;
+  GL_HIP(hipStreamBeginCapture(h->st, hipStreamCaptureModeThreadLocal));
+  try {
+    mg_apply_t<D, BS>(h, mg, deg, r, u, done, pv);
+  } catch (...) {
+    (void)hipStreamEndCapture(h->st, &graph);
+    if (graph) (void)hipGraphDestroy(graph);
+    throw;
+  }
+  GL_HIP(hipStreamEndCapture(h->st, &graph));
+  hipGraphExec_t exec = nullptr;
+  const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) throw glims_error(GLIMS_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+  if (mg.graphs.size() >= 8) {   // (r, u) pairs of one solver are few; a caller that keeps changing them just re-captures
+    (void)hipGraphExecDestroy((hipGraphExec_t)mg.graphs.front().exec);
+    mg.graphs.erase(mg.graphs.begin());
+  }
+  MgHierarchy::Graph g;
+  std::memset(&g.key, 0, sizeof(g.key));
+  std::memcpy(&g.key, &key, sizeof(key));
+  g.exec = exec;
+  mg.graphs.push_back(g);
+  GL_HIP(hipGraphLaunch(exec, h->st));
 }
 
 }  // namespace
@@ -1634,14 +1802,19 @@ void gl_mg_setup(glims_ctx* h, MgHierarchy& mg) {
   }
 }
 
-void gl_mg_apply(glims_ctx* h, MgHierarchy& mg, int degree, const double* r, double* u, const int* done) {
+void gl_mg_apply(glims_ctx* h, MgHierarchy& mg, int degree, const double* r, double* u, const int* done, double* pv) {
   GL_REQUIRE(mg.ready, "multigrid hierarchy not built");
   const int deg = std::max(1, std::min(8, degree));
   if (h->dim == 2) {
-    if (mg.bs == 1) mg_apply_t<2, 1>(h, mg, deg, r, u, done);
-    else mg_apply_t<2, 2>(h, mg, deg, r, u, done);
+    if (mg.bs == 1) mg_apply_graphed<2, 1>(h, mg, deg, r, u, done, pv);
+    else mg_apply_graphed<2, 2>(h, mg, deg, r, u, done, pv);
   } else {
-    if (mg.bs == 1) mg_apply_t<3, 1>(h, mg, deg, r, u, done);
-    else mg_apply_t<3, 3>(h, mg, deg, r, u, done);
+    if (mg.bs == 1) mg_apply_graphed<3, 1>(h, mg, deg, r, u, done, pv);
+    else mg_apply_graphed<3, 3>(h, mg, deg, r, u, done, pv);
   }
+}
+
+void MgHierarchy::drop_graphs() {
+  for (Graph& g : graphs) (void)hipGraphExecDestroy((hipGraphExec_t)g.exec);
+  graphs.clear();
 }

@@ -358,9 +358,21 @@ __global__ __launch_bounds__(1024) void k_reduce_cg(int ns, const double* __rest
     for (; i < ns; i += 1024) a0 += ps[i];
     v[1] = (a0 + a1) + (a2 + a3);
   }
-  for (int i = threadIdx.x; i < nv; i += 1024) {
-    v[0] += pv[(size_t)i * 2];
-    v[2] += pv[(size_t)i * 2 + 1];
+  {   // (up to ~40 k pairs when the multigrid cycle's last pass supplies them: two chains per value)
+    double g0 = 0.0, g1 = 0.0, r0 = 0.0, r1 = 0.0;
+    int i = threadIdx.x;
+    for (; i + 1024 < nv; i += 2048) {
+      g0 += pv[(size_t)i * 2];
+      r0 += pv[(size_t)i * 2 + 1];
+      g1 += pv[(size_t)(i + 1024) * 2];
+      r1 += pv[(size_t)(i + 1024) * 2 + 1];
+    }
+    for (; i < nv; i += 1024) {
+      g0 += pv[(size_t)i * 2];
+      r0 += pv[(size_t)i * 2 + 1];
+    }
+    v[0] = g0 + g1;
+    v[2] = r0 + r1;
   }
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
@@ -770,7 +782,8 @@ void gl_mg_setup_rd(glims_ctx* h) {
 // sum over the owned rows of S_ii / M_ii  (and the row count) -> partials of k_reduce, [blocks][2]
 __global__ __launch_bounds__(256) void k_diag_ratio(int64_t n_own, const int64_t* __restrict__ slice_ptr,
                                                      const uint8_t* __restrict__ diag_k, const double* __restrict__ vS,
-                                                     const double* __restrict__ vM, double* __restrict__ pv) {
+                                                     const double* __restrict__ vM, double lattice,
+                                                     double* __restrict__ pv /*[blocks][3]*/) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   double q = 0.0, cnt = 0.0;
   for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < n_own; row += stride) {
@@ -778,7 +791,23 @@ __global__ __launch_bounds__(256) void k_diag_ratio(int64_t n_own, const int64_t
     q += vS[e] / vM[e];
     cnt += 1.0;
   }
-  block_sum2(q, cnt, pv);
+  __shared__ double sm[4][2];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    q += __shfl_down(q, o, 64);
+    cnt += __shfl_down(cnt, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    sm[threadIdx.x >> 6][0] = q;
+    sm[threadIdx.x >> 6][1] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double qs = sm[0][0] + sm[1][0] + sm[2][0] + sm[3][0], cs = sm[0][1] + sm[1][1] + sm[2][1] + sm[3][1];
+    pv[(size_t)blockIdx.x * 3 + 0] = qs;
+    pv[(size_t)blockIdx.x * 3 + 1] = cs;
+    pv[(size_t)blockIdx.x * 3 + 2] = lattice * cs;   // rows that sit on a lattice (all or none of this rank's)
+  }
 }
 
 // Which preconditioner the RD solves use.  The reference's sparse LU (simulation_tumor_growth.py:126-130) does not care
@@ -791,16 +820,23 @@ __global__ __launch_bounds__(256) void k_diag_ratio(int64_t n_own, const int64_t
 void gl_rd_choose_precond(glims_ctx* h) {
   const unsigned g = grid_for(h->n_own, 256, 1024);
   hipLaunchKernelGGL(k_diag_ratio, dim3(g), dim3(256), 0, h->st, h->n_own, h->pat.slice_ptr.p, h->pat.diag_k.p,
-                     h->vS.p, h->vM.p, h->partials.p);
+                     h->vS.p, h->vM.p, h->mm.lattice ? 1.0 : 0.0, h->partials.p);
   GL_HIP(hipGetLastError());
-  reduce_partials(h, (int)g, 2, nullptr);
-  allreduce_sum(h, h->red.p, 2);
-  double out[2];
-  read_red(h, 2, out);
+  reduce_partials(h, (int)g, 3, nullptr);
+  allreduce_sum(h, h->red.p, 3);
+  double out[3];
+  read_red(h, 3, out);
   const double rows = std::max(1.0, out[1]);
   h->rd_stiffness_ratio = out[0] / rows;
   const double jacobi_its = std::sqrt(2.0 * std::max(0.0, h->rd_stiffness_ratio));
-  const double break_even = rows >= 4.0e6 ? 20.0 : rows >= 4.0e5 ? 45.0 : rows >= 5.0e4 ? 75.0 : 120.0;
+  // Break-even Jacobi count per Newton solve (tools/run_rd_precond.py).  Lattice meshes: the cycle needs 3-4 iterations
+  // and costs ~5 (10 M rows) to ~20 (0.1 M rows, launch-bound) Jacobi iterations.  General meshes (measured on Delaunay
+  // tetrahedralisations of random points, slivers included): 40 iterations per solve with degree-3 smoothers at 6.5 Jacobi
+  // iterations each -- four times the lattice figure; the prediction sqrt(2 q) is also poor there (85 measured where it
+  // says 14), which the observed count corrects after the first step (gl_step).
+  double break_even = rows >= 4.0e6 ? 20.0 : rows >= 4.0e5 ? 45.0 : rows >= 5.0e4 ? 75.0 : 120.0;
+  if (out[2] != out[1]) break_even *= 4.0;   // (a partitioned mesh is a lattice if every rank's part is)
+  h->rd_break_even = break_even;
   int pick = h->opt.rd_precond;
   if (pick == GLIMS_RD_PRECOND_AUTO)
     pick = jacobi_its > break_even ? GLIMS_RD_PRECOND_MULTIGRID : GLIMS_RD_PRECOND_JACOBI;
@@ -905,11 +941,11 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
   }
   const int ext = v.mg ? 1 : 0;
   if (ext) pm = PackMap();   // the cycle's last kernel produces u: the halo payload is packed by k_pack
+  // external preconditioner: the cycle's last kernel writes u and the (r.u, r.r) partial pairs of ITS blocks
+  const int nvp = ext ? gl_spmv_grid(p.n_slices) : (int)g;
   auto precondition = [&]() {
     if (!ext) return;
-    gl_mg_apply(h, *v.mg, v.mg_degree, v.r, v.u, h->done.p);
-    hipLaunchKernelGGL(k_dot2, dim3(g), dim3(256), 0, h->st, n * v.bs, v.r, v.u, h->partials_v.p, h->done.p);
-    GL_HIP(hipGetLastError());
+    gl_mg_apply(h, *v.mg, v.mg_degree, v.r, v.u, h->done.p, h->partials_v.p);
   };
   GL_VEC(k_cg_init, n, v.r, v.dinv, v.u, v.p, v.s, h->partials_v.p, h->scal.p, h->done.p, pm, ext);
   precondition();
@@ -920,14 +956,16 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
   double* info_dev = h->scal.p + 2 * SC_COUNT;
   while (enq < maxit + 1) {
     int want = batch;
-    if (hint > 0) want = enq == 0 ? hint + (defer ? 2 : 1) : std::max(2, std::min(batch, hint / 4 + 1));
+    // (deferred: one spare iteration with the Jacobi scaling, none with a V-cycle per iteration -- an iteration enqueued
+    //  behind the decision word still costs its ~25 launches, and the residual test of the Newton iteration decides anyway)
+    if (hint > 0) want = enq == 0 ? hint + (defer && !ext ? 2 : 1) : std::max(2, std::min(batch, hint / 4 + 1));
     const int nb = std::min(want, maxit + 1 - enq);
     for (int j = 0; j < nb; ++j) {
       const double* prev = h->scal.p + ((enq + j) & 1) * SC_COUNT;
       double* cur = h->scal.p + ((enq + j + 1) & 1) * SC_COUNT;
       apply_with_halo(h, v);
       // gamma / rr partials: one pair per block of the previous vector kernel; delta: one per SpMV block
-      hipLaunchKernelGGL(k_reduce_cg, dim3(1), dim3(1024), 0, h->st, nblocks, h->partials.p, (int)g, h->partials_v.p,
+      hipLaunchKernelGGL(k_reduce_cg, dim3(1), dim3(1024), 0, h->st, nblocks, h->partials.p, nvp, h->partials_v.p,
                          h->red.p, h->done.p, h->nm);
       allreduce_sum(h, h->red.p, 3);
       const bool timed_upd = v.vals && h->timing(glims_ctx::TK_UPDATE);
@@ -1014,11 +1052,12 @@ int gl_step(glims_ctx* h, int n_steps) {
   }
   h->tev_used = 0;
   if (h->rd_precond_active == 0) gl_rd_choose_precond(h);
-  const bool rd_mg = h->rd_precond_active == GLIMS_RD_PRECOND_MULTIGRID;
+  bool rd_mg = h->rd_precond_active == GLIMS_RD_PRECOND_MULTIGRID;
   if (rd_mg && !h->mg_rd.ready) gl_mg_setup_rd(h);
   const int64_t rd_cycles0 = h->mg_rd.cycles;
   GL_HIP(hipEventRecord(h->ev_a, h->st));
   for (int step = 0; step < n_steps && status == GLIMS_OK; ++step) {
+    const int64_t newton0 = h->stats.newton_its, cg0 = h->stats.cg_its;
     double norms[2] = {0.0, 0.0};
     double nr;
     if (h->pending) {
@@ -1076,7 +1115,7 @@ int gl_step(glims_ctx* h, int n_steps) {
       if (h->jac32) v.vals32 = h->vA32.p;
       if (rd_mg) {
         v.mg = &h->mg_rd;
-        v.mg_degree = o.rd_mg_smooth;
+        v.mg_degree = o.rd_mg_smooth > 0 ? o.rd_mg_smooth : (h->mg_rd.lattice ? 1 : 3);
       }
       int64_t its = 0;
       double res = 0.0;
@@ -1126,6 +1165,21 @@ int gl_step(glims_ctx* h, int n_steps) {
     h->stats.last_newton_res = nr;
     if (status == GLIMS_OK) h->stats.steps++;
     else h->stats.failed_steps++;
+    // `auto` corrects its prediction by what the step just showed: Jacobi-PCG iterations per Newton solve above the
+    // break-even -> the following steps use the hierarchy (the counts are global numbers: every rank switches together)
+    if (status == GLIMS_OK && o.rd_precond == GLIMS_RD_PRECOND_AUTO && h->rd_precond_active == GLIMS_RD_PRECOND_JACOBI) {
+      const int64_t dn = h->stats.newton_its - newton0, dc = h->stats.cg_its - cg0;
+      if (dn > 0 && (double)dc / (double)dn > h->rd_break_even) {
+        if (getenv("GLIMS_VERBOSE"))
+          fprintf(stderr, "glims RD preconditioner: %.1f Jacobi-PCG iterations per Newton solve observed (break-even %.0f): "
+                  "multigrid V-cycle from the next step on\n", (double)dc / (double)dn, h->rd_break_even);
+        h->rd_precond_active = GLIMS_RD_PRECOND_MULTIGRID;
+        h->stats.rd_precond_used = GLIMS_RD_PRECOND_MULTIGRID;
+        rd_mg = true;
+        if (!h->mg_rd.ready) gl_mg_setup_rd(h);
+        for (int& hint : h->cg_hint) hint = 0;   // the counts of the Jacobi solves say nothing about the new ones
+      }
+    }
   }
   GL_HIP(hipEventRecord(h->ev_b, h->st));
   GL_HIP(hipEventSynchronize(h->ev_b));
@@ -1365,6 +1419,9 @@ int gl_solve_mechanics(glims_ctx* h, const double* c_dev) {
         cs = GLIMS_NAN;
         break;
       }
+      if (getenv("GLIMS_VERBOSE"))
+        fprintf(stderr, "glims elasticity solve: %lld iterations, recurrence residual <= %.3e, true residual %.3e (%.2f x the tolerance)\n",
+                (long long)its, tol, res, res / tol);
       if (res <= 4.0 * tol || round >= 2) break;
       int64_t more = 0;
       double r2 = 0.0;

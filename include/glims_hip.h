@@ -100,11 +100,16 @@ typedef struct glims_options {
                              [1, 1 + 2 dt rho c / (1 - dt rho)]).  AUTO decides at the first glims_step after glims_setup
                              from q = mean_i S_ii / M_ii: multigrid when the predicted Jacobi count sqrt(2 q) exceeds the
                              break-even (20 for >= 400 k rows, 45 for >= 50 k, 90 below); the choice and q are in
-                             glims_stats.rd_precond_used / rd_stiffness_ratio                            default AUTO  */
-  int    rd_mg_smooth;    /* Chebyshev degree of the RD hierarchy's smoothers (1 = damped Jacobi).  Measured on the unit
-                             cube with D = 0.1, dt = 1 at 0.1 / 1 / 10 M rows: degree 1 on [lambda/10, lambda] 2.6 / 5.2 /
-                             36.7 ms per step, degree 3 on [lambda/30, lambda] 2.9 / 7.4 / 46.2 (Jacobi-PCG: 4.4 / 26.5 /
-                             486); mg_cheb_ratio = 0 means 10 for this hierarchy                          default 1     */
+                             glims_stats.rd_precond_used / rd_stiffness_ratio.  General (non-lattice) meshes: four
+                             times those break-even counts (the cycle is weaker and dearer there), and because the
+                             prediction is poor on such meshes, AUTO also switches to the hierarchy after any step
+                             whose OBSERVED Jacobi count per solve exceeds the break-even                 default AUTO  */
+  int    rd_mg_smooth;    /* Chebyshev degree of the RD hierarchy's smoothers (1 = damped Jacobi); 0 = by mesh class: 1 on
+                             lattice meshes, 3 on general ones.  Measured on the unit cube with D = 0.1, dt = 1 at 0.1 / 1 /
+                             10 M rows: degree 1 on [lambda/10, lambda] 1.9 / 4.3 / 26.3 ms per step, degree 3 on
+                             [lambda/30, lambda] 2.9 / 7.4 / 46.2 (Jacobi-PCG: 4.4 / 26.5 / 486); on a Delaunay mesh of
+                             200 k random points degree 1 / 3: 77 / 40 iterations per solve.  mg_cheb_ratio = 0 means 10
+                             for this hierarchy                                                           default 0     */
 } glims_options;
 
 #define GLIMS_PRECOND_BLOCK_JACOBI 0
@@ -126,6 +131,8 @@ typedef struct glims_options {
                                            preconditioned residual handed to the Krylov solver is double either way */
 #define GLIMS_FLAG_INT32_COLUMNS 16       /* OFF by default.  Stream the 4-byte column indices everywhere instead of the 16-bit
                                            (window, offset) codes (same bits in every result; takes effect at glims_setup) */
+#define GLIMS_FLAG_NO_GRAPHS 64          /* OFF by default.  The V-cycles are launched kernel by kernel instead of being replayed
+                                           from a captured hipGraph (A/B measurements, debugging; same bits either way) */
 #define GLIMS_FLAG_WARM_START 2         /* first linear solve of a step starts from the previous step's increment
                                            (ignored when GLIMS_FLAG_EXTRAPOLATE_GUESS is set) */
 

@@ -169,7 +169,7 @@ def test_delaunay_mesh_with_a_stiff_step(backend):
     """General (off-lattice) mesh: 125-point coarse stencils; against the Jacobi path and the oracle's LU."""
     w = workloads.config_unstructured(30000)
     t = dict(w.tables)
-    t['D'] = [50.0 * d for d in w.tables['D']]                            # dt D / h^2 ~ 10-50 at a mean edge of ~6 mm
+    t['D'] = [2000.0 * d for d in w.tables['D']]                          # dt D / h^2 of a few hundred at a mean edge of ~6 mm
     per = {k: np.asarray(v)[w.cell_label] for k, v in t.items()}
     o = OracleTumorGrowth(w.mesh.points, w.mesh.cells, per['D'], per['rho'], per['gamma'], per['E'], per['nu'], 1.0)
     co = w.c0.copy()
@@ -189,6 +189,21 @@ def test_delaunay_mesh_with_a_stiff_step(backend):
     for pre in res:
         assert rel_l2(res[pre][0], co) < 1e-9
     assert res[backend.RD_PRECOND_MULTIGRID][1] < res[backend.RD_PRECOND_JACOBI][1]
+    # `auto` on a general mesh: the prediction from q is poor there, the OBSERVED Jacobi count of a step decides (four
+    # times the lattice break-even: 4 x 120 below 50 k rows)
+    h = _handle(backend, w.mesh, w.cell_label, t)
+    h.setup(False)
+    h.set_state(w.c0)
+    assert h.step(2) == 0
+    st = h.stats()
+    ca = h.get_state(want_u=False)[0]
+    h.close()
+    print("auto: q = %.1f, used %d" % (st['rd_stiffness_ratio'], st['rd_precond_used']))
+    assert rel_l2(ca, co) < 1e-9
+    if res[backend.RD_PRECOND_JACOBI][1] > 480.0:
+        assert st['rd_precond_used'] == backend.RD_PRECOND_MULTIGRID and st['rd_mg_cycles'] > 0
+    elif np.sqrt(2.0 * st['rd_stiffness_ratio']) <= 480.0:
+        assert st['rd_precond_used'] == backend.RD_PRECOND_JACOBI
 
 
 # ---- partitioned: the RD hierarchy on the global frame (replicated coarse levels) through the transport hook -------------

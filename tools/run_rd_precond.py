@@ -5,6 +5,7 @@
     python tools/run_rd_precond.py 46 99 215          # 3-D, cells per edge
     DIM=2 python tools/run_rd_precond.py 1000
     DEG=2 ... (Chebyshev degree of the RD hierarchy)   RATIO=10 (mg_cheb_ratio)   STEPS=10
+    MESH=delaunay DSCALE=100 python tools/run_rd_precond.py 200000     # general mesh, diffusivities x DSCALE
 """
 import json
 import os
@@ -19,6 +20,12 @@ from glimslib_amd.mesh import RectangleMesh  # noqa: E402
 
 
 def problem(dim, n):
+    if os.environ.get("MESH") == "delaunay":     # n random points in the brain-extent box, D scaled by DSCALE
+        w = workloads.config_unstructured(n)
+        f = float(os.environ.get("DSCALE", "100"))
+        w.tables = dict(w.tables)
+        w.tables['D'] = [f * d for d in w.tables['D']]
+        return w
     if dim == 3:
         return workloads.config_c2(n)
     mesh = RectangleMesh((0.0, 0.0), (1.0, 1.0), n, n)
@@ -31,7 +38,7 @@ def problem(dim, n):
 def main():
     dim = int(os.environ.get("DIM", "3"))
     steps = int(os.environ.get("STEPS", "10"))
-    deg = int(os.environ.get("DEG", "1"))
+    deg = int(os.environ.get("DEG", "0"))
     ratio = float(os.environ.get("RATIO", "0"))
     out = []
     for n in [int(a) for a in sys.argv[1:]] or [46]:
