@@ -87,6 +87,98 @@ def cpu_baseline(w_headline=None, budget_s=12.0):
     return out
 
 
+def alt_c2(Handle, device, steps=20, warmup=2):
+    """BASELINE config C2 (unit cube n=46, D = rho = 0.1, dt = 1: a STIFF step, dt D / h^2 = 211) under the driver's
+    clock: ms per step and Krylov iterations with the preconditioner `auto` picks, and with Jacobi for comparison."""
+    from glimslib_amd import workloads, _backend
+    w = workloads.config_c2()
+    h = Handle(w.mesh.points, w.mesh.cells, w.cell_label, device=device)
+    t = w.tables
+    h.set_materials(t['D'], t['rho'], t['gamma'], t['E'], t['nu'])
+    out = {"workload": w.name, "dofs": w.mesh.num_vertices(), "steps": steps, "warmup": warmup}
+    for name, pre in (("auto", _backend.RD_PRECOND_AUTO), ("jacobi", _backend.RD_PRECOND_JACOBI)):
+        h.set_options(dt=w.dt, rd_precond=pre)
+        h.setup(with_mechanics=False)
+        h.set_state(w.c0)
+        st = h.step(warmup)
+        h.reset_stats()
+        t0 = time.perf_counter()
+        st |= h.step(steps)
+        el = time.perf_counter() - t0
+        s = h.stats()
+        out[name] = {"ms_per_step": 1e3 * el / steps, "value": w.mesh.num_vertices() * steps / el, "solver_status": int(st),
+                     "newton_its_per_step": s['newton_its'] / steps, "pcg_its_per_step": s['cg_its'] / steps,
+                     "pcg_its_per_newton_solve": s['cg_its'] / max(1, s['newton_its']),
+                     "preconditioner": {1: "jacobi", 2: "multigrid"}.get(int(s['rd_precond_used']), "?"),
+                     "stiffness_ratio_q": s['rd_stiffness_ratio'], "mg_levels": int(s['rd_mg_levels']),
+                     "mg_setup_ms": s['ms_rd_mg_setup']}
+    out.update({k: out["auto"][k] for k in ("ms_per_step", "value", "solver_status", "pcg_its_per_step", "preconditioner")})
+    h.close()
+    return out
+
+
+def alt_c5(Handle, device, steps=10, warmup=10):
+    """BASELINE config C5 (coupled model, c + u = 4 DoF per node) on the brain-extent box at n = 99 (1 M nodes) under the
+    driver's clock: one RD step + one elasticity solve per step, as the reference's monolithic solve does (10 warm-up
+    steps: the elasticity solver's initial guess is a fit over the last 8 solves, a run of the reference's length -- 50
+    steps -- spends its time in that steady state); then a short pass with HIP events around the two dominant kernels of the
+    elasticity solve for their roofline entries."""
+    from glimslib_amd import workloads
+    w = workloads.config_c5()
+    n = w.mesh.num_vertices()
+    h = Handle(w.mesh.points, w.mesh.cells, w.cell_label, device=device)
+    t = w.tables
+    h.set_materials(t['D'], t['rho'], t['gamma'], t['E'], t['nu'])
+    h.set_options(dt=w.dt)
+    nodes = np.asarray(w.dirichlet_nodes, dtype=np.int64)
+    dofs = (nodes[:, None] * 3 + np.arange(3)).ravel()
+    h.set_dirichlet_u(dofs, np.zeros(len(dofs)))
+    h.setup(with_mechanics=True)
+    h.set_state(w.c0)
+    st = h.solve_mechanics()                      # builds the hierarchy (set-up reported, not timed)
+    for _ in range(warmup):
+        st |= h.step(1) | h.solve_mechanics()
+    h.reset_stats()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        st |= h.step(1) | h.solve_mechanics()
+    el = time.perf_counter() - t0
+    s = h.stats()
+    out = {"workload": w.name, "dofs": 4 * n, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * el / steps,
+           "value": 4 * n * steps / el, "solver_status": int(st),
+           "mech_pcg_its_per_solve": s['mech_cg_its'] / max(1, s['mech_solves']), "mech_ms_per_solve": s['ms_mech'] / steps,
+           "rd_device_ms_per_step": s['ms_steps'] / steps, "mg_levels": int(s['mg_levels']),
+           "mg_complexity": s['mg_complexity'], "mg_setup_ms": s['ms_mg_setup'], "last_mech_true_residual": s['last_mech_res']}
+    # per-kernel figures: eager launches with event pairs, 3 more coupled steps
+    h.set_options(time_kernels=3)
+    h.reset_stats()
+    for _ in range(3):
+        st |= h.step(1) | h.solve_mechanics()
+    k = h.stats()
+    h.set_options(time_kernels=0)
+    kernels = []
+    ent, rows = k['nnz_padded'], k['n_rows']
+    for name, what, alg, ms, cnt, med in (
+            ("k_mg_fine<3, 1, 2, _Float16, 1, float>", "level-0 pass of the V-cycle: half-precision copy of the scaled K_el "
+             "with 16-bit column codes + the Chebyshev step's vector update (algorithmic bytes: 20 per stored 3x3 block + "
+             "~100 per node of vectors and inverse diagonal blocks)", 20 * ent + 100 * rows,
+             k['ms_mgfine_mech'], k['n_mgfine_mech'], k['us_mgfine_median']),
+            ("k_spmv_block2<3, 1, 2, double>", "w = K_el u of the Krylov iteration, fp64 3x3 blocks, fused w.u partials "
+             "(algorithmic bytes: 76 per stored block + 48 per node)", 76 * ent + 48 * rows,
+             k['ms_spmvb_mech'], k['n_spmvb_mech'], k['us_spmvb_median'])):
+        if cnt > 0:
+            mean_us = 1e3 * ms / cnt
+            kernels.append({"name": name, "does": what, "algorithmic_bytes_per_launch": alg, "median_us": med,
+                            "mean_us": mean_us, "launches_per_solve": cnt / 3.0,
+                            "achieved_GBps": alg / (mean_us * 1e-6) / 1e9,
+                            "frac": alg / (mean_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                            "timed": "HIP events, eager launches, 3 coupled steps after the timed ones"})
+    out["kernels"] = kernels
+    out["solver_status"] = int(st)
+    h.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -270,8 +362,11 @@ def main():
     b_alg = workloads.b_spmv_bytes(st['nnz'], st['n_rows'])
     t_isolated = t_spmv
     in_step = st.get('n_spmv_steps', 0) > 0
+    post_pass = (not in_step) and st_k is not None and st_k.get('n_spmv_steps', 0) > 0
     if in_step:
         t_spmv = st['ms_spmv_steps'] * 1e-3 / st['n_spmv_steps']
+    elif post_pass:
+        t_spmv = st_k['ms_spmv_steps'] * 1e-3 / st_k['n_spmv_steps']
     achieved = b_alg / t_spmv / 1e9
     # HBM-side bytes per launch from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate rocprofv3 runs,
     # calibrated on kernels with exactly known byte counts).  A LOOKUP into the committed summary of those passes, not
@@ -293,7 +388,7 @@ def main():
         keys = [k for k in pmc["kernels"] if k.startswith(prefix)]
         return pmc["kernels"][keys[0]]["hbm_bytes_per_launch"] if keys else None
 
-    traffic = pmc_bytes("k_spmv<1" if in_step else "k_spmv<0")
+    traffic = pmc_bytes("k_spmv<1" if (in_step or post_pass) else "k_spmv<0")
     steps_n = max(1, steps_done)
     ms_step = 1e3 * elapsed / steps_n
     kernels = []
@@ -317,6 +412,12 @@ def main():
                      "(algorithmic bytes: CSR with 4-byte columns, 12 nnz + 20 rows)", b_alg,
                      st['ms_spmv_steps'], st['n_spmv_steps'], st['us_spmv_median'], "k_spmv<1", steps_n, ms_step,
                      "HIP events inside the %d timed steps" % steps_n)
+    elif world == 1 and post_pass:
+        kernel_entry("k_spmv<1, 4, 1, 1, double, 1>", "y = A(c) x, SELL-64 with 16-bit column codes, fused w.u partials "
+                     "(algorithmic bytes: CSR with 4-byte columns, 12 nnz + 20 rows)", b_alg,
+                     st_k['ms_spmv_steps'], st_k['n_spmv_steps'], st_k['us_spmv_median'], "k_spmv<1", st_k['_steps'],
+                     st_k['ms_steps'] / st_k['_steps'],
+                     "HIP events in a separate pass of %d steps right after the timed region" % st_k['_steps'])
     if st_k is not None:
         ks, kms = st_k['_steps'], st_k['ms_steps'] / st_k['_steps']
         where = "HIP events in a separate pass of %d steps right after the timed region" % ks
@@ -336,13 +437,15 @@ def main():
                 "operator, tools/pmc_summary.py)" % pmc_file,
                 "achieved_real": None if traffic is None else traffic / t_spmv / 1e9,
                 "frac_real": None if traffic is None else traffic / t_spmv / 1e9 / HBM_PEAK_GBS,
-                "kernel": ("k_spmv<1, 4, 1, 1, double, 1>" if in_step else "k_spmv<0, 4, 1, 1, double, 1>") +
+                "kernel": ("k_spmv<1, 4, 1, 1, double, 1>" if (in_step or post_pass) else "k_spmv<0, 4, 1, 1, double, 1>") +
                 " (SELL-64, fp64 values, columns streamed as 16-bit window codes; algorithmic bytes still count 4-byte "
                 "CSR columns)",
                 "algorithmic_bytes_per_launch": b_alg, "avg_launch_us": t_spmv * 1e6,
-                "median_launch_us": st['us_spmv_median'] if in_step else None,
-                "launches_timed": int(st['n_spmv_steps']) if in_step else args.spmv_reps,
+                "median_launch_us": st['us_spmv_median'] if in_step else st_k['us_spmv_median'] if post_pass else None,
+                "launches_timed": int(st['n_spmv_steps']) if in_step else int(st_k['n_spmv_steps']) if post_pass
+                else args.spmv_reps,
                 "timed": "inside the timed steps (k_spmv<1,..>, fused dot product)" if in_step
+                         else "inside the steps of a separate pass right after the timed region (k_spmv<1,..>)" if post_pass
                          else "back-to-back launches after the timed steps (k_spmv<0,..>)",
                 "isolated_launch_us": t_isolated * 1e6,
                 "kernels": kernels}
@@ -402,6 +505,22 @@ def main():
             del c_ref, c_alt
         except Exception as e:   # noqa: BLE001 -- informational only, never in the way of the line
             log("[bench] alt (fp32 Jacobian storage) pass skipped: %r" % (e,))
+
+    # ---- informational, after the headline region: BASELINE configs C2 (a stiff step -> multigrid-preconditioned RD
+    # solves) and C5 (coupled, 1 M nodes) under the same clock, each a few seconds; the headline handle is released first
+    if world == 1 and not args.no_alt and args.workload.lower() == "c4" and not args.n:
+        h.close()
+        for key, fn in (("c2", alt_c2), ("c5_coupled", alt_c5)):
+            try:
+                ta = time.perf_counter()
+                res = fn(Handle, local_rank)
+                res["wall_seconds_incl_setup"] = time.perf_counter() - ta
+                alt = alt or {}
+                alt[key] = res
+                log("[bench] alt.%s: %.2f ms/step, status %d (%.1f s incl. mesh and set-up)" %
+                    (key, res["ms_per_step"], res["solver_status"], res["wall_seconds_incl_setup"]))
+            except Exception as e:   # noqa: BLE001 -- informational only
+                log("[bench] alt.%s skipped: %r" % (key, e))
 
     if rank == 0:
         out = {

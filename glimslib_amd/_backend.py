@@ -58,7 +58,9 @@ class Stats(C.Structure):
                 ("n_update_steps", C.c_int64), ("us_spmv_median", C.c_double), ("us_sweep_median", C.c_double),
                 ("us_update_median", C.c_double),
                 ("rd_precond_used", C.c_int64), ("rd_stiffness_ratio", C.c_double), ("rd_mg_levels", C.c_int64),
-                ("rd_mg_cycles", C.c_int64), ("rd_mg_complexity", C.c_double), ("ms_rd_mg_setup", C.c_double)]
+                ("rd_mg_cycles", C.c_int64), ("rd_mg_complexity", C.c_double), ("ms_rd_mg_setup", C.c_double),
+                ("ms_mgfine_mech", C.c_double), ("n_mgfine_mech", C.c_int64), ("us_mgfine_median", C.c_double),
+                ("ms_spmvb_mech", C.c_double), ("n_spmvb_mech", C.c_int64), ("us_spmvb_median", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

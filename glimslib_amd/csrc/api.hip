@@ -336,7 +336,10 @@ int glims_set_options(glims_ctx* h, const glims_options* opt) {
     // mg_smooth and mg_cheb_ratio are read by every cycle (no rebuild); the grids depend on the other two
     if (opt->mg_coarse_nodes != h->opt.mg_coarse_nodes || opt->mg_h_factor != h->opt.mg_h_factor)
       h->mg.ready = h->mg_rd.ready = false;
-    if (opt->rd_precond != h->opt.rd_precond) h->rd_precond_active = 0;   // decided again by the next glims_step
+    if (opt->rd_precond != h->opt.rd_precond) {
+      h->rd_precond_active = 0;                   // decided again by the next glims_step
+      for (int& hint : h->cg_hint) hint = 0;      // iteration counts of the other preconditioner predict nothing
+    }
     // the solve history is a ring of `mech_history` slots: a new depth starts an empty ring (a larger depth would
     // otherwise count never-allocated slots as stored solves)
     if (opt->mech_history != h->opt.mech_history) h->mh_count = h->mh_next = 0;
@@ -442,6 +445,8 @@ int glims_setup(glims_ctx* h, int with_mechanics) {
     h->mg.ready = h->mg_rd.ready = false;
     h->rd_precond_active = 0;       // decided by the first glims_step (a collective in partitioned runs)
     h->stats.rd_precond_used = 0;
+    for (int& hint : h->cg_hint) hint = 0;
+    h->mech_hint = 0;
     GL_REQUIRE(h->have_materials, "glims_setup before glims_set_materials");
     if (with_mechanics) {
       const size_t nd = (size_t)h->n_nodes * h->dim;

@@ -200,13 +200,6 @@ struct MgHierarchy {
   dvec<int64_t> pt_ptr;                    // [ceil(nn / 64) + 1]
   dvec<int32_t> pt_idx;
   dvec<float> pt_w;
-  // captured applications (mg.hip, mg_apply_graphed): one executable graph per (r, u, done, pv, degree, interval)
-  struct Graph {
-    unsigned char key[64];
-    hipGraphExec_t exec;
-  };
-  std::vector<Graph> graphs;
-  void drop_graphs();
   dvec<double> x, x2, d, res;              // level-0 work vectors [n_nodes*bs] (ghost slots stay zero)
   double lam0 = 1.0;
   double cheb_ratio = 30.0;                // the smoothers' interval is [lambda_max / cheb_ratio, lambda_max]
@@ -222,7 +215,6 @@ struct MgHierarchy {
   dvec<double> coarse_inv;                 // dense inverse of the coarsest operator [nc][nc], nc = lv.back()->g.nn * bs
   int64_t entries = 0;                     // stored operator entries of the coarse levels (scalars)
   void clear() {
-    drop_graphs();   // they hold the addresses of the levels' buffers
     for (auto* l : lv) delete l;
     lv.clear();
     ready = false;
@@ -367,15 +359,20 @@ struct glims_ctx {
   int64_t stats_defer_miss = 0;
   int64_t nnz_idx16_avail = 0;             // stored entries of slices that have 16-bit codes
   // glims_options.time_kernels: event pairs around the hot kernels of glims_step (bench.py's in-step roofline figures)
-  enum { TK_SPMV = 0, TK_SWEEP = 1, TK_UPDATE = 2 };
+  enum { TK_SPMV = 0, TK_SWEEP = 1, TK_UPDATE = 2, TK_MGFINE = 3, TK_SPMVB = 4, TK_COUNT = 5 };
   std::vector<hipEvent_t> tev;
   std::vector<uint8_t> tev_cat;             // category of pair q = events 2q, 2q+1
   size_t tev_used = 0;
   // time_kernels = 1: the Krylov SpMV only (two event records per launch cost ~2 us each -- too much for the other two
   // kernels inside a timed region at 1 M rows); 2: all three categories
+  // 3: the two dominant kernels of the elasticity solve instead (level-0 multigrid pass, block SpMV; eager launches)
   bool timing(int cat) const {
-    return (opt.time_kernels >= 2 || (opt.time_kernels == 1 && cat == TK_SPMV)) && tev_used + 2 <= tev.size();
+    const bool on = cat >= TK_MGFINE ? opt.time_kernels == 3
+                                     : (opt.time_kernels == 2 || (opt.time_kernels == 1 && cat == TK_SPMV));
+    return on && tev_used + 2 <= tev.size();
   }
+  void timing_begin();                      // allocates the event pool on first use
+  void timing_collect();                    // elapsed times of the recorded pairs -> stats (sums, counts, medians)
   void tick(int cat) {                      // first call opens a pair of category `cat`, the second closes it
     if ((tev_used & 1) == 0) tev_cat[tev_used / 2] = (uint8_t)cat;
     (void)hipEventRecord(tev[tev_used++], st);

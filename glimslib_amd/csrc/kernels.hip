@@ -1096,10 +1096,18 @@ void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* s
   // ev0 / ev1 (glims_options.time_kernels): start / stop events attached to THIS dispatch (hipExtLaunchKernelGGL) --
   // the kernel's own timestamps, no extra packets in the queue.  hipEventRecord before and after the launch put a
   // 5-6 us idle gap on either side of every SpMV (profiles/r02_c3_timeline.txt), 14 % of the step at 1 M rows.
+  // (plain launch without events: that is the form stream capture is specified for)
 #define GL_SPMV4(DOTS, CIDX, VT, PAIR, VPTR, C16)                                                                    \
-  hipExtLaunchKernelGGL((k_spmv<DOTS, 4, 1, CIDX, VT, PAIR>), dim3(grid), dim3(256), 0, st, ev0, ev1, 0, n_launch,    \
-                        chunk, slice_list, h->n_own, p.slice_ptr.p, p.cols.p, C16, p.win_base.p, p.win_ok.p,         \
-                        p.diag_k.p, VPTR, x, y, fixed, addv, r, partials, partial_off, done, remap)
+  do {                                                                                                               \
+    if (ev0 || ev1)                                                                                                  \
+      hipExtLaunchKernelGGL((k_spmv<DOTS, 4, 1, CIDX, VT, PAIR>), dim3(grid), dim3(256), 0, st, ev0, ev1, 0, n_launch, \
+                            chunk, slice_list, h->n_own, p.slice_ptr.p, p.cols.p, C16, p.win_base.p, p.win_ok.p,     \
+                            p.diag_k.p, VPTR, x, y, fixed, addv, r, partials, partial_off, done, remap);             \
+    else                                                                                                             \
+      hipLaunchKernelGGL((k_spmv<DOTS, 4, 1, CIDX, VT, PAIR>), dim3(grid), dim3(256), 0, st, n_launch, chunk,         \
+                         slice_list, h->n_own, p.slice_ptr.p, p.cols.p, C16, p.win_base.p, p.win_ok.p, p.diag_k.p,   \
+                         VPTR, x, y, fixed, addv, r, partials, partial_off, done, remap);                            \
+  } while (0)
 #define GL_SPMV3(DOTS, CIDX)                                                                                         \
   do {                                                                                                               \
     if (pair && vals32) GL_SPMV4(DOTS, 1, float, 1, vals32, p.cols16p.p);                                            \
@@ -1212,9 +1220,12 @@ void gl_launch_mg_fine(glims_ctx* h, MgHierarchy& mg, int mode, const double* xi
   do {                                                                                                               \
     if (mode == 0) GL_MGF(BS, KB, 0); else if (mode == 1) GL_MGF(BS, KB, 1); else GL_MGF(BS, KB, 2);                 \
   } while (0)
+  const bool timed = &mg == &h->mg && mode != 2 && h->timing(glims_ctx::TK_MGFINE);
+  if (timed) h->tick(glims_ctx::TK_MGFINE);
   if (mg.bs == 1) GL_MGFM(1, 8);
   else if (mg.bs == 2) GL_MGFM(2, 2);
   else GL_MGFM(3, 2);
+  if (timed) h->tick(glims_ctx::TK_MGFINE);
 #undef GL_MGFM
 #undef GL_MGF
 #undef GL_MGF2

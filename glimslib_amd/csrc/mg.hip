@@ -1730,63 +1730,17 @@ void mg_apply_t(glims_ctx* h, MgHierarchy& mg, int deg, const double* r, double*
   }
 }
 
-// One application = a fixed sequence of launches with fixed arguments (given r, u, the degree and the smoothers' interval):
-// captured once into a hipGraph and replayed.  The small grids' kernels run 3-9 us each, and launched one by one the host
-// cannot enqueue them as fast as the device retires them (5-6 us of idle device between two of them, more than their own
-// run time: profiles/r03_rdmg46_gaps.txt); replayed from a graph the dependent launches follow each other at the
-// device's own pace.  Not in partitioned runs whose cycle contains host callbacks or collectives.
-struct MgGraphKey {
-  const void *r, *u, *done, *pv;
-  int deg;
-  double ratio;
-  bool operator==(const MgGraphKey& o) const {
-    return r == o.r && u == o.u && done == o.done && pv == o.pv && deg == o.deg && ratio == o.ratio;
-  }
-};
-
 template <int D, int BS>
-void mg_apply_graphed(glims_ctx* h, MgHierarchy& mg, int deg, const double* r, double* u, const int* done, double* pv) {
+void mg_apply_cycle(glims_ctx* h, MgHierarchy& mg, int deg, const double* r, double* u, const int* done, double* pv) {
   // the smoothers' interval follows the options of the moment (no rebuild: the eigenvalue estimates do not depend on it)
   // (defaults, measured: elasticity 30 on lattice meshes / 10 on general ones with degree 3; the scalar RD hierarchy 10
   // with degree 1 -- tools/run_rd_precond.py)
   mg.cheb_ratio = h->opt.mg_cheb_ratio > 1.0 ? h->opt.mg_cheb_ratio : (mg.bs == 1 ? 10.0 : mg.lattice ? 30.0 : 10.0);
   mg.cycles++;
-  const bool graphable = h->world <= 1 && (h->opt.flags & GLIMS_FLAG_NO_GRAPHS) == 0;
-  if (!graphable) {
-    mg_apply_t<D, BS>(h, mg, deg, r, u, done, pv);
-    return;
-  }
-  const MgGraphKey key{r, u, done, pv, deg, mg.cheb_ratio};
-  for (const MgHierarchy::Graph& g : mg.graphs)
-    if (std::memcmp(&g.key, &key, sizeof(key)) == 0) {
-      GL_HIP(hipGraphLaunch((hipGraphExec_t)g.exec, h->st));
-      return;
-    }
-  static_assert(sizeof(MgGraphKey) <= sizeof(MgHierarchy::Graph::key), "graph key does not fit");
-  hipGraph_t graph = nullptr;
-  GL_HIP(hipStreamBeginCapture(h->st, hipStreamCaptureModeThreadLocal));
-  try {
-    mg_apply_t<D, BS>(h, mg, deg, r, u, done, pv);
-  } catch (...) {
-    (void)hipStreamEndCapture(h->st, &graph);
-    if (graph) (void)hipGraphDestroy(graph);
-    throw;
-  }
-  GL_HIP(hipStreamEndCapture(h->st, &graph));
-  hipGraphExec_t exec = nullptr;
-  const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-  (void)hipGraphDestroy(graph);
-  if (e != hipSuccess) throw glims_error(GLIMS_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
-  if (mg.graphs.size() >= 8) {   // (r, u) pairs of one solver are few; a caller that keeps changing them just re-captures
-    (void)hipGraphExecDestroy((hipGraphExec_t)mg.graphs.front().exec);
-    mg.graphs.erase(mg.graphs.begin());
-  }
-  MgHierarchy::Graph g;
-  std::memset(&g.key, 0, sizeof(g.key));
-  std::memcpy(&g.key, &key, sizeof(key));
-  g.exec = exec;
-  mg.graphs.push_back(g);
-  GL_HIP(hipGraphLaunch(exec, h->st));
+  // (Replaying the cycle -- or whole Krylov iterations -- from a captured hipGraph was built and measured in round 3: no
+  //  gain at any size, 1.99 vs 1.88 ms per step on config C2, 4.37 vs 4.34 at 1 M rows, C5 12.15 vs 12.07: the idle time
+  //  between dependent kernels is the write-back of the predecessor's dirty lines, not launch latency.)
+  mg_apply_t<D, BS>(h, mg, deg, r, u, done, pv);
 }
 
 }  // namespace
@@ -1806,15 +1760,10 @@ void gl_mg_apply(glims_ctx* h, MgHierarchy& mg, int degree, const double* r, dou
   GL_REQUIRE(mg.ready, "multigrid hierarchy not built");
   const int deg = std::max(1, std::min(8, degree));
   if (h->dim == 2) {
-    if (mg.bs == 1) mg_apply_graphed<2, 1>(h, mg, deg, r, u, done, pv);
-    else mg_apply_graphed<2, 2>(h, mg, deg, r, u, done, pv);
+    if (mg.bs == 1) mg_apply_cycle<2, 1>(h, mg, deg, r, u, done, pv);
+    else mg_apply_cycle<2, 2>(h, mg, deg, r, u, done, pv);
   } else {
-    if (mg.bs == 1) mg_apply_graphed<3, 1>(h, mg, deg, r, u, done, pv);
-    else mg_apply_graphed<3, 3>(h, mg, deg, r, u, done, pv);
+    if (mg.bs == 1) mg_apply_cycle<3, 1>(h, mg, deg, r, u, done, pv);
+    else mg_apply_cycle<3, 3>(h, mg, deg, r, u, done, pv);
   }
-}
-
-void MgHierarchy::drop_graphs() {
-  for (Graph& g : graphs) (void)hipGraphExecDestroy((hipGraphExec_t)g.exec);
-  graphs.clear();
 }

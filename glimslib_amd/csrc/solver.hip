@@ -885,8 +885,12 @@ static void apply_with_halo(glims_ctx* h, const CgVecs& v) {
       hipEvent_t* ev = h->timing(glims_ctx::TK_SPMV) ? h->pair(glims_ctx::TK_SPMV) : nullptr;
       gl_launch_spmv(h, h->st, p.n_slices, nullptr, v.vals, v.u, v.w, v.fixed, nullptr, v.r, h->partials.p, 0,
                      h->done.p, v.vals32, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr);
-    } else
+    } else {
+      const bool timed = h->timing(glims_ctx::TK_SPMVB);
+      if (timed) h->tick(glims_ctx::TK_SPMVB);
       gl_launch_spmv_block(h, h->st, p.n_slices, nullptr, v.u, v.w, v.fixed, v.r, h->partials.p, 0, h->done.p, v.k32);
+      if (timed) h->tick(glims_ctx::TK_SPMVB);
+    }
     return;
   }
   // interior slices overlap with the xGMI transfer; boundary slices run once the ghosts have landed
@@ -954,27 +958,28 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
   const int batch = h->opt.check_every > 0 ? h->opt.check_every : 8;
   int enq = 0;
   double* info_dev = h->scal.p + 2 * SC_COUNT;
+  auto iteration = [&](int parity) {   // one Krylov iteration: operator, reduction, recurrence + vector update, M^-1
+    const double* prev = h->scal.p + parity * SC_COUNT;
+    double* cur = h->scal.p + (parity ^ 1) * SC_COUNT;
+    apply_with_halo(h, v);
+    // gamma / rr partials: one pair per block of the previous vector kernel; delta: one per SpMV block
+    hipLaunchKernelGGL(k_reduce_cg, dim3(1), dim3(1024), 0, h->st, nblocks, h->partials.p, nvp, h->partials_v.p,
+                       h->red.p, h->done.p, h->nm);
+    allreduce_sum(h, h->red.p, 3);
+    const bool timed_upd = v.vals && h->timing(glims_ctx::TK_UPDATE);
+    if (timed_upd) h->tick(glims_ctx::TK_UPDATE);
+    GL_VEC(k_cg_update, n, h->red.p, prev, cur, info_dev, h->done.p, tol2, v.p, v.s, v.x, v.r, v.u, v.w, v.dinv,
+           h->partials_v.p, /*nt=*/0, pm, ext);
+    if (timed_upd) h->tick(glims_ctx::TK_UPDATE);
+    precondition();
+  };
   while (enq < maxit + 1) {
     int want = batch;
     // (deferred: one spare iteration with the Jacobi scaling, none with a V-cycle per iteration -- an iteration enqueued
     //  behind the decision word still costs its ~25 launches, and the residual test of the Newton iteration decides anyway)
     if (hint > 0) want = enq == 0 ? hint + (defer && !ext ? 2 : 1) : std::max(2, std::min(batch, hint / 4 + 1));
     const int nb = std::min(want, maxit + 1 - enq);
-    for (int j = 0; j < nb; ++j) {
-      const double* prev = h->scal.p + ((enq + j) & 1) * SC_COUNT;
-      double* cur = h->scal.p + ((enq + j + 1) & 1) * SC_COUNT;
-      apply_with_halo(h, v);
-      // gamma / rr partials: one pair per block of the previous vector kernel; delta: one per SpMV block
-      hipLaunchKernelGGL(k_reduce_cg, dim3(1), dim3(1024), 0, h->st, nblocks, h->partials.p, nvp, h->partials_v.p,
-                         h->red.p, h->done.p, h->nm);
-      allreduce_sum(h, h->red.p, 3);
-      const bool timed_upd = v.vals && h->timing(glims_ctx::TK_UPDATE);
-      if (timed_upd) h->tick(glims_ctx::TK_UPDATE);
-      GL_VEC(k_cg_update, n, h->red.p, prev, cur, info_dev, h->done.p, tol2, v.p, v.s, v.x, v.r, v.u, v.w, v.dinv,
-             h->partials_v.p, /*nt=*/0, pm, ext);
-      if (timed_upd) h->tick(glims_ctx::TK_UPDATE);
-      precondition();
-    }
+    for (int j = 0; j < nb; ++j) iteration((enq + j) & 1);
     enq += nb;
     if (defer && hint > 0) {
       *its_out = -1;
@@ -1036,6 +1041,48 @@ static void rd_sweep(glims_ctx* h, const double* b2, double* norms /*[2]*/, Mail
   h->stats.rd_assemblies++;
 }
 
+void glims_ctx::timing_begin() {
+  if (opt.time_kernels && tev.empty()) {
+    tev.resize(16384);
+    tev_cat.assign(tev.size() / 2, 0);
+    for (hipEvent_t& e : tev) GL_HIP(hipEventCreate(&e));
+  }
+  tev_used = 0;
+}
+
+void glims_ctx::timing_collect() {
+  if (tev_used < 2) return;
+  // launches that the decision word turned into no-ops last a few microseconds: leave them out of sums and medians
+  std::vector<float> d[TK_COUNT];
+  for (size_t q = 0; q < tev_used / 2; ++q) {
+    float t = 0.f;
+    GL_HIP(hipEventElapsedTime(&t, tev[2 * q], tev[2 * q + 1]));
+    d[std::min<int>(TK_COUNT - 1, tev_cat[q])].push_back(t);
+  }
+  double* sums[TK_COUNT] = {&stats.ms_spmv_steps, &stats.ms_sweep_steps, &stats.ms_update_steps, &stats.ms_mgfine_mech,
+                            &stats.ms_spmvb_mech};
+  int64_t* cnts[TK_COUNT] = {&stats.n_spmv_steps, &stats.n_sweep_steps, &stats.n_update_steps, &stats.n_mgfine_mech,
+                             &stats.n_spmvb_mech};
+  double* meds[TK_COUNT] = {&stats.us_spmv_median, &stats.us_sweep_median, &stats.us_update_median,
+                            &stats.us_mgfine_median, &stats.us_spmvb_median};
+  for (int c = 0; c < TK_COUNT; ++c) {
+    float dmax = 0.f;
+    for (float t : d[c]) dmax = std::max(dmax, t);
+    std::vector<float> real;
+    for (float t : d[c])
+      if (t > 0.2f * dmax) real.push_back(t);
+    for (float t : real) {
+      *sums[c] += t;
+      ++*cnts[c];
+    }
+    if (!real.empty()) {
+      std::nth_element(real.begin(), real.begin() + real.size() / 2, real.end());
+      *meds[c] = 1e3 * real[real.size() / 2];
+    }
+  }
+  tev_used = 0;
+}
+
 int gl_step(glims_ctx* h, int n_steps) {
   GL_REQUIRE(h->is_setup, "glims_step before glims_setup");
   GL_REQUIRE(h->have_state, "glims_step before glims_set_state");
@@ -1045,12 +1092,7 @@ int gl_step(glims_ctx* h, int n_steps) {
   const bool extrapolate = (o.flags & GLIMS_FLAG_EXTRAPOLATE_GUESS) != 0;
   const double* load = h->have_load_rd ? h->load_rd.p : nullptr;
   int status = GLIMS_OK;
-  if (h->opt.time_kernels && h->tev.empty()) {
-    h->tev.resize(16384);
-    h->tev_cat.assign(h->tev.size() / 2, 0);
-    for (hipEvent_t& e : h->tev) GL_HIP(hipEventCreate(&e));
-  }
-  h->tev_used = 0;
+  h->timing_begin();
   if (h->rd_precond_active == 0) gl_rd_choose_precond(h);
   bool rd_mg = h->rd_precond_active == GLIMS_RD_PRECOND_MULTIGRID;
   if (rd_mg && !h->mg_rd.ready) gl_mg_setup_rd(h);
@@ -1187,34 +1229,7 @@ int gl_step(glims_ctx* h, int n_steps) {
   GL_HIP(hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
   h->stats.ms_steps += ms;
   h->stats.rd_mg_cycles += h->mg_rd.cycles - rd_cycles0;
-  if (h->tev_used >= 2) {
-    // launches that the decision word turned into no-ops last a few microseconds: leave them out of sums and medians
-    std::vector<float> d[3];
-    for (size_t q = 0; q < h->tev_used / 2; ++q) {
-      float t = 0.f;
-      GL_HIP(hipEventElapsedTime(&t, h->tev[2 * q], h->tev[2 * q + 1]));
-      d[std::min<int>(2, h->tev_cat[q])].push_back(t);
-    }
-    double* sums[3] = {&h->stats.ms_spmv_steps, &h->stats.ms_sweep_steps, &h->stats.ms_update_steps};
-    int64_t* cnts[3] = {&h->stats.n_spmv_steps, &h->stats.n_sweep_steps, &h->stats.n_update_steps};
-    double* meds[3] = {&h->stats.us_spmv_median, &h->stats.us_sweep_median, &h->stats.us_update_median};
-    for (int c = 0; c < 3; ++c) {
-      float dmax = 0.f;
-      for (float t : d[c]) dmax = std::max(dmax, t);
-      std::vector<float> real;
-      for (float t : d[c])
-        if (t > 0.2f * dmax) real.push_back(t);
-      for (float t : real) {
-        *sums[c] += t;
-        ++*cnts[c];
-      }
-      if (!real.empty()) {
-        std::nth_element(real.begin(), real.begin() + real.size() / 2, real.end());
-        *meds[c] = 1e3 * real[real.size() / 2];
-      }
-    }
-    h->tev_used = 0;
-  }
+  h->timing_collect();
   return status;
 }
 
@@ -1263,6 +1278,7 @@ int gl_solve_mechanics(glims_ctx* h, const double* c_dev) {
   const int mh_depth = std::max(0, std::min((int)glims_ctx::MHIST, h->opt.mech_history));
   if (h->mh_next >= std::max(1, mh_depth)) h->mh_count = h->mh_next = 0;   // the depth option shrank
   const double t_wall0 = omp_get_wtime();
+  if (h->opt.time_kernels == 3) h->timing_begin();
   // preconditioner of the constrained operator: one multigrid V-cycle (built on first use, K_el does not change in
   // time) or block-Jacobi
   const bool use_mg = h->opt.mech_precond == GLIMS_PRECOND_MULTIGRID;
@@ -1490,6 +1506,7 @@ int gl_solve_mechanics(glims_ctx* h, const double* c_dev) {
   gl_halo_exchange(h, h->U.p, bs);
   GL_HIP(hipStreamSynchronize(h->st));
   h->stats.ms_mech += 1e3 * (omp_get_wtime() - t_wall0);
+  if (h->opt.time_kernels == 3) h->timing_collect();
   return cs;
 }
 

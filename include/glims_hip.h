@@ -88,8 +88,9 @@ typedef struct glims_options {
   double mg_cheb_ratio;   /* the Chebyshev smoothers act on [lambda_max / ratio, lambda_max] of Dinv A;
                              0 = by mesh class: 30 on lattice meshes, 10 on general ones (measured)  default 0     */
   int    time_kernels;    /* HIP-event pairs on the handle's stream around hot kernels of glims_step: 1 = the Krylov
-                             SpMV, 2 = also the assembly sweep and the PCG vector update; results in
-                             glims_stats.*_steps / us_*_median (bench.py's in-step roofline figures)  default 0     */
+                             SpMV, 2 = also the assembly sweep and the PCG vector update; 3 = instead the level-0
+                             multigrid pass and the block SpMV of glims_solve_mechanics; results in glims_stats.*_steps / *_mech /
+                             us_*_median (bench.py's roofline figures)                                default 0     */
   /* ---- ABI 3: preconditioner of the RD linear solves.  The reference's LU does not care how stiff a step is
    * (simulation_tumor_growth.py:126-130); Jacobi-PCG needs ~sqrt(2 dt D / h^2 ...) iterations per Newton solve, e.g.
    * 66 / 129 on the unit cube with D = 0.1, dt = 1 at n = 32 / 64 (BASELINE config C2 is such a case), 4-5 on the
@@ -131,8 +132,6 @@ typedef struct glims_options {
                                            preconditioned residual handed to the Krylov solver is double either way */
 #define GLIMS_FLAG_INT32_COLUMNS 16       /* OFF by default.  Stream the 4-byte column indices everywhere instead of the 16-bit
                                            (window, offset) codes (same bits in every result; takes effect at glims_setup) */
-#define GLIMS_FLAG_NO_GRAPHS 64          /* OFF by default.  The V-cycles are launched kernel by kernel instead of being replayed
-                                           from a captured hipGraph (A/B measurements, debugging; same bits either way) */
 #define GLIMS_FLAG_WARM_START 2         /* first linear solve of a step starts from the previous step's increment
                                            (ignored when GLIMS_FLAG_EXTRAPOLATE_GUESS is set) */
 
@@ -178,6 +177,13 @@ typedef struct glims_stats {
   int64_t rd_mg_cycles;     /* V-cycles applied inside glims_step */
   double  rd_mg_complexity; /* stored operator entries of all levels / entries of S */
   double  ms_rd_mg_setup;   /* wall time of the last set-up of the RD hierarchy */
+  /* time_kernels = 3 only: the two dominant kernels of glims_solve_mechanics (HIP events, eager launches) */
+  double  ms_mgfine_mech;   /* level-0 passes of the elasticity multigrid (k_mg_fine) */
+  int64_t n_mgfine_mech;
+  double  us_mgfine_median;
+  double  ms_spmvb_mech;    /* block SpMV of the Krylov iteration (k_spmv_block2) */
+  int64_t n_spmvb_mech;
+  double  us_spmvb_median;
 } glims_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------------------- */

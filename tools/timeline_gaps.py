@@ -43,8 +43,8 @@ def main():
     print("gaps (total ms, count, median us):")
     for k, v in sorted(gap_after.items(), key=lambda kv: -sum(kv[1]))[:16]:
         v = np.array(v)
-        print("  %-60s %8.2f ms %6d  med %6.1f us  max %8.1f us" % (k, v.sum() / 1e6, len(v), np.median(v) / 1e3,
-                                                                   v.max() / 1e3))
+        print("  %-60s %8.2f ms %6d  med %6.1f us  p90 %6.1f us  max %8.1f us" %
+              (k, v.sum() / 1e6, len(v), np.median(v) / 1e3, np.percentile(v, 90) / 1e3, v.max() / 1e3))
 
 
 if __name__ == '__main__':
