@@ -93,6 +93,8 @@ SIGNATURES = {
     "glims_reset_stats": (C.c_int, [_h]),
     "glims_apply": (C.c_int, [_h, C.c_int, _dp, _dp, C.c_int, _dp]),
     "glims_rd_residual": (C.c_int, [_h, _dp, _dp, _dp]),
+    "glims_get_numbering": (C.c_int, [_h, _i32p]),
+    "glims_pattern_checksum": (C.c_int, [_h, C.POINTER(C.c_uint64)]),
     "glims_snapshot_save": (C.c_int, [_h, _i64p]),
     "glims_snapshot_load": (C.c_int, [_h, C.c_int64, _dp]),
     "glims_snapshot_mechanics": (C.c_int, [_h, C.c_int64, _dp]),
@@ -267,6 +269,18 @@ class Handle:
         R = np.empty(self.n_nodes)
         self._check(self.lib.glims_rd_residual(self._h, _ptr(c, _dp), _ptr(cp, _dp), _ptr(R, _dp)))
         return R
+
+    def numbering(self):
+        """old2new: internal index of every node of the caller's numbering."""
+        a = np.empty(self.n_nodes, dtype=np.int32)
+        self._check(self.lib.glims_get_numbering(self._h, _ptr(a, _i32p)))
+        return a
+
+    def pattern_checksum(self):
+        """Twelve 64-bit hashes of the device-resident discretisation structures (see glims_pattern_checksum)."""
+        a = (C.c_uint64 * 12)()
+        self._check(self.lib.glims_pattern_checksum(self._h, a))
+        return [int(v) for v in a]
 
     def snapshot_save(self):
         sid = C.c_int64(-1)

@@ -58,6 +58,17 @@ void from_device_perm(glims_ctx* h, const double* src, double* host, int bs, int
   GL_HIP(hipStreamSynchronize(h->st));
 }
 
+template <class T>
+uint64_t fnv_of(glims_ctx* h, const T* dev, size_t n) {
+  std::vector<T> host(n);
+  if (n) GL_HIP(hipMemcpyAsync(host.data(), dev, n * sizeof(T), hipMemcpyDeviceToHost, h->st));
+  GL_HIP(hipStreamSynchronize(h->st));
+  uint64_t x = 1469598103934665603ull;
+  const unsigned char* b = reinterpret_cast<const unsigned char*>(host.data());
+  for (size_t i = 0; i < n * sizeof(T); ++i) x = (x ^ b[i]) * 1099511628211ull;
+  return x;
+}
+
 template <class F>
 int guarded(glims_ctx* h, F&& f) {
   if (!h) return GLIMS_E_USAGE;
@@ -157,64 +168,75 @@ int glims_create(glims_ctx** out, int dim, int64_t n_nodes, int64_t n_own, int64
       fprintf(stderr, "glims create: %-43s %7.3f s\n", what, t - t_last);
       t_last = t;
     };
-    HostPattern hp;
-    build_host_pattern(hp, dim, n_nodes, n_own, n_cells, xyz, cells);
-    lap("host pattern (total)");
-    gl_mesh_metrics(h, hp, xyz);
-    lap("mesh metrics (lattice test, edge lengths)");
-    h->old2new = hp.old2new;
-    h->new2old = hp.new2old;
-    h->nnz = hp.nnz;
-    h->n_corners = hp.n_corners;
-
+    // caller's mesh to the device: the symbolic phase and the per-cell geometry read it there; coordinates and
+    // connectivity in the caller's numbering are not kept
+    dvec<double> d_xyz;
+    dvec<int32_t> d_cells;
+    d_xyz.upload(xyz, (size_t)n_nodes * dim, h->st);
+    d_cells.upload(cells, (size_t)n_cells * (dim + 1), h->st);
     DevPattern& p = h->pat;
-    p.n_slices = hp.n_slices;
-    p.max_len = hp.max_len;
-    p.max_clen = hp.max_clen;
-    p.total_entries = hp.slice_ptr[hp.n_slices];
-    p.total_corners = hp.cslice_ptr[hp.n_slices];
-    p.slice_ptr.upload(hp.slice_ptr, h->st);
-    p.cols.upload(hp.cols, h->st);
-    p.cols16.upload(hp.cols16, h->st);
-    p.win_base.upload(hp.win_base, h->st);
-    p.win_ok.upload(hp.win_ok, h->st);
-    p.diag_k.upload(hp.diag_k, h->st);
-    p.cslice_ptr.upload(hp.cslice_ptr, h->st);
-    p.cslots.upload(hp.cslots, h->st);
-    p.celem.upload(hp.celem, h->st);
-    p.interior_slices.upload(hp.interior_slices, h->st);
-    p.boundary_slices.upload(hp.boundary_slices, h->st);
-    p.n_interior = (int32_t)hp.interior_slices.size();
-    p.n_boundary = (int32_t)hp.boundary_slices.size();
-    h->d_old2new.upload(hp.old2new, h->st);
-    for (size_t b = 0; b < hp.bucket_cap.size(); ++b) {
-      if (hp.bucket_slices[b].empty()) continue;
-      // LDS of the class = its actual longest slice, not the class bound (16 rows x 1 KB would be exactly 1/10 of
-      // the CU's LDS and fit only 9 times; the structured meshes' 15 fits 10 times)
-      int cap = 1;
-      for (int32_t sl : hp.bucket_slices[b])
-        cap = std::max(cap, (int)((hp.slice_ptr[sl + 1] - hp.slice_ptr[sl]) / GL_WAVE));
-      p.bucket_cap.push_back(cap);
-      p.bucket_count.push_back((int32_t)hp.bucket_slices[b].size());
-      p.bucket_interior.push_back(hp.bucket_interior[b]);
-      auto* dv = new dvec<int32_t>();
-      dv->upload(hp.bucket_slices[b], h->st);
-      p.bucket_slices.push_back(dv);
+    if (getenv("GLIMS_HOST_SYMBOLIC")) {   // TEST HOOK: the host implementation of the same phase (setup_host.cpp)
+      HostPattern hp;
+      build_host_pattern(hp, dim, n_nodes, n_own, n_cells, xyz, cells);
+      lap("host pattern (total)");
+      gl_mesh_metrics(h, hp, xyz);
+      lap("mesh metrics (lattice test, edge lengths)");
+      h->old2new = hp.old2new;
+      h->new2old = hp.new2old;
+      h->nnz = hp.nnz;
+      h->n_corners = hp.n_corners;
+      p.n_slices = hp.n_slices;
+      p.max_len = hp.max_len;
+      p.max_clen = hp.max_clen;
+      p.total_entries = hp.slice_ptr[hp.n_slices];
+      p.total_corners = hp.cslice_ptr[hp.n_slices];
+      p.slice_ptr.upload(hp.slice_ptr, h->st);
+      p.cols.upload(hp.cols, h->st);
+      p.cols16.upload(hp.cols16, h->st);
+      p.win_base.upload(hp.win_base, h->st);
+      p.win_ok.upload(hp.win_ok, h->st);
+      p.diag_k.upload(hp.diag_k, h->st);
+      p.cslice_ptr.upload(hp.cslice_ptr, h->st);
+      p.cslots.upload(hp.cslots, h->st);
+      p.celem.upload(hp.celem, h->st);
+      p.interior_slices.upload(hp.interior_slices, h->st);
+      p.boundary_slices.upload(hp.boundary_slices, h->st);
+      p.n_interior = (int32_t)hp.interior_slices.size();
+      p.n_boundary = (int32_t)hp.boundary_slices.size();
+      h->d_old2new.upload(hp.old2new, h->st);
+      for (size_t b = 0; b < hp.bucket_cap.size(); ++b) {
+        if (hp.bucket_slices[b].empty()) continue;
+        // LDS of the class = its actual longest slice, not the class bound (16 rows x 1 KB would be exactly 1/10 of
+        // the CU's LDS and fit only 9 times; the structured meshes' 15 fits 10 times)
+        int cap = 1;
+        for (int32_t sl : hp.bucket_slices[b])
+          cap = std::max(cap, (int)((hp.slice_ptr[sl + 1] - hp.slice_ptr[sl]) / GL_WAVE));
+        p.bucket_cap.push_back(cap);
+        p.bucket_count.push_back((int32_t)hp.bucket_slices[b].size());
+        p.bucket_interior.push_back(hp.bucket_interior[b]);
+        auto* dv = new dvec<int32_t>();
+        dv->upload(hp.bucket_slices[b], h->st);
+        p.bucket_slices.push_back(dv);
+      }
+      for (int32_t sl = 0; sl < hp.n_slices; ++sl)
+        if (hp.win_ok[sl]) h->nnz_idx16_avail += hp.slice_ptr[sl + 1] - hp.slice_ptr[sl];
+      lap("pattern upload");
+    } else {
+      gl_build_pattern_device(h, d_xyz.p, d_cells.p);
+      // (the multigrid set-up still lays its first grid over host coordinates)
+      h->mm.xyz.resize((size_t)n_nodes * dim);
+      GL_HIP(hipMemcpyAsync(h->mm.xyz.data(), h->xyz_new.p, h->mm.xyz.size() * sizeof(double), hipMemcpyDeviceToHost, h->st));
+      GL_HIP(hipStreamSynchronize(h->st));
+      h->xyz_new.release();
+      lap("symbolic phase on the device (total)");
     }
-
-    lap("pattern upload");
     std::vector<uint8_t> lab(n_cells);
     for (int64_t e = 0; e < n_cells; ++e) lab[e] = (uint8_t)cell_label[e];
     h->label.upload(lab, h->st);
-
-    {   // per-cell geometry from the caller's numbering; coordinates and connectivity are not kept on the device
-      dvec<double> d_xyz;
-      dvec<int32_t> d_cells;
-      d_xyz.upload(xyz, (size_t)n_nodes * dim, h->st);
-      d_cells.upload(cells, (size_t)n_cells * (dim + 1), h->st);
-      gl_compute_egeo(h, d_xyz.p, d_cells.p);
-      GL_HIP(hipStreamSynchronize(h->st));
-    }
+    gl_compute_egeo(h, d_xyz.p, d_cells.p);
+    GL_HIP(hipStreamSynchronize(h->st));
+    d_xyz.release();
+    d_cells.release();
 
     lap("labels, geometry");
     const size_t nn = (size_t)n_nodes, nd = (size_t)n_nodes * dim;
@@ -241,11 +263,9 @@ int glims_create(glims_ctx** out, int dim, int64_t n_nodes, int64_t n_own, int64
     GL_HIP(hipStreamSynchronize(h->st));
 
     h->stats.n_rows = n_own;
-    h->stats.nnz = hp.nnz;
+    h->stats.nnz = h->nnz;
     h->stats.nnz_padded = p.total_entries;
-    h->stats.n_corners = hp.n_corners;
-    for (int32_t sl = 0; sl < hp.n_slices; ++sl)
-      if (hp.win_ok[sl]) h->nnz_idx16_avail += hp.slice_ptr[sl + 1] - hp.slice_ptr[sl];
+    h->stats.n_corners = h->n_corners;
     h->stats.nnz_idx16 = h->nnz_idx16_avail;
     *out = h;
     return GLIMS_OK;
@@ -603,6 +623,34 @@ int glims_rd_residual(glims_ctx* h, const double* c, const double* c_prev, doubl
       from_device_perm(h, h->cg_r.p, R, 1, h->n_own);
       for (int64_t i = 0; i < h->n_nodes; ++i) R[i] = -R[i];   // the kernel stores -R (the Newton right-hand side)
     }
+    return GLIMS_OK;
+  });
+}
+
+int glims_get_numbering(glims_ctx* h, int32_t* old2new) {
+  return guarded(h, [&]() {
+    GL_REQUIRE(old2new, "null output");
+    std::memcpy(old2new, h->old2new.data(), (size_t)h->n_nodes * sizeof(int32_t));
+    return GLIMS_OK;
+  });
+}
+
+int glims_pattern_checksum(glims_ctx* h, uint64_t out[12]) {
+  return guarded(h, [&]() {
+    GL_REQUIRE(out, "null output");
+    const DevPattern& p = h->pat;
+    out[0] = fnv_of(h, p.slice_ptr.p, (size_t)p.n_slices + 1);
+    out[1] = fnv_of(h, p.cols.p, (size_t)p.total_entries);
+    out[2] = fnv_of(h, p.cols16.p, (size_t)p.total_entries);
+    out[3] = fnv_of(h, p.win_base.p, (size_t)p.n_slices * GL_N_WIN);
+    out[4] = fnv_of(h, p.win_ok.p, (size_t)p.n_slices);
+    out[5] = fnv_of(h, p.diag_k.p, (size_t)p.n_slices * GL_WAVE);
+    out[6] = fnv_of(h, p.cslice_ptr.p, (size_t)p.n_slices + 1);
+    out[7] = fnv_of(h, p.cslots.p, (size_t)p.total_corners);
+    out[8] = fnv_of(h, p.celem.p, (size_t)p.total_corners);
+    out[9] = fnv_of(h, p.interior_slices.p, (size_t)p.n_interior);
+    out[10] = fnv_of(h, p.boundary_slices.p, (size_t)p.n_boundary);
+    out[11] = fnv_of(h, h->d_old2new.p, (size_t)h->n_nodes);
     return GLIMS_OK;
   });
 }

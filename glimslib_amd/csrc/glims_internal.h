@@ -113,6 +113,9 @@ struct HostPattern {
   int64_t nnz = 0, n_corners = 0;
 };
 
+struct glims_ctx;
+// symbolic.hip: the same phase on the device (the default; the host version above stays as its cross-check)
+void gl_build_pattern_device(glims_ctx* h, const double* d_xyz, const int32_t* d_cells);
 int gl_host_threads();   // OpenMP team the host phases may use (affinity mask, cgroup quota, ranks per host)
 void build_host_pattern(HostPattern& hp, int dim, int64_t n_nodes, int64_t n_own, int64_t n_cells,
                         const double* xyz, const int32_t* cells);
@@ -344,6 +347,7 @@ struct glims_ctx {
 
   std::vector<int32_t> old2new, new2old;
   dvec<int32_t> d_old2new;
+  dvec<double> xyz_new;                     // coordinates in the internal numbering [n_nodes][dim] (device-side symbolic phase)
   DevPattern pat;
   int64_t nnz = 0, n_corners = 0;
 

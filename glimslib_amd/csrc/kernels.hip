@@ -110,23 +110,33 @@ __global__ void k_corner_weights(int64_t n, const int32_t* __restrict__ celem, c
 // ---------------------------------------------------------------------------------------------------
 // static assembly: one scalar plane of one operator per launch (setup path, not timed per step)
 // ---------------------------------------------------------------------------------------------------
-enum { MODE_M = 0, MODE_S = 1, MODE_KEL = 2, MODE_G = 3 };
+enum { MODE_M = 0, MODE_KEL = 2, MODE_G = 3 };   // MODE_M: the two scalar planes M and S together
 
-template <int D>
+// NP planes per launch, all from ONE walk over the row's (row, cell) incidences: {M, S}, the D blocks K_el(ca, 0..D-1) of
+// one block row, or the D components of G.  (Until round 3 every plane was a launch of its own, 14 with mechanics in 3-D,
+// and each re-read the incidence records and -- through cell ids in the caller's numbering, i.e. with poor locality -- the
+// cells' 104-byte geometry records: 41-83 GB of fetches per plane at 10 M rows, profiles/r02_pmc_c4.json.)  Every plane
+// accumulates the same terms in the same order as before: the operators are bit-identical.
+struct PlaneOut {
+  double* out[3];
+  int stride[3], off[3];
+};
+template <int D, int NP>
 __global__ __launch_bounds__(GL_WAVE) void k_assemble_static(
-    int mode, int ca, int cb, int64_t n_own, const int64_t* __restrict__ slice_ptr,
+    int mode, int ca, int64_t n_own, const int64_t* __restrict__ slice_ptr,
     const int64_t* __restrict__ cslice_ptr, const uint32_t* __restrict__ cslots,
     const int32_t* __restrict__ celem, const uint8_t* __restrict__ diag_k, const double* __restrict__ egeo,
-    const uint8_t* __restrict__ label, const double* __restrict__ mat, double dt, double* __restrict__ out,
-    int ostride, int ooff) {
+    const uint8_t* __restrict__ label, const double* __restrict__ mat, double dt, const PlaneOut po, int max_len) {
   constexpr int NV = D + 1, GE = 1 + NV * D;
   constexpr double mfac = 1.0 / ((D + 1) * (D + 2));
-  extern __shared__ double acc[];
+  extern __shared__ double acc[];   // [NP][max_len][64]
   const int s = blockIdx.x, lane = threadIdx.x;
   const int64_t row = (int64_t)s * GL_WAVE + lane;
   const int64_t base = slice_ptr[s], cbase = cslice_ptr[s];
   const int len = (int)((slice_ptr[s + 1] - base) >> 6), clen = (int)((cslice_ptr[s + 1] - cbase) >> 6);
-  for (int k = 0; k < len; ++k) acc[k * GL_WAVE + lane] = 0.0;
+#pragma unroll
+  for (int pl = 0; pl < NP; ++pl)
+    for (int k = 0; k < len; ++k) acc[(pl * max_len + k) * GL_WAVE + lane] = 0.0;
   const int dk = diag_k[row];
   for (int q = 0; q < clen; ++q) {
     const int64_t ci = cbase + (int64_t)q * GL_WAVE + lane;
@@ -155,20 +165,24 @@ __global__ __launch_bounds__(GL_WAVE) void k_assemble_static(
         gm[a] = g[1 + m * D + a];
         gg += gi[a] * gm[a];
       }
-      double v;
-      if (mode == MODE_M)
-        v = vol * mfac * (m == li ? 2.0 : 1.0);
-      else if (mode == MODE_S)
-        v = (1.0 - dt * rho) * vol * mfac * (m == li ? 2.0 : 1.0) + dt * Dc * vol * gg;
-      else if (mode == MODE_KEL)
-        v = vol * (lam * gi[ca] * gm[cb] + mu * gi[cb] * gm[ca] + (ca == cb ? mu * gg : 0.0));
-      else
-        v = gam * (2.0 * mu + D * lam) * vol * (1.0 / (D + 1)) * gi[ca];
-      acc[k * GL_WAVE + lane] += v;
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) {
+        double v;
+        if (mode == MODE_M)   // planes: 0 = M, 1 = S
+          v = pl == 0 ? vol * mfac * (m == li ? 2.0 : 1.0)
+                      : (1.0 - dt * rho) * vol * mfac * (m == li ? 2.0 : 1.0) + dt * Dc * vol * gg;
+        else if (mode == MODE_KEL)   // plane pl = block entry (ca, cb = pl)
+          v = vol * (lam * gi[ca] * gm[pl] + mu * gi[pl] * gm[ca] + (ca == pl ? mu * gg : 0.0));
+        else                         // plane pl = component ca = pl of G
+          v = gam * (2.0 * mu + D * lam) * vol * (1.0 / (D + 1)) * gi[pl];
+        acc[(pl * max_len + k) * GL_WAVE + lane] += v;
+      }
     }
   }
-  for (int k = 0; k < len; ++k)
-    out[(base + (int64_t)k * GL_WAVE) * ostride + ooff + lane] = acc[k * GL_WAVE + lane];
+#pragma unroll
+  for (int pl = 0; pl < NP; ++pl)
+    for (int k = 0; k < len; ++k)
+      po.out[pl][(base + (int64_t)k * GL_WAVE) * po.stride[pl] + po.off[pl] + lane] = acc[(pl * max_len + k) * GL_WAVE + lane];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -964,14 +978,14 @@ __global__ void k_to_float(int64_t n, const double* __restrict__ a, float* __res
   if (i < n) b[i] = (float)a[i];
 }
 
-template <int D>
-static void assemble_plane(glims_ctx* h, int mode, int ca, int cb, double* out, int ostride, int ooff) {
+template <int D, int NP>
+static void assemble_planes(glims_ctx* h, int mode, int ca, const PlaneOut& po) {
   const DevPattern& p = h->pat;
-  const size_t lds = (size_t)p.max_len * GL_WAVE * sizeof(double);
-  set_lds(k_assemble_static<D>, lds);
-  hipLaunchKernelGGL(k_assemble_static<D>, dim3(p.n_slices), dim3(GL_WAVE), lds, h->st, mode, ca, cb, h->n_own,
+  const size_t lds = (size_t)NP * p.max_len * GL_WAVE * sizeof(double);
+  set_lds(k_assemble_static<D, NP>, lds);
+  hipLaunchKernelGGL((k_assemble_static<D, NP>), dim3(p.n_slices), dim3(GL_WAVE), lds, h->st, mode, ca, h->n_own,
                      p.slice_ptr.p, p.cslice_ptr.p, p.cslots.p, p.celem.p, p.diag_k.p, h->egeo.p, h->label.p,
-                     h->mat.p, h->opt.dt, out, ostride, ooff);
+                     h->mat.p, h->opt.dt, po, p.max_len);
   GL_HIP(hipGetLastError());
 }
 
@@ -982,8 +996,7 @@ static void assemble_static_t(glims_ctx* h, int with_mechanics) {
   h->vM.alloc(ne);
   h->vS.alloc(ne);
   h->vA.alloc(ne);
-  assemble_plane<D>(h, MODE_M, 0, 0, h->vM.p, 1, 0);
-  assemble_plane<D>(h, MODE_S, 0, 0, h->vS.p, 1, 0);
+  assemble_planes<D, 2>(h, MODE_M, 0, PlaneOut{{h->vM.p, h->vS.p, nullptr}, {1, 1, 0}, {0, 0, 0}});
   if (h->pair_A)
     hipLaunchKernelGGL((k_plane_to_pairs<double, double>), dim3(p.n_slices), dim3(GL_WAVE), 0, h->st, p.n_slices,
                        p.slice_ptr.p, h->vS.p, h->vA.p);
@@ -1016,9 +1029,17 @@ static void assemble_static_t(glims_ctx* h, int with_mechanics) {
   if (with_mechanics) {
     h->vKel.alloc(ne * D * D);
     h->vG.alloc(ne * D);
-    for (int a = 0; a < D; ++a)
-      for (int b = 0; b < D; ++b) assemble_plane<D>(h, MODE_KEL, a, b, h->vKel.p, D * D, (a * D + b) * GL_WAVE);
-    for (int a = 0; a < D; ++a) assemble_plane<D>(h, MODE_G, a, 0, h->vG.p, D, a * GL_WAVE);
+    // one launch per block row of K_el (D planes), one for G: 1 + D + 1 launches instead of 2 + D * D + D
+    for (int a = 0; a < D; ++a) {
+      PlaneOut po{{h->vKel.p, h->vKel.p, h->vKel.p}, {D * D, D * D, D * D}, {0, 0, 0}};
+      for (int b = 0; b < D; ++b) po.off[b] = (a * D + b) * GL_WAVE;
+      assemble_planes<D, D>(h, MODE_KEL, a, po);
+    }
+    {
+      PlaneOut po{{h->vG.p, h->vG.p, h->vG.p}, {D, D, D}, {0, 0, 0}};
+      for (int a = 0; a < D; ++a) po.off[a] = a * GL_WAVE;
+      assemble_planes<D, D>(h, MODE_G, 0, po);
+    }
     h->vKel32.release();   // the single-precision copy (mixed-precision solver only) is rebuilt on demand, gl_make_kel32
   }
 }

@@ -24,6 +24,8 @@
  *   GLIMS_VERBOSE        any value: timing lines of the set-up phases on stderr
  *   GLIMS_HOST_THREADS   OpenMP team of the host-side symbolic phase (default: the CPUs this process may use,
  *                        divided by the ranks on the host)
+ *   GLIMS_HOST_SYMBOLIC  TEST HOOK: glims_create runs the host (OpenMP) implementation of the symbolic phase instead of
+ *                        the device one -- same structures, array by array (tests/test_gpu_symbolic.py)
  *   GLIMS_WIN_LIMIT      TEST HOOK: at most this many (<= 32) column windows per 64-row slice before a slice falls back
  *                        to 4-byte column indices -- lets tests/ exercise the mixed 16-bit / 32-bit index path on
  *                        meshes whose slices would all be compressible
@@ -270,6 +272,18 @@ int glims_apply(glims_ctx* h, int which, const double* x, double* y, int reps, d
 /* Assembles A(c) and the Newton residual R(c; c_prev) for host vectors (ghost rows 0):
  *   R = 1/2 (A(c) + S) c - M c_prev - rd_load.  R may be NULL. */
 int glims_rd_residual(glims_ctx* h, const double* c, const double* c_prev, double* R);
+
+/* Diagnostics of the symbolic phase (node renumbering, SELL-64 sparsity, incidence lists, column codes -- built on the
+ * device by glims_create; DOLFIN's counterpart is the dofmap + AIJ preallocation behind fenics.FunctionSpace,
+ * helper_classes.py:271-282).
+ *   glims_get_numbering     old2new[n_nodes]: internal index of the caller's node i (ghosts keep their index)
+ *   glims_pattern_checksum  64-bit FNV-1a hashes of the device arrays, in this order: slice offsets, columns, 16-bit
+ *                           column codes, window bases, window flags, diagonal slots, incidence offsets, incidence slots,
+ *                           incidence cells, interior slice list, boundary slice list, numbering (12 values).  Two handles
+ *                           with equal checksums hold identical discretisation structures (tests compare the device-built
+ *                           structures with the host implementation kept behind the test hook GLIMS_HOST_SYMBOLIC). */
+int glims_get_numbering(glims_ctx* h, int32_t* old2new);
+int glims_pattern_checksum(glims_ctx* h, uint64_t out[12]);
 
 /* ---- device-resident time series ----------------------------------------------------------------------------------
  * Results.add_to_results deep-copies the mixed solution on the host at every recorded step
