@@ -223,11 +223,6 @@ int glims_create(glims_ctx** out, int dim, int64_t n_nodes, int64_t n_own, int64
       lap("pattern upload");
     } else {
       gl_build_pattern_device(h, d_xyz.p, d_cells.p);
-      // (the multigrid set-up still lays its first grid over host coordinates)
-      h->mm.xyz.resize((size_t)n_nodes * dim);
-      GL_HIP(hipMemcpyAsync(h->mm.xyz.data(), h->xyz_new.p, h->mm.xyz.size() * sizeof(double), hipMemcpyDeviceToHost, h->st));
-      GL_HIP(hipStreamSynchronize(h->st));
-      h->xyz_new.release();
       lap("symbolic phase on the device (total)");
     }
     std::vector<uint8_t> lab(n_cells);

@@ -230,7 +230,6 @@ struct MeshMetrics {
   double h_lattice[3] = {0, 0, 0};         // lattice constant per axis if the nodes form a lattice
   bool lattice = false;
   double mean_edge = 0.0;
-  std::vector<double> xyz;                 // all local nodes (owned, then ghosts), internal numbering [n_nodes][dim]
 };
 
 #ifdef __HIPCC__
@@ -505,6 +504,9 @@ void gl_make_kel32(glims_ctx* h);
 void gl_launch_mg_fine(glims_ctx* h, MgHierarchy& mg, int mode, const double* xin, const double* r, double* d,
                        double* xout, double c1, double c2, const int* done = nullptr, double* uout = nullptr,
                        const double* r_full = nullptr, double* pv = nullptr);
+// symbolic.hip: device sort helpers (rocPRIM)
+void gl_sort_pairs_u32(glims_ctx* h, uint32_t* k_in, uint32_t* k_out, int32_t* v_in, int32_t* v_out, size_t n, int end_bit);
+void gl_offsets_of_sorted_keys(glims_ctx* h, const uint32_t* keys_sorted, int64_t n, int64_t n_keys, int32_t* ptr);
 // solver.hip: the two hierarchies
 void gl_mg_setup_mech(glims_ctx* h);
 void gl_mg_setup_rd(glims_ctx* h);

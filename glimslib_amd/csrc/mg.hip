@@ -106,30 +106,142 @@ __global__ void k_mg_reach(int64_t n_own, int64_t n_col, GridDev g1, const int64
   if (n2) atomicAdd(reach + 2, (unsigned long long)n2);
 }
 
-// A1[I, off] = sum_{i child of I} sum_{j in row i, I + off parent of j} w_iI w_j(I+off) F_i K_ij F_j
-// one thread per (grid node, stencil offset): a gather in a fixed order
+// level-1 cell and interpolation weights of every mesh node (internal numbering): cell = floor((x - lo) / H) clamped to
+// the grid, weight towards the cell's upper node per axis; weights within 1e-6 of 0 / 1 are snapped (lattice-aligned nodes:
+// exact weights, compact stencils)
+template <int D>
+__global__ void k_mg_node_cells(int64_t n, const double* __restrict__ xyz, double lo0, double lo1, double lo2, double H0,
+                                double H1, double H2, GridDev g1, int32_t* __restrict__ cell0, double* __restrict__ wgt) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double lo[3] = {lo0, lo1, lo2}, H[3] = {H0, H1, H2};
+  long long lin = 0, stride = 1;
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    const double t = (xyz[i * D + a] - lo[a]) / H[a];
+    int c = (int)floor(t);
+    c = max(0, min(gn(g1, a) - 2, c));
+    double w = t - c;
+    if (fabs(w) < 1e-6) w = 0.0;
+    if (fabs(w - 1.0) < 1e-6) w = 1.0;
+    w = fmax(0.0, fmin(1.0, w));
+    wgt[i * D + a] = w;
+    lin += (long long)c * stride;
+    stride *= gn(g1, a);
+  }
+  cell0[i] = (int32_t)lin;
+}
+__global__ void k_mg_cell_keys(int64_t n, const int32_t* __restrict__ cell0, uint32_t* __restrict__ key,
+                               int32_t* __restrict__ val) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  key[i] = (uint32_t)cell0[i];
+  val[i] = (int32_t)i;
+}
+
+// Galerkin product mesh -> first grid, A1 = P^T K P, in two gathers (no atomics, fixed summation orders).
+//
+// Step 1, T = K P restricted to a box: the parents of the neighbours of mesh node i lie in the (2R + 2)^D grid nodes
+// around i's cell (origin = cell - R); one WAVE per row, lane b owns box node b and walks the row's entries with the
+// wave (broadcast loads), adding w_j,b K_ij where box node b is a parent of column j.  Entries whose parents fall outside
+// the box are exactly the ones outside the stencil: dropped, as before.  T is kept in single precision (the product is
+// stored in single precision anyway), rows [r0, r1) at a time so that its size stays bounded.
+// Step 2, A1[I, off] += sum over the children i of I in [r0, r1) of w_iI T[i][I + off]: a thread per (grid node, stencil
+// offset) walks the explicit restriction operator's entries of I.
+// (Until round 3 one thread per (I, off) walked ALL rows of ALL children of the 2^D cells around I and tested every entry's
+//  parents against I + off: 63x the operator's bytes in fetches, 29 ms at 1 M and 290 ms at 10 M mesh nodes --
+//  profiles/r02_pmc_c5.json.)
 template <int D, int BS>
-__global__ void k_mg_rap0(GridDev g1, int nbx, int nby, int R, int S, int64_t n_own, int64_t n_col,
-                          const int32_t* __restrict__ cell_ptr,
-                          const int32_t* __restrict__ cell_nodes, const int32_t* __restrict__ cell0,
-                          const double* __restrict__ wgt, const int64_t* __restrict__ slice_ptr,
-                          const int32_t* __restrict__ cols, const double* __restrict__ vK,
-                          const uint8_t* __restrict__ fixed, float* __restrict__ A1) {
+__global__ __launch_bounds__(256) void k_mg_kp(GridDev g1, int R, int64_t r0, int64_t r1, int64_t n_col,
+                                                const int32_t* __restrict__ cell0, const double* __restrict__ wgt,
+                                                const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ cols,
+                                                const double* __restrict__ vK, const uint8_t* __restrict__ fixed,
+                                                float* __restrict__ T) {
   constexpr int B2 = BS * BS;
-  // grid nodes in bricks of 4^3 (8^2), the blocks of four bricks in a row on one XCD: the nodes around a cell all
-  // walk the rows of its children (see k_mg_restrict0)
-  constexpr int BW = D == 3 ? 4 : 8;
-  const long long t = (long long)xcd_chunk_remap(blockIdx.x, gridDim.x, S) * blockDim.x + threadIdx.x;   // S blocks = 4 bricks
-  const long long Ib = t / S;
-  const int off = (int)(t - Ib * S);
-  const long long brick = Ib >> 6;
-  const int q = (int)(Ib & 63);
-  int Iv[3] = {0, 0, 0}, o[3], Jv[3] = {0, 0, 0};
-  Iv[0] = (int)(brick % nbx) * BW + (D == 3 ? (q & 3) : (q & 7));
-  Iv[1] = (int)((brick / nbx) % nby) * BW + (D == 3 ? ((q >> 2) & 3) : (q >> 3));
-  if (D == 3) Iv[2] = (int)(brick / ((long long)nbx * nby)) * BW + (q >> 4);
-  if (Iv[0] >= g1.n0 || Iv[1] >= g1.n1 || (D == 3 && Iv[2] >= g1.n2)) return;   // also every thread past the last brick
-  const long long I = v2lin(Iv, g1);
+  const int E = 2 * R + 2, NB = D == 3 ? E * E * E : E * E;
+  const int64_t i = r0 + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= r1) return;
+  const int lane = threadIdx.x & 63;
+  int ci[3];
+  lin2v(cell0[i], g1, ci);
+  const int64_t base = slice_ptr[i >> 6];
+  const int len = (int)((slice_ptr[(i >> 6) + 1] - base) >> 6);
+  const int rl = (int)(i & 63);
+  int fi = 0;   // constrained components of the row's own node
+  if (fixed) {
+#pragma unroll
+    for (int c = 0; c < BS; ++c) fi |= fixed[i * BS + c] ? 1 << c : 0;
+  }
+  // lane k holds what the wave needs to know about entry k of the row (column, its cell, its weights, whether it counts);
+  // the loop below hands these round by cross-lane reads, so that the only memory accesses inside it are the (wave-uniform,
+  // mutually independent) loads of the entry's values
+  for (int k0 = 0; k0 < len; k0 += GL_WAVE) {   // rows longer than 64 entries: in batches (len <= 150)
+    const int kk = k0 + lane;
+    int64_t jl = 0;
+    int cjl[3] = {0, 0, 0};
+    double wl[3] = {0.0, 0.0, 0.0};
+    int okl = 0;   // bit 0: the entry counts; bits 1 .. BS: constrained components of its column
+    if (kk < len) {
+      jl = cols[base + (int64_t)kk * GL_WAVE + rl];
+      if (jl < n_col) {   // ghost column: dropped unless the hierarchy has a replicated (global) level
+        okl = 1;
+        lin2v(cell0[jl], g1, cjl);
+#pragma unroll
+        for (int a = 0; a < D; ++a) wl[a] = wgt[jl * D + a];
+        if (fixed) {
+#pragma unroll
+          for (int c = 0; c < BS; ++c) okl |= fixed[jl * BS + c] ? 2 << c : 0;
+        }
+      }
+    }
+    const int nk = min(GL_WAVE, len - k0);
+    for (int b = lane; b < ((NB + 63) & ~63); b += GL_WAVE) {
+      const bool live = b < NB;
+      int Jv[3] = {0, 0, 0};
+      Jv[0] = ci[0] - R + b % E;
+      Jv[1] = ci[1] - R + (b / E) % E;
+      if (D == 3) Jv[2] = ci[2] - R + b / (E * E);
+      double acc[B2];
+      float* t = T + ((i - r0) * NB + (live ? b : 0)) * B2;
+#pragma unroll
+      for (int e = 0; e < B2; ++e) acc[e] = k0 == 0 ? 0.0 : (double)t[e];
+      for (int k = 0; k < nk; ++k) {
+        const int ok = __shfl(okl, k, 64);
+        double wj = live && (ok & 1) ? 1.0 : 0.0;
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+          const int dj = Jv[a] - __shfl(cjl[a], k, 64);
+          const double w = __shfl(wl[a], k, 64);
+          wj *= dj == 0 ? 1.0 - w : dj == 1 ? w : 0.0;
+        }
+        const double* v = vK + (base + (int64_t)(k0 + k) * GL_WAVE) * B2 + rl;
+#pragma unroll
+        for (int e = 0; e < B2; ++e) {
+          double val = v[e * GL_WAVE];
+          if (((fi >> (e / BS)) | (ok >> (1 + e % BS))) & 1) val = 0.0;
+          acc[e] += wj * val;
+        }
+      }
+      if (live) {
+#pragma unroll
+        for (int e = 0; e < B2; ++e) t[e] = (float)acc[e];
+      }
+    }
+  }
+}
+
+template <int D, int BS>
+__global__ void k_mg_ptkp(GridDev g1, int R, int S, int64_t r0, int64_t r1, const int64_t* __restrict__ pt_ptr,
+                          const int32_t* __restrict__ pt_idx, const float* __restrict__ pt_w,
+                          const int32_t* __restrict__ cell0, const float* __restrict__ T, double* __restrict__ A1d) {
+  constexpr int B2 = BS * BS;
+  const int E = 2 * R + 2, NB = D == 3 ? E * E * E : E * E;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= g1.nn * S) return;
+  const long long I = t / S;
+  const int off = (int)(t - I * S);
+  int Iv[3], o[3], Jv[3] = {0, 0, 0};
+  lin2v(I, g1, Iv);
   off2v<D>(off, R, o);
   bool inside = true;
 #pragma unroll
@@ -137,59 +249,27 @@ __global__ void k_mg_rap0(GridDev g1, int nbx, int nby, int R, int S, int64_t n_
     Jv[a] = Iv[a] + o[a];
     inside = inside && Jv[a] >= 0 && Jv[a] < gn(g1, a);
   }
+  if (!inside) return;   // (A1d is zero-initialised)
   double acc[B2];
 #pragma unroll
-  for (int e = 0; e < B2; ++e) acc[e] = 0.0;
-  if (inside) {
-    for (int corner = 0; corner < (1 << D); ++corner) {
-      int cv[3] = {0, 0, 0};
-      bool ok = true;
+  for (int e = 0; e < B2; ++e) acc[e] = A1d[((long long)off * B2 + e) * g1.nn + I];
+  const long long sl = I >> 6;
+  const int64_t base = pt_ptr[sl] + (I & 63);
+  const int len = (int)((pt_ptr[sl + 1] - pt_ptr[sl]) >> 6);
+  for (int k = 0; k < len; ++k) {
+    const float w = pt_w[base + (int64_t)k * GL_WAVE];
+    if (w == 0.0f) continue;   // padding
+    const int64_t i = pt_idx[base + (int64_t)k * GL_WAVE];
+    if (i < r0 || i >= r1) continue;
+    int ci[3];
+    lin2v(cell0[i], g1, ci);
+    const int b = (Jv[0] - ci[0] + R) + E * ((Jv[1] - ci[1] + R) + (D == 3 ? E * (Jv[2] - ci[2] + R) : 0));
+    const float* tp = T + ((i - r0) * NB + b) * B2;
 #pragma unroll
-      for (int a = 0; a < D; ++a) {
-        cv[a] = Iv[a] - ((corner >> a) & 1);
-        ok = ok && cv[a] >= 0 && cv[a] <= gn(g1, a) - 2;
-      }
-      if (!ok) continue;
-      const long long c = v2lin(cv, g1);
-      for (int32_t q = cell_ptr[c]; q < cell_ptr[c + 1]; ++q) {
-        const int64_t i = cell_nodes[q];
-        double wi = 1.0;
-#pragma unroll
-        for (int a = 0; a < D; ++a) {
-          const double w = wgt[i * D + a];
-          wi *= ((corner >> a) & 1) ? w : 1.0 - w;
-        }
-        if (wi == 0.0) continue;
-        const int lane = (int)(i & 63);
-        const int64_t base = slice_ptr[i >> 6];
-        const int len = (int)((slice_ptr[(i >> 6) + 1] - base) >> 6);
-        for (int k = 0; k < len; ++k) {
-          const int64_t j = cols[base + (int64_t)k * GL_WAVE + lane];
-          if (j >= n_col) continue;   // ghost column: dropped unless the hierarchy has a replicated (global) level
-          int cj[3];
-          lin2v(cell0[j], g1, cj);
-          double wj = 1.0;
-#pragma unroll
-          for (int a = 0; a < D; ++a) {
-            const int dj = Jv[a] - cj[a];
-            const double w = wgt[j * D + a];
-            wj *= dj == 0 ? 1.0 - w : dj == 1 ? w : 0.0;
-          }
-          if (wj == 0.0) continue;
-          const double ww = wi * wj;
-          const double* v = vK + (base + (int64_t)k * GL_WAVE) * B2 + lane;
-#pragma unroll
-          for (int e = 0; e < B2; ++e) {
-            double val = v[e * GL_WAVE];
-            if (fixed && (fixed[i * BS + e / BS] || fixed[j * BS + e % BS])) val = 0.0;
-            acc[e] += ww * val;
-          }
-        }
-      }
-    }
+    for (int e = 0; e < B2; ++e) acc[e] += (double)w * (double)tp[e];
   }
 #pragma unroll
-  for (int e = 0; e < B2; ++e) A1[((long long)off * B2 + e) * g1.nn + I] = (float)acc[e];
+  for (int e = 0; e < B2; ++e) A1d[((long long)off * B2 + e) * g1.nn + I] = acc[e];
 }
 
 // Transfer between two Cartesian levels.  Levels are boxes of ONE global index frame per level (partitioned runs:
@@ -988,26 +1068,27 @@ struct Cheb {
 }  // namespace
 
 // ===================================================================================================
-// mesh metrics (glims_create): bounding box, lattice detection, mean edge length, coordinates in internal numbering
+// mesh metrics, HOST version (glims_create behind the test hook GLIMS_HOST_SYMBOLIC; the product computes them on the
+// device, symbolic.hip): bounding box, lattice detection, mean edge length, coordinates in internal numbering
 // ===================================================================================================
 void gl_mesh_metrics(glims_ctx* h, const HostPattern& hp, const double* xyz_old) {
   MeshMetrics& mm = h->mm;
   const int d = h->dim;
   const int64_t n = h->n_own;
-  mm.xyz.resize((size_t)h->n_nodes * d);
+  std::vector<double> xyzn((size_t)h->n_nodes * d);   // coordinates in the internal numbering
   const int nth = gl_host_threads();   // not the runtime's default team (one thread per visible hardware thread)
   (void)nth;                           // (the device pass of the compiler does not see the OpenMP clauses)
 #pragma omp parallel for schedule(static) num_threads(nth)
   for (int64_t i = 0; i < h->n_nodes; ++i)   // ghosts keep their place in the numbering (new2old = identity there)
-    for (int a = 0; a < d; ++a) mm.xyz[i * d + a] = xyz_old[(int64_t)hp.new2old[i] * d + a];
+    for (int a = 0; a < d; ++a) xyzn[i * d + a] = xyz_old[(int64_t)hp.new2old[i] * d + a];
   for (int a = 0; a < 3; ++a) {
     mm.lo[a] = 1e300;
     mm.hi[a] = -1e300;
   }
   for (int64_t i = 0; i < n; ++i)
     for (int a = 0; a < d; ++a) {
-      mm.lo[a] = std::min(mm.lo[a], mm.xyz[i * d + a]);
-      mm.hi[a] = std::max(mm.hi[a], mm.xyz[i * d + a]);
+      mm.lo[a] = std::min(mm.lo[a], xyzn[i * d + a]);
+      mm.hi[a] = std::max(mm.hi[a], xyzn[i * d + a]);
     }
   for (int a = d; a < 3; ++a) mm.lo[a] = mm.hi[a] = 0.0;
   // edges from the SELL pattern (owned columns only): smallest positive coordinate difference per axis, mean length
@@ -1031,7 +1112,7 @@ void gl_mesh_metrics(glims_ctx* h, const HostPattern& hp, const double* xyz_old)
           if (j <= i || j >= n) continue;
           double e2 = 0.0;
           for (int a = 0; a < d; ++a) {
-            const double dl = std::fabs(mm.xyz[i * d + a] - mm.xyz[j * d + a]);
+            const double dl = std::fabs(xyzn[i * d + a] - xyzn[j * d + a]);
             e2 += dl * dl;
             if (dl > 1e-9 * ext[a]) hm[a] = std::min(hm[a], dl);
           }
@@ -1058,13 +1139,15 @@ void gl_mesh_metrics(glims_ctx* h, const HostPattern& hp, const double* xyz_old)
     int bad = 0;
 #pragma omp parallel for schedule(static) reduction(+ : bad) num_threads(nth)
     for (int64_t i = 0; i < n; ++i) {
-      const double t = (mm.xyz[i * d + a] - mm.lo[a]) / hmin[a];
+      const double t = (xyzn[i * d + a] - mm.lo[a]) / hmin[a];
       if (std::fabs(t - std::round(t)) > 1e-6) ++bad;
     }
     lat = bad == 0;
     mm.h_lattice[a] = hmin[a];
   }
   mm.lattice = lat;
+  h->xyz_new.upload(xyzn, h->st);
+  GL_HIP(hipStreamSynchronize(h->st));
 }
 
 // ===================================================================================================
@@ -1176,7 +1259,7 @@ void mg_setup_t(glims_ctx* h, MgHierarchy& mg) {
   };
   mg.clear();
   GL_REQUIRE(mg.op_vals && mg.op_dinv && mg.bs == BS, "multigrid set-up without an operator");
-  GL_REQUIRE(!mm.xyz.empty(), "mesh metrics missing");
+  GL_REQUIRE(h->xyz_new.n == (size_t)h->n_nodes * D, "mesh coordinates missing");
   const uint8_t* fx = mg.op_fixed;
   const double hf = h->opt.mg_h_factor > 0.5 ? h->opt.mg_h_factor : 2.0;
   const int coarse_max = std::max(8, h->opt.mg_coarse_nodes);
@@ -1224,9 +1307,6 @@ void mg_setup_t(glims_ctx* h, MgHierarchy& mg) {
   for (int a = 0; a < D; ++a) H[a] = lattice ? hf * h_lat[a] : hf * mean_edge / 1.2;
   MgGrid g1;
   int ng1[3] = {1, 1, 1}, o1[3] = {0, 0, 0};             // global dims of level 1, offset of this rank's box
-  std::vector<int32_t> cell0(n_all);
-  std::vector<int32_t> cgl((size_t)n_all * D);           // global cell index per node and axis
-  std::vector<double> wgt((size_t)n_all * D);
   int S_try = D == 3 ? 27 : 9, widenings = 0;
   for (int attempt = 0;; ++attempt) {
     for (int a = 0; a < D; ++a) {
@@ -1249,31 +1329,6 @@ void mg_setup_t(glims_ctx* h, MgHierarchy& mg) {
         continue;
       }
     }
-    int cmin[3] = {1 << 30, 1 << 30, 1 << 30}, cmax[3] = {0, 0, 0};
-#pragma omp parallel num_threads(gl_host_threads())
-    {
-      int lmin[3] = {1 << 30, 1 << 30, 1 << 30}, lmax[3] = {0, 0, 0};
-#pragma omp for schedule(static) nowait
-      for (int64_t i = 0; i < n_all; ++i)
-        for (int a = 0; a < D; ++a) {
-          const double t = (mm.xyz[i * D + a] - flo[a]) / H[a];
-          int c = (int)std::floor(t);
-          c = std::max(0, std::min(ng1[a] - 2, c));
-          double w = t - c;
-          if (std::fabs(w) < 1e-6) w = 0.0;            // lattice-aligned nodes: exact weights, compact stencils
-          if (std::fabs(w - 1.0) < 1e-6) w = 1.0;
-          w = std::max(0.0, std::min(1.0, w));
-          wgt[i * D + a] = w;
-          cgl[i * D + a] = c;
-          lmin[a] = std::min(lmin[a], c);
-          lmax[a] = std::max(lmax[a], c);
-        }
-#pragma omp critical
-      for (int a = 0; a < D; ++a) {
-        cmin[a] = std::min(cmin[a], lmin[a]);
-        cmax[a] = std::max(cmax[a], lmax[a]);
-      }
-    }
     g1 = MgGrid();
     g1.nn = 1;
     for (int a = 0; a < D; ++a) {
@@ -1282,17 +1337,11 @@ void mg_setup_t(glims_ctx* h, MgHierarchy& mg) {
       g1.nn *= g1.n[a];
     }
     GL_REQUIRE(g1.nn < (int64_t(1) << 31), "auxiliary grid too large");
-#pragma omp parallel for schedule(static) num_threads(gl_host_threads())
-    for (int64_t i = 0; i < n_all; ++i) {
-      int64_t lin = 0, stride = 1;
-      for (int a = 0; a < D; ++a) {
-        lin += (int64_t)(cgl[i * D + a] - o1[a]) * stride;
-        stride *= g1.n[a];
-      }
-      cell0[i] = (int32_t)lin;
-    }
-    mg.cell0.upload(cell0, h->st);
-    mg.wgt.upload(wgt, h->st);
+    mg.cell0.alloc((size_t)n_all);
+    mg.wgt.alloc((size_t)n_all * D);
+    hipLaunchKernelGGL(k_mg_node_cells<D>, dim3(gridn(n_all)), dim3(256), 0, h->st, n_all, h->xyz_new.p, flo[0], flo[1],
+                       flo[2], H[0], H[1], H[2], gdev(g1), mg.cell0.p, mg.wgt.p);
+    GL_HIP(hipGetLastError());
     dvec<unsigned long long> reach;
     reach.alloc_zero(3, h->st);
     hipLaunchKernelGGL(k_mg_reach<D>, dim3(gridn(n)), dim3(256), 0, h->st, n, n_all, gdev(g1), p.slice_ptr.p, p.cols.p,
@@ -1325,17 +1374,23 @@ void mg_setup_t(glims_ctx* h, MgHierarchy& mg) {
   lap("grid choice, node -> cell map, reach");
   mg.S = 1;
   for (int a = 0; a < D; ++a) mg.S *= 2 * mg.R + 1;
-  {   // children lists: counting sort of the OWNED mesh nodes by cell
-    std::vector<int32_t> ptr((size_t)g1.nn + 1, 0), nodes((size_t)n);
-    for (int64_t i = 0; i < n; ++i) ptr[(size_t)cell0[i] + 1]++;
-    for (int64_t c = 0; c < g1.nn; ++c) ptr[c + 1] += ptr[c];
-    std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
-    for (int64_t i = 0; i < n; ++i) nodes[fill[cell0[i]]++] = (int32_t)i;
-    mg.cell_ptr.upload(ptr, h->st);
-    mg.cell_nodes.upload(nodes, h->st);
+  {   // children lists: the OWNED mesh nodes sorted by cell (stable radix sort: ascending node index inside a cell)
+    dvec<uint32_t> k_in, k_out;
+    dvec<int32_t> v_in;
+    k_in.alloc((size_t)n);
+    k_out.alloc((size_t)n);
+    v_in.alloc((size_t)n);
+    mg.cell_nodes.alloc((size_t)n);
+    hipLaunchKernelGGL(k_mg_cell_keys, dim3(gridn(n)), dim3(256), 0, h->st, n, mg.cell0.p, k_in.p, v_in.p);
+    GL_HIP(hipGetLastError());
+    int bits = 1;
+    while ((int64_t(1) << bits) <= g1.nn) ++bits;
+    gl_sort_pairs_u32(h, k_in.p, k_out.p, v_in.p, mg.cell_nodes.p, (size_t)n, bits);
+    mg.cell_ptr.alloc((size_t)g1.nn + 1);
+    gl_offsets_of_sorted_keys(h, k_out.p, n, g1.nn, mg.cell_ptr.p);
     GL_HIP(hipStreamSynchronize(h->st));
   }
-  lap("children lists (counting sort, upload)");
+  lap("children lists (device sort)");
   {   // explicit restriction operator mesh -> grid (k_mg_restrict0): count, slice lengths on the host, fill
     dvec<int32_t> cnt;
     cnt.alloc((size_t)g1.nn);
@@ -1419,13 +1474,27 @@ void mg_setup_t(glims_ctx* h, MgHierarchy& mg) {
   };
   const bool g1_global = framed;
   MgLevel* L1 = new_level(g1, o1, ng1, g1_global);
-  constexpr int BW0 = D == 3 ? 4 : 8;   // bricks of k_mg_rap0
-  const int nbx0 = (g1.n[0] + BW0 - 1) / BW0, nby0 = (g1.n[1] + BW0 - 1) / BW0, nbz0 = D == 3 ? (g1.n[2] + BW0 - 1) / BW0 : 1;
-  hipLaunchKernelGGL((k_mg_rap0<D, BS>), dim3(gridn((long long)nbx0 * nby0 * nbz0 * 64 * mg.S)), dim3(256), 0, h->st, gdev(g1),
-                     nbx0, nby0, mg.R, mg.S, n,
-                     n_all, mg.cell_ptr.p, mg.cell_nodes.p, mg.cell0.p, mg.wgt.p, p.slice_ptr.p, p.cols.p, mg.op_vals,
-                     fxr, L1->A.p);
-  GL_HIP(hipGetLastError());
+  {   // A1 = P^T K P in two gathers (k_mg_kp, k_mg_ptkp); rows in chunks so that T = K P stays below ~8 GB
+    const int E = 2 * mg.R + 2;
+    const int64_t NB = D == 3 ? (int64_t)E * E * E : (int64_t)E * E;
+    const size_t ne = (size_t)mg.S * B2 * g1.nn;
+    dvec<double> A1d;
+    A1d.alloc_zero(ne, h->st);
+    const int64_t chunk = std::max<int64_t>(GL_WAVE, std::min<int64_t>(n, ((int64_t)8 << 30) / (NB * B2 * (int64_t)sizeof(float))));
+    dvec<float> T;
+    T.alloc((size_t)(std::min(chunk, n) * NB * B2));
+    for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+      const int64_t r1 = std::min(n, r0 + chunk);
+      hipLaunchKernelGGL((k_mg_kp<D, BS>), dim3(gridn(r1 - r0, 4)), dim3(256), 0, h->st, gdev(g1), mg.R, r0, r1, n_all,
+                         mg.cell0.p, mg.wgt.p, p.slice_ptr.p, p.cols.p, mg.op_vals, fxr, T.p);
+      hipLaunchKernelGGL((k_mg_ptkp<D, BS>), dim3(gridn((long long)g1.nn * mg.S)), dim3(256), 0, h->st, gdev(g1), mg.R, mg.S,
+                         r0, r1, mg.pt_ptr.p, mg.pt_idx.p, mg.pt_w.p, mg.cell0.p, T.p, A1d.p);
+      GL_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_mg_d2f, dim3(gridn((long long)ne)), dim3(256), 0, h->st, (int64_t)ne, A1d.p, L1->A.p);
+    GL_HIP(hipGetLastError());
+    GL_HIP(hipStreamSynchronize(h->st));
+  }
   if (g1_global) allreduce_operator(L1);
   mg.entries = (int64_t)mg.S * B2 * g1.nn;
   // coarsen until the GLOBAL grid is small enough (the level count is then the same on every rank)

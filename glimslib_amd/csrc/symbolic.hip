@@ -739,3 +739,33 @@ void gl_build_pattern_device(glims_ctx* h, const double* d_xyz, const int32_t* d
   GL_HIP(hipStreamSynchronize(st));
   lap("slice lists, mesh metrics");
 }
+
+// ---- helpers shared with the multigrid set-up (mg.hip): rocPRIM stays in this translation unit --------------------------
+void gl_sort_pairs_u32(glims_ctx* h, uint32_t* k_in, uint32_t* k_out, int32_t* v_in, int32_t* v_out, size_t n, int end_bit) {
+  size_t bytes = 0;
+  GL_HIP(rocprim::radix_sort_pairs(nullptr, bytes, k_in, k_out, v_in, v_out, n, 0, end_bit, h->st));
+  dvec<unsigned char> tmp;
+  tmp.alloc(std::max<size_t>(bytes, 16));
+  GL_HIP(rocprim::radix_sort_pairs(tmp.p, bytes, k_in, k_out, v_in, v_out, n, 0, end_bit, h->st));
+  GL_HIP(hipStreamSynchronize(h->st));
+}
+
+namespace {
+__global__ void k_offsets32(int64_t n_keys, int64_t n, const uint32_t* __restrict__ key, int32_t* __restrict__ ptr) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > n_keys) return;
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)key[mid] < c) lo = mid + 1;
+    else hi = mid;
+  }
+  ptr[c] = (int32_t)lo;
+}
+}  // namespace
+
+// ptr[c] = first position of a key >= c in the sorted keys, c = 0 .. n_keys
+void gl_offsets_of_sorted_keys(glims_ctx* h, const uint32_t* keys_sorted, int64_t n, int64_t n_keys, int32_t* ptr) {
+  hipLaunchKernelGGL(k_offsets32, dim3(gridn(n_keys + 1)), dim3(256), 0, h->st, n_keys, n, keys_sorted, ptr);
+  GL_HIP(hipGetLastError());
+}
