@@ -408,12 +408,12 @@ def main():
                         "timed": where})
 
     if world == 1 and in_step:
-        kernel_entry("k_spmv<1, 4, 1, 1, double, 1>", "y = A(c) x, SELL-64 with 16-bit column codes, fused w.u partials "
+        kernel_entry("k_spmv<1, 8, 1, 1, double>", "y = A(c) x, SELL-64 with 16-bit column codes, fused w.u partials "
                      "(algorithmic bytes: CSR with 4-byte columns, 12 nnz + 20 rows)", b_alg,
                      st['ms_spmv_steps'], st['n_spmv_steps'], st['us_spmv_median'], "k_spmv<1", steps_n, ms_step,
                      "HIP events inside the %d timed steps" % steps_n)
     elif world == 1 and post_pass:
-        kernel_entry("k_spmv<1, 4, 1, 1, double, 1>", "y = A(c) x, SELL-64 with 16-bit column codes, fused w.u partials "
+        kernel_entry("k_spmv<1, 8, 1, 1, double>", "y = A(c) x, SELL-64 with 16-bit column codes, fused w.u partials "
                      "(algorithmic bytes: CSR with 4-byte columns, 12 nnz + 20 rows)", b_alg,
                      st_k['ms_spmv_steps'], st_k['n_spmv_steps'], st_k['us_spmv_median'], "k_spmv<1", st_k['_steps'],
                      st_k['ms_steps'] / st_k['_steps'],
@@ -421,7 +421,7 @@ def main():
     if st_k is not None:
         ks, kms = st_k['_steps'], st_k['ms_steps'] / st_k['_steps']
         where = "HIP events in a separate pass of %d steps right after the timed region" % ks
-        kernel_entry("k_rd_assemble<4, 0, 24, 1, double, 1>", "Jacobian + Newton residual(s) in one sweep over the "
+        kernel_entry("k_rd_assemble<4, 0, 24, 1, double>", "Jacobian + Newton residual(s) in one sweep over the "
                      "(row, cell) incidences (algorithmic bytes: 12 per incidence + 20 per stored entry [S read, A write, "
                      "4-byte column] + 32 per row)", 12 * st['n_corners'] + 20 * st['nnz_padded'] + 32 * st['n_rows'],
                      st_k['ms_sweep_steps'], st_k['n_sweep_steps'], st_k['us_sweep_median'], "k_rd_assemble", ks, kms,
@@ -437,7 +437,7 @@ def main():
                 "operator, tools/pmc_summary.py)" % pmc_file,
                 "achieved_real": None if traffic is None else traffic / t_spmv / 1e9,
                 "frac_real": None if traffic is None else traffic / t_spmv / 1e9 / HBM_PEAK_GBS,
-                "kernel": ("k_spmv<1, 4, 1, 1, double, 1>" if (in_step or post_pass) else "k_spmv<0, 4, 1, 1, double, 1>") +
+                "kernel": ("k_spmv<1, 8, 1, 1, double>" if (in_step or post_pass) else "k_spmv<0, 8, 1, 1, double>") +
                 " (SELL-64, fp64 values, columns streamed as 16-bit window codes; algorithmic bytes still count 4-byte "
                 "CSR columns)",
                 "algorithmic_bytes_per_launch": b_alg, "avg_launch_us": t_spmv * 1e6,

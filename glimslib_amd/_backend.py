@@ -277,8 +277,8 @@ class Handle:
         return a
 
     def pattern_checksum(self):
-        """Twelve 64-bit hashes of the device-resident discretisation structures (see glims_pattern_checksum)."""
-        a = (C.c_uint64 * 12)()
+        """Thirteen 64-bit hashes of the device-resident discretisation structures (see glims_pattern_checksum)."""
+        a = (C.c_uint64 * 13)()
         self._check(self.lib.glims_pattern_checksum(self._h, a))
         return [int(v) for v in a]
 

@@ -196,6 +196,7 @@ int glims_create(glims_ctx** out, int dim, int64_t n_nodes, int64_t n_own, int64
       p.win_base.upload(hp.win_base, h->st);
       p.win_ok.upload(hp.win_ok, h->st);
       p.diag_k.upload(hp.diag_k, h->st);
+      p.rlen.upload(hp.rlen, h->st);
       p.cslice_ptr.upload(hp.cslice_ptr, h->st);
       p.cslots.upload(hp.cslots, h->st);
       p.celem.upload(hp.celem, h->st);
@@ -257,6 +258,7 @@ int glims_create(glims_ctx** out, int dim, int64_t n_nodes, int64_t n_own, int64
     h->done.alloc_zero(1, h->st);
     GL_HIP(hipStreamSynchronize(h->st));
 
+    h->spmv_unroll = h->mm.lattice ? 8 : 16;
     h->stats.n_rows = n_own;
     h->stats.nnz = h->nnz;
     h->stats.nnz_padded = p.total_entries;
@@ -481,7 +483,6 @@ int glims_setup(glims_ctx* h, int with_mechanics) {
     h->jac32 = (h->opt.flags & GLIMS_FLAG_FP32_JACOBIAN) != 0;
     h->use_idx16 = (h->opt.flags & GLIMS_FLAG_INT32_COLUMNS) == 0;
     h->stats.nnz_idx16 = h->use_idx16 ? h->nnz_idx16_avail : 0;
-    h->pair_A = h->use_idx16 && h->stats.nnz_idx16 == h->stats.nnz_padded;
     gl_assemble_static(h, with_mechanics);
     GL_HIP(hipStreamSynchronize(h->st));
     h->is_setup = true;
@@ -630,7 +631,7 @@ int glims_get_numbering(glims_ctx* h, int32_t* old2new) {
   });
 }
 
-int glims_pattern_checksum(glims_ctx* h, uint64_t out[12]) {
+int glims_pattern_checksum(glims_ctx* h, uint64_t out[13]) {
   return guarded(h, [&]() {
     GL_REQUIRE(out, "null output");
     const DevPattern& p = h->pat;
@@ -646,6 +647,7 @@ int glims_pattern_checksum(glims_ctx* h, uint64_t out[12]) {
     out[9] = fnv_of(h, p.interior_slices.p, (size_t)p.n_interior);
     out[10] = fnv_of(h, p.boundary_slices.p, (size_t)p.n_boundary);
     out[11] = fnv_of(h, h->d_old2new.p, (size_t)h->n_nodes);
+    out[12] = fnv_of(h, p.rlen.p, (size_t)p.n_slices * GL_WAVE);
     return GLIMS_OK;
   });
 }

@@ -100,6 +100,7 @@ struct HostPattern {
   std::vector<uint8_t> win_ok;             // [n_slices]
   int64_t n_compressed = 0;                // slices with win_ok
   std::vector<uint8_t> diag_k;             // [n_slices*64] slot of the diagonal in each row
+  std::vector<uint8_t> rlen;               // [n_slices*64] stored entries of each row (0 on the padding rows of the last slice)
   std::vector<int64_t> cslice_ptr;         // [n_slices+1] offsets into the (row, cell) incidence arrays
   std::vector<uint32_t> cslots;            // 4 x uint8: slot (within the row) of each vertex of the cell
   std::vector<int32_t> celem;              // cell id, -1 = padding
@@ -127,10 +128,10 @@ struct DevPattern {
   dvec<int64_t> slice_ptr;
   dvec<int32_t> cols;
   dvec<uint16_t> cols16;
-  dvec<uint16_t> cols16p;                  // the same codes in the slot-pair layout (Newton Jacobian only)
   dvec<int32_t> win_base;
   dvec<uint8_t> win_ok;
   dvec<uint8_t> diag_k;
+  dvec<uint8_t> rlen;                      // entries of each row: the SpMV's lanes stop there (slots beyond are padding)
   dvec<int64_t> cslice_ptr;
   dvec<uint32_t> cslots;
   dvec<int32_t> celem;
@@ -390,8 +391,7 @@ struct glims_ctx {
   dvec<double> vM, vS, vA, vKel, vG;
   dvec<float> vA32;                        // Newton Jacobian in single precision (GLIMS_FLAG_FP32_JACOBIAN only)
   bool jac32 = false;
-  bool pair_A = false;                     // vA / vA32 and cols16p use the slot-pair layout (GLIMS_PAIR_A, needs 16-bit codes everywhere)
-  int tune_pair_A = 1;
+  int spmv_unroll = 8;                     // entries in flight per lane of the scalar SpMV: 8 on lattice meshes, 16 on general ones
   dvec<float> vKel32;                      // single-precision copy of K_el (inner solves of the elasticity solver)
   // vectors (internal numbering; length n_nodes unless noted)
   dvec<double> c, c_old, b, load_rd, dinv;

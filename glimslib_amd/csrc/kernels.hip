@@ -191,17 +191,6 @@ __global__ __launch_bounds__(GL_WAVE) void k_assemble_static(
 //   s_T = sum of c over the cell's vertices, w_T = rho_T |T| d!/(d+3)!   [exact integral of rho c_h phi_i phi_j]
 //   -R = b - 1/2 (A + S) c,   b = M c_prev + load
 // ---------------------------------------------------------------------------------------------------
-template <class VT> struct Pair2;
-template <> struct Pair2<double> { using type = double2; };
-template <> struct Pair2<float> { using type = float2; };
-// Slot-pair layout of the Newton Jacobian A(c) and of its column codes: two consecutive slots of a row are adjacent in
-// memory, so that a lane reads 16 B of values (8 B in single precision) and 4 B of codes per load -- 1024-B / 256-B wave
-// loads, half the load instructions.  Element offset of slot k of lane l inside a slice with `len` slots (the odd last
-// slot stays a single element after the pairs):
-__device__ __forceinline__ int64_t pair_off(int k, int len, int lane) {
-  return ((len & 1) && k == len - 1) ? (int64_t)(len >> 1) * (2 * GL_WAVE) + lane
-                                     : ((int64_t)(k >> 1) * GL_WAVE + lane) * 2 + (k & 1);
-}
 // column of one entry from its 16-bit code: window base by cross-lane read (lane w of `wb` holds base w), + offset
 __device__ __forceinline__ int32_t decode_col(uint32_t code, int32_t wb) {
   return __builtin_amdgcn_ds_bpermute((int)((code >> GL_WIN_BITS) << 2), wb) + (int32_t)(code & ((1u << GL_WIN_BITS) - 1u));
@@ -222,7 +211,7 @@ __device__ __forceinline__ void corner_batch(const double* __restrict__ wp, cons
   for (int j = 0; j < B; ++j) corner(wb[j], sb[j]);
 }
 
-template <int NV, int NT, int CU, int CIDX, class AT = double, int PAIR = 0>
+template <int NV, int NT, int CU, int CIDX, class AT = double>
 __global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
     const int32_t* __restrict__ slice_list, int64_t n_own, const int64_t* __restrict__ slice_ptr,
     const int32_t* __restrict__ cols, const uint16_t* __restrict__ cols16, const int32_t* __restrict__ win_base,
@@ -326,28 +315,13 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
 #pragma unroll
         for (int j = 0; j < 8; ++j)
           S8[j] = NT ? __builtin_nontemporal_load(sv + (int64_t)(k + j) * GL_WAVE) : sv[(int64_t)(k + j) * GL_WAVE];
-        double A8[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const double Av = S8[j] + two_dt * acc[(k + j) * GL_WAVE + lane];
-          A8[j] = Av;
-          if (!PAIR) {
-            if (NT) __builtin_nontemporal_store((AT)Av, av + (int64_t)(k + j) * GL_WAVE);
-            else av[(int64_t)(k + j) * GL_WAVE] = (AT)Av;
-          }
+          if (NT) __builtin_nontemporal_store((AT)Av, av + (int64_t)(k + j) * GL_WAVE);
+          else av[(int64_t)(k + j) * GL_WAVE] = (AT)Av;
           r += 0.5 * (Av + S8[j]) * cn[(k + j) * GL_WAVE + lane];
           if (k + j == dk) d = Av;
-        }
-        if (PAIR) {   // k is a multiple of 8 and k + 8 <= len: these are four complete pairs -> one 16-B (8-B) store each
-          using A2 = typename Pair2<AT>::type;
-          A2* ap = reinterpret_cast<A2*>(vA + base) + lane;
-#pragma unroll
-          for (int j = 0; j < 8; j += 2) {
-            A2 t;
-            t.x = (AT)A8[j];
-            t.y = (AT)A8[j + 1];
-            ap[(int64_t)((k + j) >> 1) * GL_WAVE] = t;
-          }
         }
       }
       if (k < len) {   // ragged tail: one more batch, loads issued together
@@ -361,8 +335,7 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
         for (int j = 0; j < 8; ++j)
           if (k + j < len) {
             const double Av = S8[j] + two_dt * acc[(k + j) * GL_WAVE + lane];
-            if (PAIR) vA[base + pair_off(k + j, len, lane)] = (AT)Av;
-            else if (NT) __builtin_nontemporal_store((AT)Av, av + (int64_t)(k + j) * GL_WAVE);
+            if (NT) __builtin_nontemporal_store((AT)Av, av + (int64_t)(k + j) * GL_WAVE);
             else av[(int64_t)(k + j) * GL_WAVE] = (AT)Av;
             r += 0.5 * (Av + S8[j]) * cn[(k + j) * GL_WAVE + lane];
             if (k + j == dk) d = Av;
@@ -480,11 +453,17 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_matfree(
 // gathered x entries from L2 / Infinity Cache
 // DK >= 0 (fused dot product): also returns x at the row's own column through xdiag (slot dk of the row), so that
 // the dot y.x does not read x[row] a second time
+// `rl` = the lane's own row length: slots [rl, len) are padding (value 0, column = the row itself) and are NOT read -- the
+// rows of a slice are sorted by length, so the active lanes of a slot form a prefix and the memory system fetches only the
+// lines they touch.  On an unstructured mesh the padding is +19.5 % of the entries (sigma = 256); its bytes used to be
+// streamed like all others.
 template <int COMP, int UNR, int NT, int WANT_DIAG, class VT>
 __device__ __forceinline__ double spmv_row(const int32_t* __restrict__ cc, const uint16_t* __restrict__ c16,
                                             int32_t wb, const VT* __restrict__ v, const double* __restrict__ x,
-                                            int len, int dk, double& xdiag) {
+                                            int len, int rl, int dk, double& xdiag) {
   constexpr bool NTC = NT == 1, NTV = NT != 0;   // NT = 2: only the 8-byte value stream is non-temporal
+  // (the loops run to the SLICE's length on every lane -- the column decode reads window bases across lanes, which needs
+  //  all of them active -- and the loads are predicated on the lane's own row length)
   double acc = 0.0;
   int k = 0;
   for (; k + UNR <= len; k += UNR) {
@@ -494,22 +473,26 @@ __device__ __forceinline__ double spmv_row(const int32_t* __restrict__ cc, const
       uint16_t qu[UNR];
 #pragma unroll
       for (int j = 0; j < UNR; ++j)
-        qu[j] = NTC ? __builtin_nontemporal_load(c16 + (int64_t)(k + j) * GL_WAVE) : c16[(int64_t)(k + j) * GL_WAVE];
+        qu[j] = k + j < rl ? (NTC ? __builtin_nontemporal_load(c16 + (int64_t)(k + j) * GL_WAVE) : c16[(int64_t)(k + j) * GL_WAVE])
+                           : (uint16_t)0;
 #pragma unroll
       for (int j = 0; j < UNR; ++j)
-        vu[j] = (double)(NTV ? __builtin_nontemporal_load(v + (int64_t)(k + j) * GL_WAVE) : v[(int64_t)(k + j) * GL_WAVE]);
+        vu[j] = k + j < rl ? (double)(NTV ? __builtin_nontemporal_load(v + (int64_t)(k + j) * GL_WAVE) : v[(int64_t)(k + j) * GL_WAVE])
+                           : 0.0;
 #pragma unroll
       for (int j = 0; j < UNR; ++j) cu[j] = decode_col(qu[j], wb);
     } else {
 #pragma unroll
       for (int j = 0; j < UNR; ++j)
-        cu[j] = NTC ? __builtin_nontemporal_load(cc + (int64_t)(k + j) * GL_WAVE) : cc[(int64_t)(k + j) * GL_WAVE];
+        cu[j] = k + j < rl ? (NTC ? __builtin_nontemporal_load(cc + (int64_t)(k + j) * GL_WAVE) : cc[(int64_t)(k + j) * GL_WAVE])
+                           : 0;
 #pragma unroll
       for (int j = 0; j < UNR; ++j)
-        vu[j] = (double)(NTV ? __builtin_nontemporal_load(v + (int64_t)(k + j) * GL_WAVE) : v[(int64_t)(k + j) * GL_WAVE]);
+        vu[j] = k + j < rl ? (double)(NTV ? __builtin_nontemporal_load(v + (int64_t)(k + j) * GL_WAVE) : v[(int64_t)(k + j) * GL_WAVE])
+                           : 0.0;
     }
 #pragma unroll
-    for (int j = 0; j < UNR; ++j) xu[j] = x[cu[j]];
+    for (int j = 0; j < UNR; ++j) xu[j] = k + j < rl ? x[cu[j]] : 0.0;
 #pragma unroll
     for (int j = 0; j < UNR; ++j) acc += vu[j] * xu[j];
     if (WANT_DIAG) {
@@ -518,30 +501,29 @@ __device__ __forceinline__ double spmv_row(const int32_t* __restrict__ cc, const
     }
   }
   if (k < len) {
-    // ragged tail (len is rarely a multiple of UNR: 15 on the structured 3-D meshes) as ONE more batch with the slot
-    // index clamped and the surplus products zeroed, so that its loads are in flight together like all the others
+    // ragged tail (len is rarely a multiple of UNR: 15 on the structured 3-D meshes) as ONE more batch, so that its loads
+    // are in flight together like all the others
     int32_t cu[UNR];
     double vu[UNR], xu[UNR];
 #pragma unroll
     for (int j = 0; j < UNR; ++j) {
-      const int kk = min(k + j, len - 1);
+      const int kk = k + j;
       if (COMP)
-        cu[j] = (int32_t)(NTC ? __builtin_nontemporal_load(c16 + (int64_t)kk * GL_WAVE) : c16[(int64_t)kk * GL_WAVE]);
+        cu[j] = kk < rl ? (int32_t)(NTC ? __builtin_nontemporal_load(c16 + (int64_t)kk * GL_WAVE) : c16[(int64_t)kk * GL_WAVE]) : 0;
       else
-        cu[j] = NTC ? __builtin_nontemporal_load(cc + (int64_t)kk * GL_WAVE) : cc[(int64_t)kk * GL_WAVE];
+        cu[j] = kk < rl ? (NTC ? __builtin_nontemporal_load(cc + (int64_t)kk * GL_WAVE) : cc[(int64_t)kk * GL_WAVE]) : 0;
     }
 #pragma unroll
     for (int j = 0; j < UNR; ++j) {
-      const int kk = min(k + j, len - 1);
-      const double vj = (double)(NTV ? __builtin_nontemporal_load(v + (int64_t)kk * GL_WAVE) : v[(int64_t)kk * GL_WAVE]);
-      vu[j] = (k + j < len) ? vj : 0.0;
+      const int kk = k + j;
+      vu[j] = kk < rl ? (double)(NTV ? __builtin_nontemporal_load(v + (int64_t)kk * GL_WAVE) : v[(int64_t)kk * GL_WAVE]) : 0.0;
     }
     if (COMP) {
 #pragma unroll
       for (int j = 0; j < UNR; ++j) cu[j] = decode_col((uint32_t)cu[j], wb);
     }
 #pragma unroll
-    for (int j = 0; j < UNR; ++j) xu[j] = x[cu[j]];
+    for (int j = 0; j < UNR; ++j) xu[j] = k + j < rl ? x[cu[j]] : 0.0;
 #pragma unroll
     for (int j = 0; j < UNR; ++j) acc += vu[j] * xu[j];
     if (WANT_DIAG) {
@@ -553,65 +535,15 @@ __device__ __forceinline__ double spmv_row(const int32_t* __restrict__ cc, const
 }
 
 
-// one lane's row through the pair layout (16-bit codes on every slice is a precondition of this layout)
-template <int WANT_DIAG, class VT>
-__device__ __forceinline__ double spmv_row_pair(const uint16_t* __restrict__ c16s, const VT* __restrict__ vs, int32_t wb,
-                                                 const double* __restrict__ x, int len, int lane, int dk,
-                                                 double& xdiag) {
-  using V2 = typename Pair2<VT>::type;
-  const V2* v2 = reinterpret_cast<const V2*>(vs) + lane;
-  const uint32_t* c2 = reinterpret_cast<const uint32_t*>(c16s) + lane;
-  const int np = len >> 1;
-  double acc = 0.0;
-  int q = 0;
-  for (; q + 2 <= np; q += 2) {   // two pairs = four entries in flight, like UNR = 4 of the slot-major kernel
-    uint32_t cc[2];
-    double va[4], xg[4];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) cc[j] = __builtin_nontemporal_load(c2 + (int64_t)(q + j) * GL_WAVE);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      va[2 * j] = (double)__builtin_nontemporal_load(&v2[(int64_t)(q + j) * GL_WAVE].x);
-      va[2 * j + 1] = (double)__builtin_nontemporal_load(&v2[(int64_t)(q + j) * GL_WAVE].y);
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      xg[2 * j] = x[decode_col(cc[j] & 0xffffu, wb)];
-      xg[2 * j + 1] = x[decode_col(cc[j] >> 16, wb)];
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc += va[j] * xg[j];
-    if (WANT_DIAG) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) xdiag = (2 * q + j == dk) ? xg[j] : xdiag;
-    }
-  }
-  if (q < np) {                    // one more pair
-    const uint32_t c = __builtin_nontemporal_load(c2 + (int64_t)q * GL_WAVE);
-    const double a0 = (double)__builtin_nontemporal_load(&v2[(int64_t)q * GL_WAVE].x);
-    const double a1 = (double)__builtin_nontemporal_load(&v2[(int64_t)q * GL_WAVE].y);
-    const double x0 = x[decode_col(c & 0xffffu, wb)], x1 = x[decode_col(c >> 16, wb)];
-    acc += a0 * x0;   // same summation order as the slot-major kernel: the two layouts give the same bits
-    acc += a1 * x1;
-    if (WANT_DIAG) xdiag = (2 * q == dk) ? x0 : (2 * q + 1 == dk) ? x1 : xdiag;
-  }
-  if (len & 1) {                   // odd last slot
-    const int64_t t = (int64_t)np * (2 * GL_WAVE) + lane;
-    const double xl = x[decode_col(c16s[t], wb)];
-    acc += (double)vs[t] * xl;
-    if (WANT_DIAG) xdiag = (len - 1 == dk) ? xl : xdiag;
-  }
-  return acc;
-}
-
 // VT = double; float only for the optional single-precision copy of the Newton Jacobian (GLIMS_FLAG_FP32_JACOBIAN).
-template <int DOTS, int UNR, int NT, int CIDX, class VT = double, int PAIR = 0>
+template <int DOTS, int UNR, int NT, int CIDX, class VT = double>
 __global__ __launch_bounds__(256) void k_spmv(int n_launch, int chunk, const int32_t* __restrict__ slice_list,
                                                int64_t n_own, const int64_t* __restrict__ slice_ptr,
                                                const int32_t* __restrict__ cols, const uint16_t* __restrict__ cols16,
                                                const int32_t* __restrict__ win_base,
                                                const uint8_t* __restrict__ win_ok,
-                                               const uint8_t* __restrict__ diag_k, const VT* __restrict__ vals,
+                                               const uint8_t* __restrict__ diag_k, const uint8_t* __restrict__ rlen,
+                                               const VT* __restrict__ vals,
                                                const double* __restrict__ x, double* __restrict__ y,
                                                const uint8_t* __restrict__ fixed, const double* __restrict__ addv,
                                                const double* __restrict__ r, double* __restrict__ partials,
@@ -630,14 +562,12 @@ __global__ __launch_bounds__(256) void k_spmv(int n_launch, int chunk, const int
     const VT* v = vals + base + lane;
     double acc, xd = 0.0;
     const int dk = DOTS ? (int)diag_k[row] : -1;   // diag_k covers the padded rows of the last slice as well
-    if constexpr (PAIR != 0) {   // vals / cols16 are the slot-pair copies
+    const int rl = (int)rlen[row];                 // ... and so does rlen (0 there)
+    if (CIDX && win_ok[s]) {   // wave-uniform
       const int32_t wb = win_base[(int64_t)s * GL_N_WIN + (lane & (GL_N_WIN - 1))];
-      acc = spmv_row_pair<DOTS, VT>(cols16 + base, vals + base, wb, x, len, lane, dk, xd);
-    } else if (CIDX && win_ok[s]) {   // wave-uniform
-      const int32_t wb = win_base[(int64_t)s * GL_N_WIN + (lane & (GL_N_WIN - 1))];
-      acc = spmv_row<1, UNR, NT, DOTS, VT>(nullptr, cols16 + base + lane, wb, v, x, len, dk, xd);
+      acc = spmv_row<1, UNR, NT, DOTS, VT>(nullptr, cols16 + base + lane, wb, v, x, len, rl, dk, xd);
     } else {
-      acc = spmv_row<0, UNR, NT, DOTS, VT>(cols + base + lane, nullptr, 0, v, x, len, dk, xd);
+      acc = spmv_row<0, UNR, NT, DOTS, VT>(cols + base + lane, nullptr, 0, v, x, len, rl, dk, xd);
     }
     if (row < n_own) {
       if (fixed && fixed[row]) acc = 0.0;
@@ -647,16 +577,6 @@ __global__ __launch_bounds__(256) void k_spmv(int n_launch, int chunk, const int
     }
   }
   if (DOTS) spmv_dot_partial(pd, b, partials, partial_off);
-}
-
-// slot-major -> slot-pair copy of one per-entry array
-template <class TI, class TO>
-__global__ void k_plane_to_pairs(int n_slices, const int64_t* __restrict__ slice_ptr, const TI* __restrict__ in,
-                                 TO* __restrict__ out) {
-  const int s = blockIdx.x, lane = threadIdx.x;
-  const int64_t base = slice_ptr[s];
-  const int len = (int)((slice_ptr[s + 1] - base) >> 6);
-  for (int k = 0; k < len; ++k) out[base + pair_off(k, len, lane)] = (TO)in[base + (int64_t)k * GL_WAVE + lane];
 }
 
 // Pipelined block SpMV: KB block entries per batch -- all column loads, then all KB*BS*BS value loads (non-temporal:
@@ -997,27 +917,13 @@ static void assemble_static_t(glims_ctx* h, int with_mechanics) {
   h->vS.alloc(ne);
   h->vA.alloc(ne);
   assemble_planes<D, 2>(h, MODE_M, 0, PlaneOut{{h->vM.p, h->vS.p, nullptr}, {1, 1, 0}, {0, 0, 0}});
-  if (h->pair_A)
-    hipLaunchKernelGGL((k_plane_to_pairs<double, double>), dim3(p.n_slices), dim3(GL_WAVE), 0, h->st, p.n_slices,
-                       p.slice_ptr.p, h->vS.p, h->vA.p);
-  else
-    GL_HIP(hipMemcpyAsync(h->vA.p, h->vS.p, ne * sizeof(double), hipMemcpyDeviceToDevice, h->st));
+  GL_HIP(hipMemcpyAsync(h->vA.p, h->vS.p, ne * sizeof(double), hipMemcpyDeviceToDevice, h->st));
   if (h->jac32) {
     h->vA32.alloc(ne);
-    if (h->pair_A)
-      hipLaunchKernelGGL((k_plane_to_pairs<double, float>), dim3(p.n_slices), dim3(GL_WAVE), 0, h->st, p.n_slices,
-                         p.slice_ptr.p, h->vS.p, h->vA32.p);
-    else
-      hipLaunchKernelGGL(k_to_float, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, h->st, (int64_t)ne, h->vS.p,
-                         h->vA32.p);
+    hipLaunchKernelGGL(k_to_float, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, h->st, (int64_t)ne, h->vS.p,
+                       h->vA32.p);
     GL_HIP(hipGetLastError());
   }
-  if (h->pair_A && p.cols16p.n != (size_t)p.total_entries) {
-    p.cols16p.alloc((size_t)p.total_entries);
-    hipLaunchKernelGGL((k_plane_to_pairs<uint16_t, uint16_t>), dim3(p.n_slices), dim3(GL_WAVE), 0, h->st, p.n_slices,
-                       p.slice_ptr.p, p.cols16.p, p.cols16p.p);
-  }
-  GL_HIP(hipGetLastError());
   p.cw.alloc((size_t)p.total_corners);
   {
     const int bs = 256;
@@ -1059,24 +965,22 @@ void gl_rd_assemble(glims_ctx* h, const double* c, const double* b, const double
   const DevPattern& p = h->pat;
   const uint8_t* fx = h->have_fixed_c ? h->fixed_c.p : nullptr;
   // Kernel configuration (measured best): cached (not non-temporal) streams, 24 incidence records
-  // in flight per lane, one slice per block dealt to the XCDs in chunks.  AT / PAIR: the Newton Jacobian is written in
-  // fp64 or (GLIMS_FLAG_FP32_JACOBIAN) fp32, slot-major or -- when every slice has 16-bit column codes -- slot-pair.
-#define GL_RD(NV, CIDX, AT, PAIR, APTR)                                                                             \
+  // in flight per lane, one slice per block dealt to the XCDs in chunks.  AT: the Newton Jacobian is written in fp64 or
+  // (GLIMS_FLAG_FP32_JACOBIAN) fp32.
+#define GL_RD(NV, CIDX, AT, APTR)                                                                                   \
   do {                                                                                                             \
-    set_lds(k_rd_assemble<NV, 0, 24, CIDX, AT, PAIR>, lds);                                                        \
-    hipLaunchKernelGGL((k_rd_assemble<NV, 0, 24, CIDX, AT, PAIR>), dim3(grid), dim3(GL_WAVE), lds, h->st, list,     \
+    set_lds(k_rd_assemble<NV, 0, 24, CIDX, AT>, lds);                                                              \
+    hipLaunchKernelGGL((k_rd_assemble<NV, 0, 24, CIDX, AT>), dim3(grid), dim3(GL_WAVE), lds, h->st, list,           \
                        h->n_own, p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, p.win_ok.p, p.cslice_ptr.p,     \
                        p.cslots.p, p.cw.p, p.diag_k.p, h->vS.p, APTR, c, b, b2, r_out, r2_out, h->dinv.p, fx,        \
                        2.0 * h->opt.dt, partials, cap, GL_XCD_CHUNK);                                              \
   } while (0)
 #define GL_RDV(NV)                                                                                                  \
   do {                                                                                                             \
-    if (h->pair_A && h->jac32) GL_RD(NV, 1, float, 1, h->vA32.p);                                                  \
-    else if (h->pair_A) GL_RD(NV, 1, double, 1, h->vA.p);                                                          \
-    else if (h->jac32 && h->use_idx16) GL_RD(NV, 1, float, 0, h->vA32.p);                                          \
-    else if (h->jac32) GL_RD(NV, 0, float, 0, h->vA32.p);                                                          \
-    else if (h->use_idx16) GL_RD(NV, 1, double, 0, h->vA.p);                                                       \
-    else GL_RD(NV, 0, double, 0, h->vA.p);                                                                         \
+    if (h->jac32 && h->use_idx16) GL_RD(NV, 1, float, h->vA32.p);                                                  \
+    else if (h->jac32) GL_RD(NV, 0, float, h->vA32.p);                                                             \
+    else if (h->use_idx16) GL_RD(NV, 1, double, h->vA.p);                                                          \
+    else GL_RD(NV, 0, double, h->vA.p);                                                                            \
   } while (0)
   // one launch per row-length class: the LDS footprint (2 * cap * 512 B per wave) decides the occupancy, so the
   // (few) long rows of an unstructured mesh must not size it for everybody
@@ -1113,28 +1017,30 @@ void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* s
   const int grid = gl_spmv_grid(n_launch);
   const int chunk = (n_launch + grid - 1) / grid;
   const int remap = slice_list ? 0 : GL_XCD_CHUNK;
-  const bool pair = h->pair_A && (vals == h->vA.p || (vals32 && vals32 == h->vA32.p));
   // ev0 / ev1 (glims_options.time_kernels): start / stop events attached to THIS dispatch (hipExtLaunchKernelGGL) --
   // the kernel's own timestamps, no extra packets in the queue.  hipEventRecord before and after the launch put a
   // 5-6 us idle gap on either side of every SpMV (profiles/r02_c3_timeline.txt), 14 % of the step at 1 M rows.
-  // (plain launch without events: that is the form stream capture is specified for)
-#define GL_SPMV4(DOTS, CIDX, VT, PAIR, VPTR, C16)                                                                    \
+  // Entries in flight per lane (h->spmv_unroll): 8 on lattice meshes, 16 -- a whole typical row -- on general ones, where
+  // the x gather misses the caches far more often (1 M-point Delaunay mesh: 58.5 / 52.5 / 48.7 us with 4 / 8 / 16; the
+  // brain-extent box at 10 M rows: 332 / 323 / 323 us isolated, 366 / 356 / 379 inside the time steps).
+  const int unr = h->spmv_unroll;
+#define GL_SPMV4(DOTS, UNR, CIDX, VT, VPTR)                                                                          \
   do {                                                                                                               \
     if (ev0 || ev1)                                                                                                  \
-      hipExtLaunchKernelGGL((k_spmv<DOTS, 4, 1, CIDX, VT, PAIR>), dim3(grid), dim3(256), 0, st, ev0, ev1, 0, n_launch, \
-                            chunk, slice_list, h->n_own, p.slice_ptr.p, p.cols.p, C16, p.win_base.p, p.win_ok.p,     \
-                            p.diag_k.p, VPTR, x, y, fixed, addv, r, partials, partial_off, done, remap);             \
+      hipExtLaunchKernelGGL((k_spmv<DOTS, UNR, 1, CIDX, VT>), dim3(grid), dim3(256), 0, st, ev0, ev1, 0, n_launch,    \
+                            chunk, slice_list, h->n_own, p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p,          \
+                            p.win_ok.p, p.diag_k.p, p.rlen.p, VPTR, x, y, fixed, addv, r, partials, partial_off,     \
+                            done, remap);                                                                            \
     else                                                                                                             \
-      hipLaunchKernelGGL((k_spmv<DOTS, 4, 1, CIDX, VT, PAIR>), dim3(grid), dim3(256), 0, st, n_launch, chunk,         \
-                         slice_list, h->n_own, p.slice_ptr.p, p.cols.p, C16, p.win_base.p, p.win_ok.p, p.diag_k.p,   \
-                         VPTR, x, y, fixed, addv, r, partials, partial_off, done, remap);                            \
+      hipLaunchKernelGGL((k_spmv<DOTS, UNR, 1, CIDX, VT>), dim3(grid), dim3(256), 0, st, n_launch, chunk, slice_list, \
+                         h->n_own, p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, p.win_ok.p, p.diag_k.p,        \
+                         p.rlen.p, VPTR, x, y, fixed, addv, r, partials, partial_off, done, remap);                  \
   } while (0)
 #define GL_SPMV3(DOTS, CIDX)                                                                                         \
   do {                                                                                                               \
-    if (pair && vals32) GL_SPMV4(DOTS, 1, float, 1, vals32, p.cols16p.p);                                            \
-    else if (pair) GL_SPMV4(DOTS, 1, double, 1, vals, p.cols16p.p);                                                  \
-    else if (vals32) GL_SPMV4(DOTS, CIDX, float, 0, vals32, p.cols16.p);                                             \
-    else GL_SPMV4(DOTS, CIDX, double, 0, vals, p.cols16.p);                                                          \
+    if (vals32) GL_SPMV4(DOTS, 8, CIDX, float, vals32);                                                              \
+    else if (unr >= 16) GL_SPMV4(DOTS, 16, CIDX, double, vals);                                                      \
+    else GL_SPMV4(DOTS, 8, CIDX, double, vals);                                                                      \
   } while (0)
   if (r) {
     if (h->use_idx16) GL_SPMV3(1, 1); else GL_SPMV3(1, 0);

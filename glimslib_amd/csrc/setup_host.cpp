@@ -263,6 +263,7 @@ void build_host_pattern(HostPattern& hp, int dim, int64_t n_nodes, int64_t n_own
   hp.max_clen = max_clen;
   hp.cols.resize(hp.slice_ptr[n_slices]);
   hp.diag_k.assign((size_t)n_slices * GL_WAVE, 0);
+  hp.rlen.assign((size_t)n_slices * GL_WAVE, 0);
   hp.cslots.assign(hp.cslice_ptr[n_slices], 0u);
   hp.celem.assign(hp.cslice_ptr[n_slices], -1);
   std::vector<uint8_t> is_boundary(n_slices, 0);
@@ -291,6 +292,7 @@ void build_host_pattern(HostPattern& hp, int dim, int64_t n_nodes, int64_t n_own
           if (row[k] >= n_own) bnd = true;
         }
         for (int k = rl; k < len; ++k) hp.cols[base + (int64_t)k * GL_WAVE + l] = (int32_t)r;
+        hp.rlen[r] = (uint8_t)rl;
         int q = 0;
         for (int64_t a = adj_ptr[o]; a < adj_ptr[o + 1]; ++a, ++q) {
           const int32_t e = adj[a];

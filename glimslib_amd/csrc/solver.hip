@@ -1066,11 +1066,15 @@ void glims_ctx::timing_collect() {
   double* meds[TK_COUNT] = {&stats.us_spmv_median, &stats.us_sweep_median, &stats.us_update_median,
                             &stats.us_mgfine_median, &stats.us_spmvb_median};
   for (int c = 0; c < TK_COUNT; ++c) {
-    float dmax = 0.f;
-    for (float t : d[c]) dmax = std::max(dmax, t);
+    if (d[c].empty()) continue;
+    // reference duration = the upper quartile (no-op launches are the SHORT ones; a single pair that straddles a
+    // preemption must not set the scale -- it once made every real launch look like a no-op): keep 0.2x .. 5x of it
+    std::vector<float> sorted(d[c]);
+    std::nth_element(sorted.begin(), sorted.begin() + (sorted.size() * 3) / 4, sorted.end());
+    const float ref = sorted[(sorted.size() * 3) / 4];
     std::vector<float> real;
     for (float t : d[c])
-      if (t > 0.2f * dmax) real.push_back(t);
+      if (t > 0.2f * ref && t < 5.0f * ref) real.push_back(t);
     for (float t : real) {
       *sums[c] += t;
       ++*cnts[c];

@@ -242,6 +242,7 @@ __global__ __launch_bounds__(GL_WAVE) void k_fill_pattern(int64_t n_own, int nv,
                                                            const int32_t* __restrict__ cells,
                                                            const int32_t* __restrict__ old2new,
                                                            int32_t* __restrict__ cols, uint8_t* __restrict__ diag_k,
+                                                           uint8_t* __restrict__ rlen,
                                                            uint32_t* __restrict__ cslots, int32_t* __restrict__ celem,
                                                            uint8_t* __restrict__ is_boundary) {
   const int s = blockIdx.x, l = threadIdx.x;
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(GL_WAVE) void k_fill_pattern(int64_t n_own, int nv,
       cslots[cbase + (int64_t)q * GL_WAVE + l] = 0u;
     }
     diag_k[r] = 0;
+    rlen[r] = 0;
   } else {
     int32_t a[ROW_CAP];
     int n = 0;
@@ -271,6 +273,7 @@ __global__ __launch_bounds__(GL_WAVE) void k_fill_pattern(int64_t n_own, int nv,
       bnd = bnd || a[k] >= n_own;
     }
     for (int k = n; k < len; ++k) cols[base + (int64_t)k * GL_WAVE + l] = (int32_t)r;
+    rlen[r] = (uint8_t)n;
     int q = 0;
     for (int64_t p = q0; p < q1; ++p, ++q) {
       const int32_t e = adj[p];
@@ -625,12 +628,13 @@ void gl_build_pattern_device(glims_ctx* h, const double* d_xyz, const int32_t* d
   p.cslice_ptr.upload(cslice_ptr, st);
   p.cols.alloc((size_t)p.total_entries);
   p.diag_k.alloc((size_t)n_slices * GL_WAVE);
+  p.rlen.alloc((size_t)n_slices * GL_WAVE);
   p.cslots.alloc((size_t)p.total_corners);
   p.celem.alloc((size_t)p.total_corners);
   dvec<uint8_t> is_boundary;
   is_boundary.alloc((size_t)n_slices);
   hipLaunchKernelGGL(k_fill_pattern, dim3(n_slices), dim3(GL_WAVE), 0, st, n_own, nv, p.slice_ptr.p, p.cslice_ptr.p, row_m.p,
-                     adj_ptr.p, adj.p, d_cells, h->d_old2new.p, p.cols.p, p.diag_k.p, p.cslots.p, p.celem.p, is_boundary.p);
+                     adj_ptr.p, adj.p, d_cells, h->d_old2new.p, p.cols.p, p.diag_k.p, p.rlen.p, p.cslots.p, p.celem.p, is_boundary.p);
   GL_HIP(hipGetLastError());
   lap("slice offsets, columns + incidences");
 

@@ -279,11 +279,11 @@ int glims_rd_residual(glims_ctx* h, const double* c, const double* c_prev, doubl
  *   glims_get_numbering     old2new[n_nodes]: internal index of the caller's node i (ghosts keep their index)
  *   glims_pattern_checksum  64-bit FNV-1a hashes of the device arrays, in this order: slice offsets, columns, 16-bit
  *                           column codes, window bases, window flags, diagonal slots, incidence offsets, incidence slots,
- *                           incidence cells, interior slice list, boundary slice list, numbering (12 values).  Two handles
+ *                           incidence cells, interior slice list, boundary slice list, numbering, row lengths (13 values).  Two handles
  *                           with equal checksums hold identical discretisation structures (tests compare the device-built
  *                           structures with the host implementation kept behind the test hook GLIMS_HOST_SYMBOLIC). */
 int glims_get_numbering(glims_ctx* h, int32_t* old2new);
-int glims_pattern_checksum(glims_ctx* h, uint64_t out[12]);
+int glims_pattern_checksum(glims_ctx* h, uint64_t out[13]);
 
 /* ---- device-resident time series ----------------------------------------------------------------------------------
  * Results.add_to_results deep-copies the mixed solution on the host at every recorded step

@@ -16,7 +16,7 @@ from glimslib_amd.mesh import BoxMesh, RectangleMesh
 pytestmark = pytest.mark.gpu
 
 NAMES = ["slice_ptr", "cols", "cols16", "win_base", "win_ok", "diag_k", "cslice_ptr", "cslots", "celem", "interior",
-         "boundary", "numbering"]
+         "boundary", "numbering", "rlen"]
 
 
 def _both(backend, points, cells, label, n_own=None, env=None):
