@@ -1067,11 +1067,11 @@ void glims_ctx::timing_collect() {
                             &stats.us_mgfine_median, &stats.us_spmvb_median};
   for (int c = 0; c < TK_COUNT; ++c) {
     if (d[c].empty()) continue;
-    // reference duration = the upper quartile (no-op launches are the SHORT ones; a single pair that straddles a
+    // reference duration = the 90th percentile (no-op launches are the SHORT ones; a single pair that straddles a
     // preemption must not set the scale -- it once made every real launch look like a no-op): keep 0.2x .. 5x of it
     std::vector<float> sorted(d[c]);
-    std::nth_element(sorted.begin(), sorted.begin() + (sorted.size() * 3) / 4, sorted.end());
-    const float ref = sorted[(sorted.size() * 3) / 4];
+    std::nth_element(sorted.begin(), sorted.begin() + (sorted.size() * 9) / 10, sorted.end());
+    const float ref = sorted[(sorted.size() * 9) / 10];
     std::vector<float> real;
     for (float t : d[c])
       if (t > 0.2f * ref && t < 5.0f * ref) real.push_back(t);
