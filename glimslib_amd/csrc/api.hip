@@ -109,7 +109,7 @@ int glims_options_default(glims_options* o) {
   o->mech_history = 8;
   o->mg_smooth = 3;
   o->mg_coarse_nodes = 216;
-  o->mg_h_factor = 2.0;
+  o->mg_h_factor = 0.0;
   o->mg_cheb_ratio = 0.0;
   o->time_kernels = 0;
   o->rd_precond = GLIMS_RD_PRECOND_AUTO;
@@ -345,7 +345,7 @@ int glims_set_options(glims_ctx* h, const glims_options* opt) {
     GL_REQUIRE(opt->mech_precond == GLIMS_PRECOND_BLOCK_JACOBI || opt->mech_precond == GLIMS_PRECOND_MULTIGRID,
                "unknown mech_precond");
     GL_REQUIRE(opt->mech_mixed >= 0 && opt->mech_mixed <= 2 && opt->mech_history >= 0 && opt->mg_smooth >= 1 &&
-                   opt->mg_coarse_nodes >= 1 && opt->mg_h_factor > 0.0 && (opt->mg_cheb_ratio == 0.0 || opt->mg_cheb_ratio > 1.0),
+                   opt->mg_coarse_nodes >= 1 && opt->mg_h_factor >= 0.0 && (opt->mg_cheb_ratio == 0.0 || opt->mg_cheb_ratio > 1.0),
                "bad elasticity solver options");
     GL_REQUIRE(opt->rd_precond >= GLIMS_RD_PRECOND_AUTO && opt->rd_precond <= GLIMS_RD_PRECOND_MULTIGRID &&
                    opt->rd_mg_smooth >= 0 && opt->rd_mg_smooth <= 8,

@@ -1261,7 +1261,13 @@ void mg_setup_t(glims_ctx* h, MgHierarchy& mg) {
   GL_REQUIRE(mg.op_vals && mg.op_dinv && mg.bs == BS, "multigrid set-up without an operator");
   GL_REQUIRE(h->xyz_new.n == (size_t)h->n_nodes * D, "mesh coordinates missing");
   const uint8_t* fx = mg.op_fixed;
-  const double hf = h->opt.mg_h_factor > 0.5 ? h->opt.mg_h_factor : 2.0;
+  // spacing of the first grid in units of the mesh width.  One GPU: 2 (measured on config C5, zero guess: 16 / 22 / 28
+  // iterations and 19.5 / 25.8 / 33.6 ms per solve with 2 / 3 / 4).  Partitioned runs with a global frame replicate the
+  // Cartesian levels on every rank -- work that does not shrink with the rank count -- so a coarser first grid pays from
+  // three ranks on: per-rank operator complexity 1 + 1.8 * 1.14 * ranks / factor^3, i.e. 2.03 -> 1.30 at 4 ranks with 3,
+  // 3.05 -> 1.26 at 8 ranks with 4, and the residual all-reduce per cycle shrinks by the same factor^3 / 8.
+  const double hf = h->opt.mg_h_factor > 0.5 ? h->opt.mg_h_factor
+                    : !(h->world > 1 && h->mg_frame_set) || h->world <= 2 ? 2.0 : h->world <= 6 ? 3.0 : 4.0;
   const int coarse_max = std::max(8, h->opt.mg_coarse_nodes);
 
   // ---- partitioned runs: one global index frame for the auxiliary grids -------------------------------------------

@@ -85,8 +85,10 @@ typedef struct glims_options {
                              (1 = damped block-Jacobi)                                             default 3     */
   int    mg_coarse_nodes; /* coarsen until a grid has at most this many nodes; that level is solved with a dense
                              inverse computed once (Gauss-Jordan on the device)                     default 216   */
-  double mg_h_factor;     /* spacing of the first auxiliary Cartesian grid in units of the mesh width
-                             (lattice meshes: of the lattice constant per axis)                    default 2.0   */
+  double mg_h_factor;     /* spacing of the first auxiliary Cartesian grid in units of the mesh width (lattice meshes:
+                             of the lattice constant per axis); 0 = 2 on one GPU, and in partitioned runs with a global
+                             frame (glims_set_mg_frame), whose Cartesian levels are replicated on every rank, 2 / 3 / 4
+                             for <= 2 / <= 6 / more ranks                                          default 0     */
   double mg_cheb_ratio;   /* the Chebyshev smoothers act on [lambda_max / ratio, lambda_max] of Dinv A;
                              0 = by mesh class: 30 on lattice meshes, 10 on general ones (measured)  default 0     */
   int    time_kernels;    /* HIP-event pairs on the handle's stream around hot kernels of glims_step: 1 = the Krylov

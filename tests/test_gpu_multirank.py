@@ -294,7 +294,7 @@ def _mech_worker(rank, world, port, out_dir, n, framed):
         u = h.get_state()[1].reshape(-1, 3)
         st = h.stats()
         np.savez(os.path.join(out_dir, "mech_%d_rank%d.npz" % (int(framed), rank)), gid=part.global_ids, n_own=part.n_own,
-                 u=u, status=sm, its=st['mech_cg_its'], levels=st['mg_levels'])
+                 u=u, status=sm, its=st['mech_cg_its'], levels=st['mg_levels'], complexity=st['mg_complexity'])
         h.close()
     finally:
         dist.destroy_process_group()
@@ -316,7 +316,8 @@ def test_partitioned_elasticity_multigrid_with_replicated_coarse_levels(tmp_path
     h = backend.Handle(w.mesh.points, w.mesh.cells, w.cell_label)
     t = w.tables
     h.set_materials(t['D'], t['rho'], t['gamma'], t['E'], t['nu'])
-    h.set_options(dt=w.dt, mech_history=0)
+    # (the first grid's spacing of a framed partitioned run: 2 h up to two ranks, 3 h up to six -- the same on one rank here)
+    h.set_options(dt=w.dt, mech_history=0, mg_h_factor=2.0 if world <= 2 else 3.0)
     dofs = (np.asarray(w.dirichlet_nodes)[:, None] * 3 + np.arange(3)).ravel()
     h.set_dirichlet_u(dofs, np.zeros(len(dofs)))
     h.setup(True)
@@ -335,10 +336,14 @@ def test_partitioned_elasticity_multigrid_with_replicated_coarse_levels(tmp_path
             own = int(z['n_own'])
             u[z['gid'][:own]] = z['u'][:own]
             its[framed] = int(z['its'])
+            if framed:
+                cx = float(z['complexity'])
         assert not np.isnan(u).any()
         assert rel_l2(u, u1) < 1e-7, (framed, rel_l2(u, u1))
-    print("n = %d, %d ranks: PCG iterations single rank %d, replicated coarse levels %d, rank-local hierarchy %d" %
-          (n, world, its1, its[True], its[False]))
+    print("n = %d, %d ranks: PCG iterations single rank %d, replicated coarse levels %d (per-rank operator complexity "
+          "%.2f), rank-local hierarchy %d" % (n, world, its1, its[True], cx, its[False]))
+    if world >= 4:
+        assert cx <= 1.5            # 2.11 with a first grid of spacing 2 h replicated on 4 ranks (1.30 on a large mesh)
     assert abs(its[True] - its1) <= 2
     assert its[True] < its[False]
 

@@ -26,7 +26,7 @@ h.set_materials(t['D'], t['rho'], t['gamma'], t['E'], t['nu'])
 pre = _backend.PRECOND_BLOCK_JACOBI if os.environ.get("PRECOND", "mg") == "bj" else _backend.PRECOND_MULTIGRID
 h.set_options(dt=w.dt, mech_rtol=float(os.environ.get("MECH_RTOL", "1e-10")), mech_precond=pre,
               mg_smooth=int(os.environ.get("SMOOTH", "3")), mg_cheb_ratio=float(os.environ.get("RATIO", "0")), mech_mixed=int(os.environ.get("MIXED", "1")),
-              mech_history=int(os.environ.get("HIST", "6")), mg_h_factor=float(os.environ.get("HFAC", "2.0")),
+              mech_history=int(os.environ.get("HIST", "6")), mg_h_factor=float(os.environ.get("HFAC", "0")),
               mg_coarse_nodes=int(os.environ.get("COARSE", "216")),
               flags=h.options.flags | (_backend.FLAG_MG_FP32_SMOOTHER if os.environ.get("FP32SM") else 0) |
               (_backend.FLAG_MG_FP64_VECTORS if os.environ.get("X64") else 0))
