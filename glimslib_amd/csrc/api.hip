@@ -253,6 +253,7 @@ int glims_create(glims_ctx** out, int dim, int64_t n_nodes, int64_t n_own, int64
     h->partials2.alloc_zero((size_t)(p.n_slices * 3 + 4096) / 1024 * 3 + 64, h->st);
     // block pairs of the vector kernels (grid_for caps at 4096 blocks) or of the multigrid cycle's last level-0 pass
     h->partials_v.alloc_zero((size_t)std::max(2 * 4096, 2 * (p.n_slices / 4 + 1)) + 64, h->st);
+    h->partials_rr.alloc_zero(2 * 4096 + 64, h->st);
     h->red.alloc_zero(4, h->st);
     h->scal.alloc_zero(2 * SC_COUNT + 8, h->st);
     h->done.alloc_zero(1, h->st);

@@ -426,7 +426,8 @@ struct glims_ctx {
 
   dvec<double> partials, partials2;        // per-block partial sums (stage 1 / stage 2 of the reduction)
   dvec<double> partials_v;                 // (r.u, r.r) pairs per block of the PCG vector kernels
-  dvec<double> red;                        // [4] reduced sums
+  dvec<double> partials_rr;                // (-, r.r) pairs of the vector update when the preconditioner is a V-cycle
+  dvec<double> red;                        // [4] reduced sums ([3]: the early convergence check's |r|^2)
   dvec<double> scal;                       // [SC_COUNT] recurrence scalars
   dvec<int> done;                          // [1] 0 running, 1 converged, 2 non-finite, 3 breakdown
   double* h_pinned = nullptr;              // pinned, device-mapped mailbox [seq | red[4] | info[2] | done] (32 doubles)

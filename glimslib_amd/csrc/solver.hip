@@ -236,8 +236,11 @@ __global__ __launch_bounds__(256) void k_cg_update(int64_t n_own, const double* 
       p[j] = pi;
       s[j] = si;
       x[j] += alpha * pi;
-      r[j] -= alpha * si;
+      const double rn = r[j] - alpha * si;
+      r[j] = rn;
+      pr += rn * rn;
     }
+    block_sum2(0.0, pr, pv);   // |r|^2 of the new residual, for the early convergence check (k_early_done)
     return;
   }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_own; i += stride) {
@@ -388,6 +391,57 @@ __global__ __launch_bounds__(1024) void k_reduce_cg(int ns, const double* __rest
     red[threadIdx.x] = t;
   }
   if (nm.slots) node_allreduce(red, 3, nm);
+}
+
+// Early convergence check.  The recurrence notices a converged residual one iteration late: the vector update of
+// iteration k leaves the partial sums of |r_k|^2, and it is the update of iteration k + 1 that reads their total -- after
+// another preconditioner application and another operator pass whose results nobody uses.  One such pair per solve: a
+// V-cycle + SpMV of 1.15 ms on the 10 ms elasticity solve of config C5, a 0.36 ms SpMV on each of the 3.1 Newton solves of
+// a C4 step (8 % of the step).  This kernel sums the partials right after the update (rr pairs at pv[i * 2 + 1]) and sets
+// the decision word when the tolerance is met, so that everything enqueued behind it returns at once.  The host inserts
+// it where convergence is expected (from the previous solve's count; after every update when each iteration carries a
+// V-cycle).  `decide` = 0: partitioned run without the node mailbox -- the sum goes to red[3], an all-reduce follows,
+// k_early_decide takes the decision.
+__global__ __launch_bounds__(1024) void k_early_done(int nv, const double* __restrict__ pv, double tol2,
+                                                      double* __restrict__ red, double* __restrict__ info,
+                                                      int* __restrict__ done, int decide, const NodeMail nm) {
+  if (*done) return;
+  __shared__ double sm[16];
+  double a0 = 0.0, a1 = 0.0;
+  int i = threadIdx.x;
+  for (; i + 1024 < nv; i += 2048) {
+    a0 += pv[(size_t)i * 2 + 1];
+    a1 += pv[(size_t)(i + 1024) * 2 + 1];
+  }
+  for (; i < nv; i += 1024) a0 += pv[(size_t)i * 2 + 1];
+  double v = a0 + a1;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += sm[w];
+    red[3] = t;
+  }
+  if (nm.slots) node_allreduce(red + 3, 1, nm);
+  __syncthreads();
+  if (decide && threadIdx.x == 0) {
+    const double rr = red[3];
+    if (isfinite(rr) && rr <= tol2) {
+      info[1] = rr;
+      *done = 1;
+    }
+  }
+}
+__global__ void k_early_decide(const double* __restrict__ red, double tol2, double* __restrict__ info,
+                               int* __restrict__ done) {
+  if (*done) return;
+  const double rr = red[3];
+  if (isfinite(rr) && rr <= tol2) {
+    info[1] = rr;
+    *done = 1;
+  }
 }
 
 // Hands the host everything it decides on in ONE store sequence into pinned host memory:
@@ -958,7 +1012,8 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
   const int batch = h->opt.check_every > 0 ? h->opt.check_every : 8;
   int enq = 0;
   double* info_dev = h->scal.p + 2 * SC_COUNT;
-  auto iteration = [&](int parity) {   // one Krylov iteration: operator, reduction, recurrence + vector update, M^-1
+  // one Krylov iteration: operator, reduction, recurrence + vector update, [early convergence check], M^-1
+  auto iteration = [&](int parity, bool early) {
     const double* prev = h->scal.p + parity * SC_COUNT;
     double* cur = h->scal.p + (parity ^ 1) * SC_COUNT;
     apply_with_halo(h, v);
@@ -968,9 +1023,21 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
     allreduce_sum(h, h->red.p, 3);
     const bool timed_upd = v.vals && h->timing(glims_ctx::TK_UPDATE);
     if (timed_upd) h->tick(glims_ctx::TK_UPDATE);
+    // (with an external preconditioner the update's |r|^2 pairs go to a buffer of their own: partials_v is rewritten by
+    //  the cycle's last kernel)
     GL_VEC(k_cg_update, n, h->red.p, prev, cur, info_dev, h->done.p, tol2, v.p, v.s, v.x, v.r, v.u, v.w, v.dinv,
-           h->partials_v.p, /*nt=*/0, pm, ext);
+           ext ? h->partials_rr.p : h->partials_v.p, /*nt=*/0, pm, ext);
     if (timed_upd) h->tick(glims_ctx::TK_UPDATE);
+    if (early) {
+      const bool decide = h->world <= 1 || h->nm.slots != nullptr;
+      hipLaunchKernelGGL(k_early_done, dim3(1), dim3(1024), 0, h->st, (int)g, ext ? h->partials_rr.p : h->partials_v.p,
+                         tol2, h->red.p, info_dev, h->done.p, decide ? 1 : 0, h->nm);
+      if (!decide) {
+        allreduce_sum(h, h->red.p + 3, 1);
+        hipLaunchKernelGGL(k_early_decide, dim3(1), dim3(1), 0, h->st, h->red.p, tol2, info_dev, h->done.p);
+      }
+      GL_HIP(hipGetLastError());
+    }
     precondition();
   };
   while (enq < maxit + 1) {
@@ -979,7 +1046,9 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
     //  behind the decision word still costs its ~25 launches, and the residual test of the Newton iteration decides anyway)
     if (hint > 0) want = enq == 0 ? hint + (defer && !ext ? 2 : 1) : std::max(2, std::min(batch, hint / 4 + 1));
     const int nb = std::min(want, maxit + 1 - enq);
-    for (int j = 0; j < nb; ++j) iteration((enq + j) & 1);
+    // early check: after every update when an iteration carries a V-cycle or the count is unknown, otherwise from the
+    // iteration before the expected last one on
+    for (int j = 0; j < nb; ++j) iteration((enq + j) & 1, ext || hint <= 0 || enq + j + 2 >= hint);
     enq += nb;
     if (defer && hint > 0) {
       *its_out = -1;
