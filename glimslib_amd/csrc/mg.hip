@@ -1661,6 +1661,8 @@ void mg_setup_t(glims_ctx* h, MgHierarchy& mg) {
       ok = dense_spd_inverse_device(h, mg.coarse_inv.p, nc, col.p, bad.p);
       for (int i = 0; i < nc; ++i) M[(size_t)i * nc + i] -= shift * dmax;
     }
+    // (partitioned runs: this check and the size check above look at REPLICATED data -- the coarsest operator is the same
+    //  on every rank -- so all ranks throw together and nobody is left waiting in a collective)
     GL_REQUIRE(ok, "multigrid: the coarsest operator is not positive definite");
   }
   lap("coarsest level: dense inverse");

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void k_cg_init(int64_t n_own, const double* __
                                                   int* __restrict__ done, const PackMap pm, int ext) {
   if (blockIdx.x == 0 && threadIdx.x < 2 * SC_COUNT + 2) scal[threadIdx.x] = 0.0;
   if (blockIdx.x == 0 && threadIdx.x == 0) *done = 0;
-  if (ext) return;   // external preconditioner (multigrid): u and the (r.u, r.r) partials come from k_dot2 after the cycle
+  if (ext) return;   // external preconditioner (multigrid): u and the (r.u, r.r) partials come out of the cycle's last kernel
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   double pg = 0.0, pr = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_own; i += stride) {
@@ -607,20 +607,6 @@ __global__ void k_block_dinv(int64_t n_own, const int64_t* __restrict__ slice_pt
     o[7] = (A[0][1] * A[2][0] - A[0][0] * A[2][1]) * inv;
     o[8] = (A[0][0] * A[1][1] - A[0][1] * A[1][0]) * inv;
   }
-}
-
-// (r.u, r.r) partial pairs per block, the layout k_reduce_cg expects from the vector kernels (external preconditioner)
-__global__ __launch_bounds__(256) void k_dot2(int64_t n, const double* __restrict__ r, const double* __restrict__ u,
-                                               double* __restrict__ pv, const int* __restrict__ done) {
-  if (done && *done) return;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  double pg = 0.0, pr = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const double ri = r[i];
-    pg += ri * u[i];
-    pr += ri * ri;
-  }
-  block_sum2(pg, pr, pv);
 }
 
 inline unsigned grid_for(int64_t n, int bs = 256, int64_t cap = 256 * 16) {
