@@ -1029,11 +1029,11 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
   while (enq < maxit + 1) {
     int want = batch;
     // First batch = the previous solve's count: convergence is noticed by the early check right after the last update,
-    // not one iteration later.  With the Jacobi scaling a spare iteration or two (three no-op launches each) make a miss
-    // unlikely; with a V-cycle per iteration a spare one would cost its ~25 no-op launches, so there is none -- a solve
-    // that comes one iteration short is polled on (elasticity) or is a slightly weaker Newton step (deferred RD solves,
-    // whose own residual test decides)
-    if (hint > 0) want = enq == 0 ? hint + (ext ? 0 : defer ? 2 : 1) : std::max(2, std::min(batch, hint / 4 + 1));
+    // not one iteration later.  With the Jacobi scaling one spare iteration (three no-op launches if unused) makes a miss
+    // unlikely (two spares: +1.5 % step time at 1 M rows, same counts); with a V-cycle per iteration a spare one would cost
+    // its ~25 no-op launches, so there is none -- a solve that comes one iteration short is polled on (elasticity) or is a
+    // slightly weaker Newton step (deferred RD solves, whose own residual test decides)
+    if (hint > 0) want = enq == 0 ? hint + (ext ? 0 : 1) : std::max(2, std::min(batch, hint / 4 + 1));
     const int nb = std::min(want, maxit + 1 - enq);
     // early check: after every update when an iteration carries a V-cycle or the count is unknown, otherwise from the
     // iteration before the expected last one on
