@@ -363,7 +363,7 @@ int glims_set_options(glims_ctx* h, const glims_options* opt) {
     if (opt->mech_history != h->opt.mech_history) h->mh_count = h->mh_next = 0;
     if (opt->dt != h->opt.dt) h->is_setup = false;
     if ((opt->flags ^ h->opt.flags) & (GLIMS_FLAG_FP32_JACOBIAN | GLIMS_FLAG_INT32_COLUMNS)) h->is_setup = false;
-    if ((opt->flags ^ h->opt.flags) & (GLIMS_FLAG_MG_FP32_SMOOTHER | GLIMS_FLAG_MG_FP64_VECTORS))
+    if ((opt->flags ^ h->opt.flags) & (GLIMS_FLAG_MG_FP32_SMOOTHER | GLIMS_FLAG_MG_FP64_VECTORS | GLIMS_FLAG_MG_WHOLE_GRID))
       h->mg.ready = h->mg_rd.ready = false;
     h->opt = *opt;
     h->pending = false;

@@ -211,6 +211,11 @@ struct MgHierarchy {
   bool half_smoother = true;               // level-0 smoother streams the half-precision copy of K_el
   bool x32 = false;                        // level-0 cycle vectors in single precision (XNode<BS, float> layout)
   bool exact_level0 = false;               // partitioned run with a global frame: level-0 passes see the ghosts (halo exchange)
+  // partitioned run with a global frame, replicated first grid: each rank smooths only its work box of that grid
+  bool boxed = false;
+  int core[6] = {0, 0, 0, 0, 0, 0};        // this rank's core on the first grid: lo[3], hi[3] (inclusive) of the nodes its own mesh nodes interpolate from
+  dvec<int> cores;                         // every rank's core [world][6] (owner rule of the first-grid -> second-grid restriction)
+  double box_fraction = 1.0;               // work box / first grid at the set-up's smoother degree
   dvec<double> sc;                         // level-0 scaling s = 1 / sqrt(diag K_el) per dof (1 on constrained dofs)
   dvec<float> dinv0;                       // inverse diagonal blocks of the scaled operator S K S, single precision
   dvec<float> vK32s;                       // single-precision scaled copy (GLIMS_FLAG_MG_FP32_SMOOTHER only)

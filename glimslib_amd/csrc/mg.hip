@@ -54,6 +54,30 @@ __device__ __forceinline__ long long v2lin(const int* v, const GridDev& g) {
 }
 __device__ __forceinline__ int gn(const GridDev& g, int a) { return a == 0 ? g.n0 : a == 1 ? g.n1 : g.n2; }
 
+// Work box of a rank on a REPLICATED Cartesian level (partitioned runs with a global frame): the part of the grid this rank
+// needs results on, grown by the smoothers' dependency margin.  nn = 0: the whole grid.  Threads enumerate the box, the
+// arrays keep their global indexing; what lies outside the box is simply not recomputed (and is stale).
+struct BoxDev {
+  int lo0, lo1, lo2, n0, n1, n2;
+  long long nn;
+};
+// node of thread t: false past the end; Iv / I in the level's global indexing
+__device__ __forceinline__ bool box_node(const BoxDev& b, const GridDev& g, long long t, int* Iv, long long* I) {
+  if (b.nn == 0) {
+    if (t >= g.nn) return false;
+    *I = t;
+    lin2v(t, g, Iv);
+    return true;
+  }
+  if (t >= b.nn) return false;
+  Iv[0] = b.lo0 + (int)(t % b.n0);
+  const long long q = t / b.n0;
+  Iv[1] = b.lo1 + (int)(q % b.n1);
+  Iv[2] = b.lo2 + (int)(q / b.n1);
+  *I = v2lin(Iv, g);
+  return true;
+}
+
 template <int D>
 __device__ __forceinline__ void off2v(int off, int R, int* o) {
   const int W = 2 * R + 1;
@@ -137,6 +161,20 @@ __global__ void k_mg_cell_keys(int64_t n, const int32_t* __restrict__ cell0, uin
   if (i >= n) return;
   key[i] = (uint32_t)cell0[i];
   val[i] = (int32_t)i;
+}
+
+// bounding box (in level-1 cell coordinates) of the cells that hold this rank's OWNED mesh nodes: bb = {min[3], max[3]}
+template <int D>
+__global__ void k_mg_cell_bbox(int64_t n_own, GridDev g1, const int32_t* __restrict__ cell0, int* __restrict__ bb) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_own) return;
+  int cv[3];
+  lin2v(cell0[i], g1, cv);
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    atomicMin(bb + a, cv[a]);
+    atomicMax(bb + 3 + a, cv[a]);
+  }
 }
 
 // Galerkin product mesh -> first grid, A1 = P^T K P, in two gathers (no atomics, fixed summation orders).
@@ -462,13 +500,13 @@ __global__ __launch_bounds__(256) void k_mg_cart(GridDev g, int R, const AT* __r
                                                   const double* __restrict__ dinv, const double* __restrict__ xin,
                                                   const double* __restrict__ r, double* __restrict__ d,
                                                   double* __restrict__ xout, double c1, double c2,
-                                                  const int* __restrict__ done, const double* __restrict__ osc) {
+                                                  const int* __restrict__ done, const double* __restrict__ osc,
+                                                  const BoxDev box) {
   constexpr int B2 = BS * BS;
   if (done && *done) return;   // launches enqueued past the Krylov solver's convergence: nobody reads the result
-  const long long I = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (I >= g.nn) return;
   int Iv[3];
-  lin2v(I, g, Iv);
+  long long I;
+  if (!box_node(box, g, (long long)blockIdx.x * blockDim.x + threadIdx.x, Iv, &I)) return;
   double acc[BS];
 #pragma unroll
   for (int a = 0; a < BS; ++a) acc[a] = 0.0;
@@ -572,15 +610,15 @@ __global__ __launch_bounds__(256) void k_mg_cart_g(GridDev g, int R, int S, cons
                                                     const double* __restrict__ dinv, const double* __restrict__ xin,
                                                     const double* __restrict__ r, double* __restrict__ d,
                                                     double* __restrict__ xout, double c1, double c2,
-                                                    const int* __restrict__ done, const double* __restrict__ osc) {
+                                                    const int* __restrict__ done, const double* __restrict__ osc,
+                                                    const BoxDev box) {
   constexpr int B2 = BS * BS, NPW = GL_WAVE / G;   // nodes per wave
   if (done && *done) return;
   const int lane = threadIdx.x & 63;
   const int sub = lane / NPW;
-  const long long I = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * NPW + (lane % NPW);
-  const bool live = I < g.nn;
   int Iv[3] = {0, 0, 0};
-  if (live) lin2v(I, g, Iv);
+  long long I = 0;
+  const bool live = box_node(box, g, ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * NPW + (lane % NPW), Iv, &I);
   double acc[BS];
 #pragma unroll
   for (int a = 0; a < BS; ++a) acc[a] = 0.0;
@@ -619,10 +657,11 @@ __global__ __launch_bounds__(256) void k_mg_cart_g(GridDev g, int R, int S, cons
 template <int D, int BS>
 __global__ void k_mg_first_cart(GridDev g, const double* __restrict__ dinv, double* __restrict__ r,
                                 double* __restrict__ d, double* __restrict__ x, double c2,
-                                const double* __restrict__ sc, const int* __restrict__ done) {
+                                const double* __restrict__ sc, const int* __restrict__ done, const BoxDev box) {
   if (done && *done) return;
-  const long long I = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (I >= g.nn) return;
+  int Iv[3];
+  long long I;
+  if (!box_node(box, g, (long long)blockIdx.x * blockDim.x + threadIdx.x, Iv, &I)) return;
   double rv[BS];
 #pragma unroll
   for (int a = 0; a < BS; ++a) {
@@ -841,7 +880,11 @@ template <int D, int BS>
 __global__ __launch_bounds__(256) void k_mg_restrict(GridDev gf, GridDev gc, Fac fc, const double* __restrict__ res,
                                                       double* __restrict__ rc, const double* __restrict__ dinv_c,
                                                       double* __restrict__ d_c, double* __restrict__ x_c, double c2,
-                                                      const int* __restrict__ done) {
+                                                      const int* __restrict__ done, const int* __restrict__ cores,
+                                                      int n_ranks, int my_rank) {
+  // cores (partitioned runs, box-limited fine level): [n_ranks][6] = lo / hi (inclusive) of every rank's core box on the
+  // FINE level; a child counts on the lowest rank whose core holds it (a partition of unity: the partial sums of the ranks
+  // are all-reduced afterwards), children in nobody's core carry no residual
   if (done && *done) return;
   // one wave per coarse node, its (up to) 3^D children dealt to the lanes, fixed shuffle tree.  With dinv_c the first
   // smoothing step of the coarse level (from a zero iterate: d = x = c2 Dinv r, k_mg_first_cart) rides along.
@@ -870,6 +913,14 @@ __global__ __launch_bounds__(256) void k_mg_restrict(GridDev gf, GridDev gc, Fac
       iv[a] = child_index(fc, a, Iv[a], dv[a]);
       ok = ok && iv[a] >= 0 && iv[a] < gn(gf, a);
     }
+    if (ok && cores) {
+      int owner = -1;
+      for (int q = 0; q < n_ranks && owner < 0; ++q) {
+        const int* c = cores + q * 6;
+        if (iv[0] >= c[0] && iv[0] <= c[3] && iv[1] >= c[1] && iv[1] <= c[4] && iv[2] >= c[2] && iv[2] <= c[5]) owner = q;
+      }
+      ok = owner == my_rank;
+    }
     if (ok) {
       const long long i = v2lin(iv, gf);
 #pragma unroll
@@ -897,16 +948,27 @@ __global__ __launch_bounds__(256) void k_mg_restrict(GridDev gf, GridDev gc, Fac
   }
 }
 
+template <int D, int BS>
+__device__ __forceinline__ void prolong_node(const GridDev& gf, const GridDev& gc, const Fac& fc,
+                                             const double* __restrict__ ec, const double* __restrict__ xin,
+                                             double* __restrict__ xout, const double* __restrict__ isc, const int* iv,
+                                             long long i);
 // isc (fine level in scaled variables): x~ += (P e) / s
 template <int D, int BS>
 __global__ void k_mg_prolong(GridDev gf, GridDev gc, Fac fc, const double* __restrict__ ec,
                              const double* __restrict__ xin, double* __restrict__ xout,
-                             const double* __restrict__ isc, const int* __restrict__ done) {
+                             const double* __restrict__ isc, const int* __restrict__ done, const BoxDev box) {
   if (done && *done) return;
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= gf.nn) return;
   int iv[3];
-  lin2v(i, gf, iv);
+  long long i;
+  if (!box_node(box, gf, (long long)blockIdx.x * blockDim.x + threadIdx.x, iv, &i)) return;
+  prolong_node<D, BS>(gf, gc, fc, ec, xin, xout, isc, iv, i);
+}
+template <int D, int BS>
+__device__ __forceinline__ void prolong_node(const GridDev& gf, const GridDev& gc, const Fac& fc,
+                                             const double* __restrict__ ec, const double* __restrict__ xin,
+                                             double* __restrict__ xout, const double* __restrict__ isc, const int* iv,
+                                             long long i) {
   double acc[BS];
 #pragma unroll
   for (int a = 0; a < BS; ++a) acc[a] = 0.0;
@@ -1155,20 +1217,42 @@ void gl_mesh_metrics(glims_ctx* h, const HostPattern& hp, const double* xyz_old)
 // ===================================================================================================
 namespace {
 
+// Work box of this rank on the replicated first grid for smoothers of degree `deg`: its core (the grid nodes its own mesh
+// nodes interpolate from) grown by the dependency margin.  A pass of radius R is exact R nodes inside whatever its input
+// was exact on; the input outside the box is stale.  Down: deg - 1 stencil passes and the residual (exact on box - deg R,
+// needed on the core); up: the post-smoother starts from the pre-smoothed iterate (box - (deg - 1) R) and takes deg passes
+// (exact on box - (2 deg - 1) R, needed on the core).  Hence the margin (2 deg - 1) R.
+template <int D>
+BoxDev mg_work_box(const MgHierarchy& mg, const MgGrid& g, int deg) {
+  const int m = (2 * deg - 1) * mg.R;
+  int lo[3] = {0, 0, 0}, n[3] = {1, 1, 1};
+  long long nn = 1;
+  for (int a = 0; a < D; ++a) {
+    lo[a] = std::max(0, mg.core[a] - m);
+    const int hi = std::min(g.n[a] - 1, mg.core[3 + a] + m);
+    n[a] = hi - lo[a] + 1;
+    nn *= n[a];
+  }
+  if (nn >= g.nn) return BoxDev{0, 0, 0, 0, 0, 0, 0};
+  return BoxDev{lo[0], lo[1], lo[2], n[0], n[1], n[2], nn};
+}
+
 // One operator pass on a Cartesian level.  Kernel by size: a wave per node up to 6 k nodes, 4 lanes per node for medium
 // grids (<= 60 k nodes with 27-point stencils -- 26^3: -2.4 % per solve against a thread per node, 8 / 16 lanes the same,
 // on 51^3 a thread per node is faster -- and every larger grid with 125-point stencils: 1 M-point Delaunay mesh 133.5 ->
 // 126.7 ms per solve), a thread per node otherwise.  `osc`: see k_mg_cart (levels with MgLevel::half only).
 template <int D, int BS>
 void mg_apply_cart(glims_ctx* h, MgHierarchy& mg, MgLevel& L, int R, int mode, const double* xin, const double* r, double* d,
-                   double* xout, double c1, double c2, const int* done = nullptr, const double* osc = nullptr) {
+                   double* xout, double c1, double c2, const int* done = nullptr, const double* osc = nullptr,
+                   const BoxDev box = BoxDev{0, 0, 0, 0, 0, 0, 0}) {
   const GridDev g = gdev(L.g);
   const int S = mg.S;
+  const long long cnt = box.nn ? box.nn : g.nn;   // threads' nodes: the work box of a partitioned run, or the grid
   GL_REQUIRE(!(L.half && mode == 2), "internal: the single-precision planes of this level are gone");   // (power iteration: before)
   const bool half = L.half;
   const _Float16* A16 = (const _Float16*)L.A16.p;
   if (g.nn <= 6000) {
-    GL_REQUIRE(!half, "internal: half-precision operator on a small grid");
+    GL_REQUIRE(!half && box.nn == 0, "internal: half-precision operator / work box on a small grid");
     const unsigned gw = gridn(g.nn, 4);
     if (mode == 0)
       hipLaunchKernelGGL((k_mg_cart_w<D, BS, 0>), dim3(gw), dim3(256), 0, h->st, g, R, S, L.A.p, L.dinv.p, xin, r, d, xout, c1, c2, done);
@@ -1180,21 +1264,21 @@ void mg_apply_cart(glims_ctx* h, MgHierarchy& mg, MgLevel& L, int R, int mode, c
     return;
   }
   const bool lanes = g.nn <= 60000 || R >= 2;
-  const unsigned grid = lanes ? gridn(g.nn, 4 * (GL_WAVE / 4)) : gridn(g.nn);
+  const unsigned grid = lanes ? gridn(cnt, 4 * (GL_WAVE / 4)) : gridn(cnt);
 #define GL_CART(MODE)                                                                                                 \
   do {                                                                                                               \
     if (lanes && half)                                                                                               \
       hipLaunchKernelGGL((k_mg_cart_g<D, BS, MODE, 4, _Float16>), dim3(grid), dim3(256), 0, h->st, g, R, S, A16, L.dinv.p, \
-                         xin, r, d, xout, c1, c2, done, osc);                                                        \
+                         xin, r, d, xout, c1, c2, done, osc, box);                                                   \
     else if (lanes)                                                                                                  \
       hipLaunchKernelGGL((k_mg_cart_g<D, BS, MODE, 4, float>), dim3(grid), dim3(256), 0, h->st, g, R, S, L.A.p, L.dinv.p, \
-                         xin, r, d, xout, c1, c2, done, osc);                                                        \
+                         xin, r, d, xout, c1, c2, done, osc, box);                                                   \
     else if (half)                                                                                                   \
       hipLaunchKernelGGL((k_mg_cart<D, BS, MODE, _Float16>), dim3(grid), dim3(256), 0, h->st, g, R, A16, L.dinv.p, xin, r, \
-                         d, xout, c1, c2, done, osc);                                                                \
+                         d, xout, c1, c2, done, osc, box);                                                           \
     else                                                                                                             \
       hipLaunchKernelGGL((k_mg_cart<D, BS, MODE, float>), dim3(grid), dim3(256), 0, h->st, g, R, L.A.p, L.dinv.p, xin, r,  \
-                         d, xout, c1, c2, done, osc);                                                                \
+                         d, xout, c1, c2, done, osc, box);                                                           \
   } while (0)
   if (mode == 0) GL_CART(0); else if (mode == 1) GL_CART(1); else GL_CART(2);
 #undef GL_CART
@@ -1376,6 +1460,35 @@ void mg_setup_t(glims_ctx* h, MgHierarchy& mg) {
       break;
     }
     for (int a = 0; a < D; ++a) H[a] *= 1.5;
+  }
+  // partitioned run: this rank's core on the first grid (bounding box of the grid nodes its OWN mesh nodes interpolate from)
+  // and everybody's, for the box-limited cycle (mg_cycle_cart)
+  mg.boxed = false;
+  std::vector<int> all_cores;
+  if (framed) {
+    const int big = 1 << 30;
+    std::vector<int> bb = {big, big, big, -big, -big, -big};
+    dvec<int> dbb;
+    dbb.upload(bb, h->st);
+    if (n > 0) hipLaunchKernelGGL(k_mg_cell_bbox<D>, dim3(gridn(n)), dim3(256), 0, h->st, n, gdev(g1), mg.cell0.p, dbb.p);
+    GL_HIP(hipGetLastError());
+    GL_HIP(hipMemcpyAsync(bb.data(), dbb.p, 6 * sizeof(int), hipMemcpyDeviceToHost, h->st));
+    GL_HIP(hipStreamSynchronize(h->st));
+    for (int a = 0; a < 3; ++a) {
+      const bool any = a < D && n > 0 && bb[a] <= bb[3 + a];
+      mg.core[a] = any ? bb[a] : 0;
+      mg.core[3 + a] = any ? std::min(g1.n[a] - 1, bb[3 + a] + 1) : (a < D && n > 0 ? -1 : 0);   // cell c touches nodes c, c + 1
+    }
+    std::vector<double> all((size_t)h->world * 6, 0.0);
+    for (int q = 0; q < 6; ++q) all[(size_t)h->rank * 6 + q] = (double)mg.core[q];
+    dvec<double> dall;
+    dall.upload(all, h->st);
+    gl_allreduce_bulk(h, dall.p, all.size());
+    GL_HIP(hipMemcpyAsync(all.data(), dall.p, all.size() * sizeof(double), hipMemcpyDeviceToHost, h->st));
+    GL_HIP(hipStreamSynchronize(h->st));
+    all_cores.resize(all.size());
+    for (size_t q = 0; q < all.size(); ++q) all_cores[q] = (int)std::lround(all[q]);
+    mg.cores.upload(all_cores, h->st);
   }
   lap("grid choice, node -> cell map, reach");
   mg.S = 1;
@@ -1668,6 +1781,33 @@ void mg_setup_t(glims_ctx* h, MgHierarchy& mg) {
   lap("coarsest level: dense inverse");
   mg.ready = true;
   mg.n_levels = (int)mg.lv.size() + 1;
+  // box-limited first grid (partitioned runs): only where the thread-per-node / lanes-per-node kernels run and a coarser
+  // level exists; a decision from replicated numbers, the same on every rank (the cycle then holds one more all-reduce)
+  // Worth it when the largest work box (at the set-up's smoother degree) is at most 80 % of a first grid of 200 k nodes or
+  // more: the masked restriction adds one small all-reduce per cycle (tens of microseconds over RCCL), a pass over a 200 k-
+  // node grid of 27-point 3 x 3 stencils takes about as long.  GLIMS_MG_BOX_MIN_NODES (test hook) lowers the size threshold.
+  mg.boxed = false;
+  mg.box_fraction = 1.0;
+  if (framed && h->world > 1 && mg.lv.size() >= 2 && (h->opt.flags & GLIMS_FLAG_MG_WHOLE_GRID) == 0) {
+    const char* e = getenv("GLIMS_MG_BOX_MIN_NODES");
+    const long long min_nodes = std::max(6001ll, e ? atoll(e) : 200000ll);
+    const int deg0 = BS == 1 ? (h->opt.rd_mg_smooth > 0 ? h->opt.rd_mg_smooth : (lattice ? 1 : 3)) : std::max(1, h->opt.mg_smooth);
+    const MgGrid& g = mg.lv[0]->g;
+    double worst = 0.0;
+    MgHierarchy probe;   // (only core / R are read)
+    probe.R = mg.R;
+    for (int q = 0; q < h->world; ++q) {
+      for (int a = 0; a < 6; ++a) probe.core[a] = all_cores[(size_t)q * 6 + a];
+      const BoxDev b = mg_work_box<D>(probe, g, deg0);
+      const double f = b.nn ? (double)b.nn / (double)g.nn : 1.0;
+      worst = std::max(worst, f);
+      if (q == h->rank) mg.box_fraction = f;
+    }
+    mg.boxed = g.nn >= min_nodes && worst <= 0.8;
+    if (!mg.boxed) mg.box_fraction = 1.0;
+    // per-rank operator entries: the box's share of the first grid
+    mg.entries -= (int64_t)((1.0 - mg.box_fraction) * (double)mg.S * B2 * (double)g.nn);
+  }
   mg.complexity = 1.0 + (double)mg.entries / ((double)p.total_entries * B2);
   mg.ms_setup = 1e3 * (omp_get_wtime() - t_start);
   if (getenv("GLIMS_VERBOSE")) {
@@ -1708,32 +1848,41 @@ void mg_cycle_cart(glims_ctx* h, MgHierarchy& mg, int deg, size_t l, const int* 
   const double* sc = L.half ? L.sc.p : nullptr;   // this level works in scaled variables between first_cart and its last pass
   // (first_done on a level with scaled variables: only the mesh -> grid restriction does that, and it applies the scaling)
   GL_REQUIRE(!(first_done && L.half && l > 0), "internal: fused first step on a level with scaled variables");
+  // Replicated first grid of a partitioned run: this rank computes only its work box (mg_work_box) -- what it hands down
+  // (the residual on its core, restricted under the owner mask and summed over the ranks) and up (the correction on its
+  // core, interpolated to its own mesh nodes) is what the whole-grid sweep would have produced there.
+  const bool boxed = l == 0 && mg.boxed;
+  const BoxDev box = boxed ? mg_work_box<D>(mg, L.g, deg) : BoxDev{0, 0, 0, 0, 0, 0, 0};
+  const long long cnt = box.nn ? box.nn : g.nn;
   if (!first_done)
-    hipLaunchKernelGGL((k_mg_first_cart<D, BS>), dim3(gridn(g.nn)), dim3(256), 0, h->st, g, L.dinv.p, L.r.p, L.d.p, L.x.p, c2, sc, done);
+    hipLaunchKernelGGL((k_mg_first_cart<D, BS>), dim3(gridn(cnt)), dim3(256), 0, h->st, g, L.dinv.p, L.r.p, L.d.p, L.x.p, c2, sc,
+                       done, box);
   double *xa = L.x.p, *xb = L.x2.p;
   for (int m = 1; m < deg; ++m) {
     ch.next(m, &c1, &c2);
-    mg_apply_cart<D, BS>(h, mg, L, mg.R, 1, xa, L.r.p, L.d.p, xb, c1, c2, done);
+    mg_apply_cart<D, BS>(h, mg, L, mg.R, 1, xa, L.r.p, L.d.p, xb, c1, c2, done, nullptr, box);
     std::swap(xa, xb);
   }
-  mg_apply_cart<D, BS>(h, mg, L, mg.R, 0, xa, L.r.p, nullptr, L.res.p, 0.0, 0.0, done, sc);
+  mg_apply_cart<D, BS>(h, mg, L, mg.R, 0, xa, L.r.p, nullptr, L.res.p, 0.0, 0.0, done, sc, box);
   MgLevel& C = *mg.lv[l + 1];
   const Fac fc{{L.f[0], L.f[1], L.f[2]}, {L.o[0], L.o[1], L.o[2]}, {C.o[0], C.o[1], C.o[2]}};
-  const bool reduce_c = C.global && !L.global && h->world > 1;
+  const bool reduce_c = boxed || (C.global && !L.global && h->world > 1);
   const double c2c = mg_fused_first_c2(mg, l + 1, reduce_c);
   hipLaunchKernelGGL((k_mg_restrict<D, BS>), dim3(gridn(C.g.nn, 4)), dim3(256), 0, h->st, g, gdev(C.g), fc, L.res.p, C.r.p,
-                     c2c != 0.0 ? C.dinv.p : nullptr, C.d.p, C.x.p, c2c, done);
+                     c2c != 0.0 ? C.dinv.p : nullptr, C.d.p, C.x.p, c2c, done, boxed ? mg.cores.p : nullptr, h->world,
+                     h->rank);
   GL_HIP(hipGetLastError());
   // first replicated level of a partitioned run: every rank has restricted the residual of its own rows -> sum
+  // (box-limited first grid: of the fine nodes it owns)
   if (reduce_c) gl_allreduce_bulk(h, C.r.p, (size_t)BS * C.g.nn);
   mg_cycle_cart<D, BS>(h, mg, deg, l + 1, done, c2c != 0.0);
-  hipLaunchKernelGGL((k_mg_prolong<D, BS>), dim3(gridn(g.nn)), dim3(256), 0, h->st, g, gdev(C.g), fc, C.x.p, xa, xb, sc, done);
+  hipLaunchKernelGGL((k_mg_prolong<D, BS>), dim3(gridn(cnt)), dim3(256), 0, h->st, g, gdev(C.g), fc, C.x.p, xa, xb, sc, done, box);
   GL_HIP(hipGetLastError());
   std::swap(xa, xb);
   Cheb cp(L.lam, mg.cheb_ratio);
   for (int m = 0; m < deg; ++m) {
     cp.next(m, &c1, &c2);
-    mg_apply_cart<D, BS>(h, mg, L, mg.R, 1, xa, L.r.p, L.d.p, xb, c1, c2, done, m == deg - 1 ? sc : nullptr);
+    mg_apply_cart<D, BS>(h, mg, L, mg.R, 1, xa, L.r.p, L.d.p, xb, c1, c2, done, m == deg - 1 ? sc : nullptr, box);
     std::swap(xa, xb);
   }
   if (xa != L.x.p) std::swap(L.x.p, L.x2.p);   // the result is always handed up in L.x

@@ -29,6 +29,9 @@
  *   GLIMS_WIN_LIMIT      TEST HOOK: at most this many (<= 32) column windows per 64-row slice before a slice falls back
  *                        to 4-byte column indices -- lets tests/ exercise the mixed 16-bit / 32-bit index path on
  *                        meshes whose slices would all be compressible
+ *   GLIMS_MG_BOX_MIN_NODES  TEST HOOK: smallest replicated first grid (nodes, default 200 000, at least 6 001) on which a
+ *                        partitioned run limits each rank's smoothing to its work box (see GLIMS_FLAG_MG_WHOLE_GRID) --
+ *                        lets tests/ exercise that path on small meshes
  */
 #ifndef GLIMS_HIP_H
 #define GLIMS_HIP_H
@@ -134,6 +137,9 @@ typedef struct glims_options {
 #define GLIMS_FLAG_MG_FP64_VECTORS 32    /* OFF by default.  The level-0 cycle vectors of the elasticity multigrid (iterate,
                                            direction, scaled residual) are kept in double instead of single precision; the
                                            preconditioned residual handed to the Krylov solver is double either way */
+#define GLIMS_FLAG_MG_WHOLE_GRID 64      /* OFF by default.  Partitioned runs with glims_set_mg_frame: every rank smooths the
+                                           WHOLE replicated first grid instead of its work box (its part plus the smoothers'
+                                           dependency margin) -- the same preconditioner up to rounding, more work per rank */
 #define GLIMS_FLAG_INT32_COLUMNS 16       /* OFF by default.  Stream the 4-byte column indices everywhere instead of the 16-bit
                                            (window, offset) codes (same bits in every result; takes effect at glims_setup) */
 #define GLIMS_FLAG_WARM_START 2         /* first linear solve of a step starts from the previous step's increment
