@@ -509,7 +509,11 @@ void gl_make_kel32(glims_ctx* h);
 // level-0 operator pass of the multigrid (kernels.hip): mode 0 out = r - A x, 1 Chebyshev step, 2 out = Dinv A x
 void gl_launch_mg_fine(glims_ctx* h, MgHierarchy& mg, int mode, const double* xin, const double* r, double* d,
                        double* xout, double c1, double c2, const int* done = nullptr, double* uout = nullptr,
-                       const double* r_full = nullptr, double* pv = nullptr);
+                       const double* r_full = nullptr, double* pv = nullptr, int part = 0);
+int gl_mg_fine_blocks(glims_ctx* h, bool split);
+bool gl_mg_split_level0(const glims_ctx* h, const MgHierarchy& mg);   // level-0 passes in two launches around the halo exchange
+void gl_halo_start(glims_ctx* h, double* vec, int bs);
+void gl_halo_finish(glims_ctx* h);
 // symbolic.hip: device sort helpers (rocPRIM)
 void gl_sort_pairs_u32(glims_ctx* h, uint32_t* k_in, uint32_t* k_out, int32_t* v_in, int32_t* v_out, size_t n, int end_bit);
 void gl_offsets_of_sorted_keys(glims_ctx* h, const uint32_t* keys_sorted, int64_t n, int64_t n_keys, int32_t* ptr);

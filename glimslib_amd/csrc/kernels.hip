@@ -654,7 +654,8 @@ __global__ __launch_bounds__(256) void k_spmv_block2(int n_launch, int chunk, co
 // x = 0 there (the iterates are zero on constrained dofs by construction).  xout must not alias xin.
 //   MODE 0: xout = r - A xin          MODE 1: d = c1 d + c2 Dinv (r - A xin), xout = xin + d          MODE 2: xout = Dinv A xin
 template <int BS, int MODE, int KB, class VT, int CIDX, class XT>
-__global__ __launch_bounds__(256) void k_mg_fine(int n_launch, int chunk, int64_t n_own,
+__global__ __launch_bounds__(256) void k_mg_fine(int n_launch, const int32_t* __restrict__ slist, int pv_block0, int chunk,
+                                                  int64_t n_own,
                                                   const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ cols,
                                                   const uint16_t* __restrict__ cols16,
                                                   const int32_t* __restrict__ win_base,
@@ -672,7 +673,8 @@ __global__ __launch_bounds__(256) void k_mg_fine(int n_launch, int chunk, int64_
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int s_end = min(n_launch, (b + 1) * chunk);
   double pg = 0.0, pr = 0.0;   // last pass of a cycle inside the Krylov solver: partials of (r, u) and (r, r)
-  for (int s = b * chunk + wid; s < s_end; s += 4) {
+  for (int q = b * chunk + wid; q < s_end; q += 4) {
+    const int s = slist ? slist[q] : q;   // (partitioned runs: the interior slices while the halo travels, then the rest)
     const int64_t row = (int64_t)s * GL_WAVE + lane;
     const int64_t base = slice_ptr[s];
     const int len = (int)((slice_ptr[s + 1] - base) >> 6);
@@ -774,7 +776,7 @@ __global__ __launch_bounds__(256) void k_mg_fine(int n_launch, int chunk, int64_
     }
     __syncthreads();
     if (threadIdx.x < 2)
-      pv[(size_t)b * 2 + threadIdx.x] = (smp[0][threadIdx.x] + smp[1][threadIdx.x]) + (smp[2][threadIdx.x] + smp[3][threadIdx.x]);
+      pv[(size_t)(pv_block0 + b) * 2 + threadIdx.x] = (smp[0][threadIdx.x] + smp[1][threadIdx.x]) + (smp[2][threadIdx.x] + smp[3][threadIdx.x]);
   }
 }
 
@@ -1114,20 +1116,33 @@ void gl_apply_G(glims_ctx* h, const double* c, double* y) {
   GL_HIP(hipGetLastError());
 }
 
+// (r, u) / (r, r) pairs the last level-0 pass of a cycle leaves for the Krylov solver: one per block of its launch(es)
+int gl_mg_fine_blocks(glims_ctx* h, bool split) {
+  const DevPattern& p = h->pat;
+  if (!split) return gl_spmv_grid(p.n_slices);
+  return (p.n_interior > 0 ? gl_spmv_grid(p.n_interior) : 0) + (p.n_boundary > 0 ? gl_spmv_grid(p.n_boundary) : 0);
+}
+
+// part: 0 = every slice; 1 = the interior slices (no ghost column: may run while the halo exchange of xin is in flight);
+// 2 = the boundary slices
 void gl_launch_mg_fine(glims_ctx* h, MgHierarchy& mg, int mode, const double* xin, const double* r, double* d,
                        double* xout, double c1, double c2, const int* done, double* uout, const double* r_full,
-                       double* pv) {
+                       double* pv, int part) {
   const DevPattern& p = h->pat;
-  const int grid = gl_spmv_grid(p.n_slices);
-  const int chunk = (p.n_slices + grid - 1) / grid;
+  const int n_launch = part == 0 ? p.n_slices : part == 1 ? p.n_interior : p.n_boundary;
+  if (n_launch <= 0) return;
+  const int32_t* slist = part == 0 ? nullptr : part == 1 ? p.interior_slices.p : p.boundary_slices.p;
+  const int pv0 = part == 2 && p.n_interior > 0 ? gl_spmv_grid(p.n_interior) : 0;
+  const int grid = gl_spmv_grid(n_launch);
+  const int chunk = (n_launch + grid - 1) / grid;
   const uint8_t* fx = mg.op_fixed;
   const bool half = mg.half_smoother;
   const bool c16 = h->use_idx16 && h->stats.nnz_idx16 == h->stats.nnz_padded;   // every slice has 16-bit codes
   const bool x32 = mg.x32 && mode != 2;   // the power iteration of the set-up (mode 2) works on double vectors
   // entries in flight per lane: 2 blocks of 3 x 3 (2 x 2), or 8 scalars (an interior row of a tetrahedral mesh has 15)
 #define GL_MGF4(BS, KB, MODE, VT, VPTR, CIDX, XT)                                                                    \
-  hipLaunchKernelGGL((k_mg_fine<BS, MODE, KB, VT, CIDX, XT>), dim3(grid), dim3(256), 0, h->st, p.n_slices, chunk,     \
-                     h->n_own, p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, VPTR, mg.dinv0.p, mg.sc.p,         \
+  hipLaunchKernelGGL((k_mg_fine<BS, MODE, KB, VT, CIDX, XT>), dim3(grid), dim3(256), 0, h->st, n_launch, slist, pv0,  \
+                     chunk, h->n_own, p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, VPTR, mg.dinv0.p, mg.sc.p,         \
                      fx, (const XT*)xin, (const XT*)r, (XT*)d, (XT*)xout, uout, c1, c2, GL_XCD_CHUNK, done, r_full, pv)
 #define GL_MGF3(BS, KB, MODE, VT, VPTR, CIDX)                                                                        \
   do {                                                                                                               \
@@ -1147,7 +1162,7 @@ void gl_launch_mg_fine(glims_ctx* h, MgHierarchy& mg, int mode, const double* xi
   do {                                                                                                               \
     if (mode == 0) GL_MGF(BS, KB, 0); else if (mode == 1) GL_MGF(BS, KB, 1); else GL_MGF(BS, KB, 2);                 \
   } while (0)
-  const bool timed = &mg == &h->mg && mode != 2 && h->timing(glims_ctx::TK_MGFINE);
+  const bool timed = &mg == &h->mg && mode != 2 && part == 0 && h->timing(glims_ctx::TK_MGFINE);
   if (timed) h->tick(glims_ctx::TK_MGFINE);
   if (mg.bs == 1) GL_MGFM(1, 8);
   else if (mg.bs == 2) GL_MGFM(2, 2);

@@ -1817,6 +1817,10 @@ void mg_setup_t(glims_ctx* h, MgHierarchy& mg) {
     for (MgLevel* L : mg.lv)
       fprintf(stderr, " %dx%dx%d%s(lam %.2f)", L->g.n[0], L->g.n[1], L->g.n[2], L->global ? "[replicated]" : "", L->lam);
     fprintf(stderr, "; operator complexity %.2f; set-up %.1f ms\n", mg.complexity, mg.ms_setup);
+    if (framed)
+      fprintf(stderr, "glims multigrid, rank %d: level-0 passes %s (%d interior / %d boundary slices); first grid %s (work box %.0f %% of it)\n",
+              h->rank, gl_mg_split_level0(h, mg) ? "split around the halo exchange" : "after the halo exchange",
+              (int)p.n_interior, (int)p.n_boundary, mg.boxed ? "box-limited" : "whole on every rank", 100.0 * mg.box_fraction);
   }
 }
 
@@ -1888,6 +1892,12 @@ void mg_cycle_cart(glims_ctx* h, MgHierarchy& mg, int deg, size_t l, const int* 
   if (xa != L.x.p) std::swap(L.x.p, L.x2.p);   // the result is always handed up in L.x
 }
 
+}  // namespace
+bool gl_mg_split_level0(const glims_ctx* h, const MgHierarchy& mg) {
+  return mg.exact_level0 && h->world > 1 && h->n_peers > 0 && h->pat.n_interior > 0 && h->pat.n_boundary > 0;
+}
+namespace {
+
 template <int D, int BS>
 void mg_apply_t(glims_ctx* h, MgHierarchy& mg, int deg, const double* r, double* u, const int* done, double* pv) {
   const int64_t n = h->n_own;
@@ -1907,14 +1917,26 @@ void mg_apply_t(glims_ctx* h, MgHierarchy& mg, int deg, const double* r, double*
   r = mg.rs.p;   // from here on the level-0 passes work in the scaled variables
   double *xa = mg.x.p, *xb = mg.x2.p;
   const bool ex = mg.exact_level0;   // the passes read ghost columns: bring them in (iterates are owned-row vectors)
+  // ... and hide the exchange behind the slices that reference no ghost column, as the Krylov operator does
+  const bool split = gl_mg_split_level0(h, mg);
+  auto fine = [&](int mode, double* xin, double* dd, double* xout, double a1, double a2, double* uo, const double* rf,
+                  double* pvv) {
+    if (split) {
+      gl_halo_start(h, xin, xrec);
+      gl_launch_mg_fine(h, mg, mode, xin, r, dd, xout, a1, a2, done, uo, rf, pvv, 1);
+      gl_halo_finish(h);
+      gl_launch_mg_fine(h, mg, mode, xin, r, dd, xout, a1, a2, done, uo, rf, pvv, 2);
+    } else {
+      if (ex) gl_halo_exchange(h, xin, xrec);
+      gl_launch_mg_fine(h, mg, mode, xin, r, dd, xout, a1, a2, done, uo, rf, pvv);
+    }
+  };
   for (int m = 1; m < deg; ++m) {
     ch.next(m, &c1, &c2);
-    if (ex) gl_halo_exchange(h, xa, xrec);
-    gl_launch_mg_fine(h, mg, 1, xa, r, mg.d.p, xb, c1, c2, done);
+    fine(1, xa, mg.d.p, xb, c1, c2, nullptr, nullptr, nullptr);
     std::swap(xa, xb);
   }
-  if (ex) gl_halo_exchange(h, xa, xrec);
-  gl_launch_mg_fine(h, mg, 0, xa, r, nullptr, mg.res.p, 0.0, 0.0, done);
+  fine(0, xa, nullptr, mg.res.p, 0.0, 0.0, nullptr, nullptr, nullptr);
   MgLevel& L1 = *mg.lv[0];
   const GridDev g1 = gdev(L1.g);
   // restriction through the explicit operator (a thread per grid node); the grid level's first smoothing step rides along
@@ -1948,10 +1970,8 @@ void mg_apply_t(glims_ctx* h, MgHierarchy& mg, int deg, const double* r, double*
     cp.next(m, &c1, &c2);
     // the last step leaves the scaled variables and writes the preconditioned residual where the solver wants it -- and,
     // for the Krylov solver, the partial sums of (r, u) and (r, r) over its blocks (pv)
-    if (ex) gl_halo_exchange(h, xa, xrec);
     const bool last = m == deg - 1;
-    gl_launch_mg_fine(h, mg, 1, xa, r, mg.d.p, xb, c1, c2, done, last ? u : nullptr, last ? r_full : nullptr,
-                      last ? pv : nullptr);
+    fine(1, xa, mg.d.p, xb, c1, c2, last ? u : nullptr, last ? r_full : nullptr, last ? pv : nullptr);
     std::swap(xa, xb);
   }
 }

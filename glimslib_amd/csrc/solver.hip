@@ -660,6 +660,8 @@ void gl_halo_exchange(glims_ctx* h, double* vec, int bs) {
   halo_start(h, vec, bs);
   halo_finish(h);
 }
+void gl_halo_start(glims_ctx* h, double* vec, int bs) { halo_start(h, vec, bs); }
+void gl_halo_finish(glims_ctx* h) { halo_finish(h); }
 // Sum over ranks of the values reduce_partials / k_reduce_cg just left in `dev` (= h->red).  With the node mailbox
 // the final reduction block has already done it.
 static void allreduce_sum(glims_ctx* h, double* dev, int n) {
@@ -986,7 +988,7 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
   const int ext = v.mg ? 1 : 0;
   if (ext) pm = PackMap();   // the cycle's last kernel produces u: the halo payload is packed by k_pack
   // external preconditioner: the cycle's last kernel writes u and the (r.u, r.r) partial pairs of ITS blocks
-  const int nvp = ext ? gl_spmv_grid(p.n_slices) : (int)g;
+  const int nvp = ext ? gl_mg_fine_blocks(h, gl_mg_split_level0(h, *v.mg)) : (int)g;
   auto precondition = [&]() {
     if (!ext) return;
     gl_mg_apply(h, *v.mg, v.mg_degree, v.r, v.u, h->done.p, h->partials_v.p);
