@@ -239,16 +239,21 @@ def main():
     from glimslib_amd.partition import partition_mesh
 
     t0 = time.perf_counter()
-    w = workloads.by_name(args.workload, args.n or None)
-    n_global = w.mesh.num_vertices()
+    # N > 1 on the box configs: every rank builds only its own share of the mesh (same partition, array by array, as
+    # cutting the whole mesh: tests/test_partition_box.py)
+    lw = workloads.local_by_name(args.workload, args.n or None, world, rank) if world > 1 else None
+    w = lw if lw is not None else workloads.by_name(args.workload, args.n or None)
+    n_global = lw.n_nodes if lw is not None else w.mesh.num_vertices()
     if rank == 0:
-        log("[bench] workload %s: %d nodes, %d cells (mesh built in %.1f s)" %
-            (w.name, n_global, w.mesh.num_cells(), time.perf_counter() - t0))
+        log("[bench] workload %s: %d nodes, %d cells (%s in %.1f s)" %
+            (w.name, n_global, lw.n_cells if lw is not None else w.mesh.num_cells(),
+             "this rank's share built" if lw is not None else "mesh built", time.perf_counter() - t0))
 
     t0 = time.perf_counter()
     if world > 1:
-        part = partition_mesh(w.mesh.points, w.mesh.cells, world, rank)
-        h = Handle(part.points, part.cells, w.cell_label[part.cell_ids], n_own=part.n_own, device=local_rank)
+        part = lw.part if lw is not None else partition_mesh(w.mesh.points, w.mesh.cells, world, rank)
+        labels = lw.cell_label if lw is not None else w.cell_label[part.cell_ids]
+        h = Handle(part.points, part.cells, labels, n_own=part.n_own, device=local_rank)
         from glimslib_amd.parallel import broadcast_unique_id, HostStagedTransport
         if forced is not None:      # rehearsal: RCCL refuses several ranks per device, stage the halos through gloo
             transport = HostStagedTransport(dist)
@@ -256,12 +261,15 @@ def main():
         else:
             h.comm_init(rank, world, broadcast_unique_id(dist, rank))
         h.set_halo(part.peer_rank, part.send_ptr, part.send_idx, part.recv_count)
-        h.set_mg_frame(w.mesh.points.min(axis=0), w.mesh.points.max(axis=0))
+        if lw is not None:
+            h.set_mg_frame(lw.frame[0], lw.frame[1])
+        else:
+            h.set_mg_frame(w.mesh.points.min(axis=0), w.mesh.points.max(axis=0))
         from glimslib_amd.parallel import setup_node_mailbox
         mailbox = setup_node_mailbox(h, dist, rank)
         if rank == 0:
             log("[bench] scalar all-reduce: %s" % ("node mailbox (shared host memory)" if mailbox else "RCCL"))
-        c0 = w.c0[part.global_ids]
+        c0 = lw.c0 if lw is not None else w.c0[part.global_ids]
     else:
         part = None
         h = Handle(w.mesh.points, w.mesh.cells, w.cell_label, device=local_rank)
@@ -285,8 +293,11 @@ def main():
     # coupled configs (C5): the displacement is solved after EVERY step, as the reference's monolithic solve does; the
     # unknown count is then (d + 1) per node.  (The simulation classes solve it lazily)
     coupled = bool(w.mechanics)
-    dim = w.mesh.points.shape[1] if w.mesh is not None else 3
-    if coupled and w.dirichlet_nodes is not None:
+    dim = 3 if lw is not None else w.mesh.points.shape[1]
+    if coupled and lw is not None:
+        dofs = (lw.dirichlet_local[:, None] * dim + np.arange(dim)).ravel()
+        h.set_dirichlet_u(dofs, np.zeros(len(dofs)))
+    elif coupled and w.dirichlet_nodes is not None:
         if part is None:
             nodes = np.asarray(w.dirichlet_nodes, dtype=np.int64)
         else:

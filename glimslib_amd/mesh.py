@@ -144,8 +144,11 @@ def UnitSquareMesh(nx, ny):
     return RectangleMesh((0.0, 0.0), (1.0, 1.0), nx, ny)
 
 
-def BoxMesh(p0, p1, nx, ny, nz):
-    """DOLFIN ``BoxMesh``: 6 tetrahedra per hexahedron, all sharing the v0-v7 diagonal."""
+BOX_TETS = [(0, 1, 3, 7), (0, 1, 7, 5), (0, 5, 7, 4), (0, 3, 2, 7), (0, 6, 4, 7), (0, 2, 6, 7)]
+
+
+def box_points(p0, p1, nx, ny, nz):
+    """Vertices of DOLFIN's ``BoxMesh``: vertex (ix, iy, iz) -> (iz*(ny+1) + iy)*(nx+1) + ix."""
     p0, p1 = _as_xy(p0), _as_xy(p1)
     xs = np.linspace(p0[0], p1[0], nx + 1)
     ys = np.linspace(p0[1], p1[1], ny + 1)
@@ -155,19 +158,34 @@ def BoxMesh(p0, p1, nx, ny, nz):
     pts[:, 0] = np.tile(xs, (ny + 1) * (nz + 1))
     pts[:, 1] = np.tile(np.repeat(ys, nx + 1), nz + 1)
     pts[:, 2] = np.repeat(zs, (nx + 1) * (ny + 1))
+    return pts
+
+
+def box_cells(nx, ny, nz, xr=None, yr=None, zr=None):
+    """Cells of ``BoxMesh`` for the hexahedra ix in xr = (lo, hi), iy in yr, iz in zr (half-open; default: all), in the
+    order of the whole mesh (hexahedron (iz*ny + iy)*nx + ix, six tetrahedra each).  Returns (cells [m, 4] of GLOBAL vertex
+    ids, first_cell_id [m / 6] = 6 * hexahedron index of each hexahedron visited)."""
+    xr = (0, nx) if xr is None else xr
+    yr = (0, ny) if yr is None else yr
+    zr = (0, nz) if zr is None else zr
     sx, sy = 1, nx + 1
     sz = (nx + 1) * (ny + 1)
-    iz, iy, ix = np.meshgrid(np.arange(nz, dtype=np.int32), np.arange(ny, dtype=np.int32),
-                             np.arange(nx, dtype=np.int32), indexing='ij')
+    iz, iy, ix = np.meshgrid(np.arange(zr[0], zr[1], dtype=np.int64), np.arange(yr[0], yr[1], dtype=np.int64),
+                             np.arange(xr[0], xr[1], dtype=np.int64), indexing='ij')
     v0 = (iz * sz + iy * sy + ix).ravel().astype(np.int32)
+    hexa = ((iz * ny + iy) * nx + ix).ravel()
     del ix, iy, iz
     off = {0: 0, 1: sx, 2: sy, 3: sx + sy, 4: sz, 5: sx + sz, 6: sy + sz, 7: sx + sy + sz}
-    tets = [(0, 1, 3, 7), (0, 1, 7, 5), (0, 5, 7, 4), (0, 3, 2, 7), (0, 6, 4, 7), (0, 2, 6, 7)]
     cells = np.empty((len(v0), 6, 4), dtype=np.int32)
-    for t, tet in enumerate(tets):
+    for t, tet in enumerate(BOX_TETS):
         for m, corner in enumerate(tet):
             cells[:, t, m] = v0 + np.int32(off[corner])
-    return Mesh(pts, cells.reshape(-1, 4))
+    return cells.reshape(-1, 4), 6 * hexa
+
+
+def BoxMesh(p0, p1, nx, ny, nz):
+    """DOLFIN ``BoxMesh``: 6 tetrahedra per hexahedron, all sharing the v0-v7 diagonal."""
+    return Mesh(box_points(p0, p1, nx, ny, nz), box_cells(nx, ny, nz)[0])
 
 
 def UnitCubeMesh(nx, ny, nz):

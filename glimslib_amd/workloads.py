@@ -82,6 +82,63 @@ def _brain_box(n, mechanics, n_steps, name):
                     _exterior_nodes(mesh) if mechanics else None)
 
 
+class LocalWorkload:
+    """One rank's share of a box workload, built without the whole mesh (partition.partition_box_mesh): the fields bench.py
+    needs of a Workload, restricted to the rank's local (owned | ghost) nodes and cells."""
+
+    def __init__(self, name, part, cell_label, tables, c0, dt, n_steps, mechanics, dirichlet_local, frame, n_nodes, n_cells):
+        self.name = name
+        self.part = part                      # partition.LocalPart
+        self.cell_label = cell_label          # int32 [local cells]
+        self.tables = tables
+        self.c0 = c0                          # [local nodes]
+        self.dt = dt
+        self.n_steps = n_steps
+        self.mechanics = mechanics
+        self.dirichlet_local = dirichlet_local  # OWNED local nodes with u = 0, or None
+        self.frame = frame                    # (lo, hi) of the whole mesh
+        self.n_nodes = n_nodes                # whole mesh
+        self.n_cells = n_cells
+
+
+def brain_box_local(n, mechanics, n_steps, name, n_parts, rank):
+    """_brain_box's workload as rank ``rank`` of ``n_parts`` sees it: same owner map, same local numbering, same labels and
+    seed as partitioning the whole Workload (tests/test_partition_box.py), from ~1 / n_parts of the host work."""
+    from .partition import partition_box_mesh
+    p0, p1 = (0.0, -240.0, 0.0), (240.0, 0.0, 155.0)
+    part = partition_box_mesh(p0, p1, n, n, n, n_parts, rank)
+    mid = part.points[part.cells].mean(axis=1)
+    q = ((mid[:, 0] - 120.0) / 80.0) ** 2 + ((mid[:, 1] + 120.0) / 80.0) ** 2 + ((mid[:, 2] - 77.5) / 50.0) ** 2
+    label = np.where(q < 1.0, WM, GM).astype(np.int32)
+    tables = dict(D=[0.0, 0.0, 0.01, 0.05, 0.0], rho=[0.0, 0.0, 0.05, 0.05, 0.0],
+                  gamma=[0.0, 0.1, 0.1, 0.1, 0.1], E=[1.0, 1000e-6, 3000e-6, 3000e-6, 1000e-6],
+                  nu=[0.3, 0.45, 0.45, 0.45, 0.3])
+    d2 = ((part.points - np.array([118.0, -109.0, 72.0])) ** 2).sum(axis=1)
+    c0 = np.exp(-0.5 * d2)
+    dirichlet = None
+    if mechanics:   # the exterior nodes of a box: an index 0 or n on some axis
+        g = part.global_ids[:part.n_own]
+        i, j, k = g % (n + 1), (g // (n + 1)) % (n + 1), g // ((n + 1) * (n + 1))
+        dirichlet = np.flatnonzero((i == 0) | (i == n) | (j == 0) | (j == n) | (k == 0) | (k == n))
+    return LocalWorkload(name, part, label, tables, c0, 1.0, n_steps, mechanics, dirichlet,
+                         (np.array(p0), np.array(p1)), (n + 1) ** 3, 6 * n ** 3)
+
+
+def local_by_name(name, n, n_parts, rank):
+    """LocalWorkload of the box configs (c3, c4, c5), None for workloads that have no generator-side partition."""
+    name = name.lower()
+    if name == 'c3':
+        n = n or 99
+        return brain_box_local(n, False, 50, "C3 brain-extent box n=%d, 2 tissues" % n, n_parts, rank)
+    if name == 'c4':
+        n = n or 215
+        return brain_box_local(n, False, 500, "C4 brain-extent box n=%d, 2 tissues" % n, n_parts, rank)
+    if name == 'c5':
+        n = n or 99
+        return brain_box_local(n, True, 50, "C5 coupled (c + u) brain-extent box n=%d" % n, n_parts, rank)
+    return None
+
+
 def config_c3(n=99, mechanics=False):
     return _brain_box(n, mechanics, 50, "C3 brain-extent box n=%d, 2 tissues" % n)
 
