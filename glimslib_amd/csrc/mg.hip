@@ -1783,14 +1783,16 @@ void mg_setup_t(glims_ctx* h, MgHierarchy& mg) {
   mg.n_levels = (int)mg.lv.size() + 1;
   // box-limited first grid (partitioned runs): only where the thread-per-node / lanes-per-node kernels run and a coarser
   // level exists; a decision from replicated numbers, the same on every rank (the cycle then holds one more all-reduce)
-  // Worth it when the largest work box (at the set-up's smoother degree) is at most 80 % of a first grid of 200 k nodes or
-  // more: the masked restriction adds one small all-reduce per cycle (tens of microseconds over RCCL), a pass over a 200 k-
-  // node grid of 27-point 3 x 3 stencils takes about as long.  GLIMS_MG_BOX_MIN_NODES (test hook) lowers the size threshold.
+  // Worth it when the passes saved outweigh the one small all-reduce the masked restriction adds per cycle (taken as 40 us
+  // over RCCL): saving = (1 - largest box / grid, at the set-up's smoother degree) x (2 deg + 1) passes x the first grid's
+  // half-precision operator bytes at 4 TB/s, required to be 1.5 x the cost -- e.g. a 55^3 grid of 27-point 3 x 3 stencils
+  // (config C4's size on 8 ranks with spacing 4 h) with boxes of 22 %: 110 us saved.  GLIMS_MG_BOX_MIN_NODES (test hook)
+  // replaces the estimate by a plain size threshold so that small test meshes take the path.
   mg.boxed = false;
   mg.box_fraction = 1.0;
   if (framed && h->world > 1 && mg.lv.size() >= 2 && (h->opt.flags & GLIMS_FLAG_MG_WHOLE_GRID) == 0) {
     const char* e = getenv("GLIMS_MG_BOX_MIN_NODES");
-    const long long min_nodes = std::max(6001ll, e ? atoll(e) : 200000ll);
+    const long long min_nodes = e ? std::max(6001ll, atoll(e)) : 0;
     const int deg0 = BS == 1 ? (h->opt.rd_mg_smooth > 0 ? h->opt.rd_mg_smooth : (lattice ? 1 : 3)) : std::max(1, h->opt.mg_smooth);
     const MgGrid& g = mg.lv[0]->g;
     double worst = 0.0;
@@ -1803,7 +1805,8 @@ void mg_setup_t(glims_ctx* h, MgHierarchy& mg) {
       worst = std::max(worst, f);
       if (q == h->rank) mg.box_fraction = f;
     }
-    mg.boxed = g.nn >= min_nodes && worst <= 0.8;
+    const double saved_us = (1.0 - worst) * (2.0 * deg0 + 1.0) * (double)g.nn * mg.S * B2 * 2.0 / 4.0e6;
+    mg.boxed = g.nn > 6000 && (min_nodes ? g.nn >= min_nodes && worst <= 0.8 : saved_us >= 60.0);
     if (!mg.boxed) mg.box_fraction = 1.0;
     // per-rank operator entries: the box's share of the first grid
     mg.entries -= (int64_t)((1.0 - mg.box_fraction) * (double)mg.S * B2 * (double)g.nn);

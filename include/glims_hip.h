@@ -29,9 +29,9 @@
  *   GLIMS_WIN_LIMIT      TEST HOOK: at most this many (<= 32) column windows per 64-row slice before a slice falls back
  *                        to 4-byte column indices -- lets tests/ exercise the mixed 16-bit / 32-bit index path on
  *                        meshes whose slices would all be compressible
- *   GLIMS_MG_BOX_MIN_NODES  TEST HOOK: smallest replicated first grid (nodes, default 200 000, at least 6 001) on which a
- *                        partitioned run limits each rank's smoothing to its work box (see GLIMS_FLAG_MG_WHOLE_GRID) --
- *                        lets tests/ exercise that path on small meshes
+ *   GLIMS_MG_BOX_MIN_NODES  TEST HOOK: smallest replicated first grid (nodes, at least 6 001) on which a partitioned run
+ *                        limits each rank's smoothing to its work box (see GLIMS_FLAG_MG_WHOLE_GRID), instead of the
+ *                        library's estimate of what that saves -- lets tests/ exercise the path on small meshes
  */
 #ifndef GLIMS_HIP_H
 #define GLIMS_HIP_H
