@@ -151,16 +151,31 @@ def config_c5(n=99):
     return _brain_box(n, True, 50, "C5 coupled (c + u) brain-extent box n=%d" % n)
 
 
-def config_unstructured(n_points=200000, mechanics=False, seed=0):
+def config_unstructured(n_points=200000, mechanics=False, seed=0, jitter=None):
     """
     Truly unstructured stand-in for the CGAL atlas meshes: Delaunay tetrahedralisation (scipy / Qhull) of uniformly
     random points (np.random.default_rng(seed)) in the brain-extent box, WM ellipsoid in a GM shell, same parameters
     as C3/C4.  Row lengths range from ~6 to ~45 (mean ~16), cell volumes over three orders of magnitude.
+    ``jitter`` (e.g. 0.3): instead, the nodes of a lattice of about n_points nodes, the interior ones moved by up to
+    jitter x spacing per axis -- an unstructured mesh of bounded quality, nearer to what a quality-controlled mesher emits.
     """
     from scipy.spatial import Delaunay
     from .mesh import Mesh
     rng = np.random.default_rng(seed)
-    pts = rng.random((int(n_points), 3)) * np.array([240.0, 240.0, 155.0]) + np.array([0.0, -240.0, 0.0])
+    ext, org = np.array([240.0, 240.0, 155.0]), np.array([0.0, -240.0, 0.0])
+    if jitter is None:
+        pts = rng.random((int(n_points), 3)) * ext + org
+    else:
+        hsp = (ext.prod() / float(n_points)) ** (1.0 / 3.0)
+        m = np.maximum(2, np.round(ext / hsp).astype(int))
+        ax = [np.linspace(0.0, ext[a], m[a] + 1) for a in range(3)]
+        X, Y, Z = np.meshgrid(*ax, indexing='ij')
+        pts = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+        inner = np.ones(len(pts), dtype=bool)
+        for a in range(3):
+            inner &= (pts[:, a] > 0.0) & (pts[:, a] < ext[a])
+        pts[inner] += (rng.random((int(inner.sum()), 3)) - 0.5) * 2.0 * float(jitter) * (ext / m)
+        pts += org
     cells = Delaunay(pts).simplices.astype(np.int32)
     X = pts[cells]
     vol = np.abs(np.linalg.det(X[:, 1:] - X[:, :1])) / 6.0
@@ -174,7 +189,8 @@ def config_unstructured(n_points=200000, mechanics=False, seed=0):
                   nu=[0.3, 0.45, 0.45, 0.45, 0.3])
     d2 = ((pts - np.array([118.0, -109.0, 72.0])) ** 2).sum(axis=1)
     c0 = np.exp(-0.005 * d2)
-    return Workload("unstructured Delaunay mesh, %d points" % n_points, mesh, label, tables, c0, 1.0, 50, mechanics,
+    return Workload("unstructured Delaunay mesh, %d points%s" % (len(pts), "" if jitter is None else " (lattice jittered by %.2f h)" % jitter),
+                    mesh, label, tables, c0, 1.0, 50, mechanics,
                     _exterior_nodes(mesh) if mechanics else None)
 
 

@@ -3,7 +3,7 @@
 iterations from a zero guess and ms per solve for each setting.
 
     python tools/sweep_mg_general.py [n_points=300000]
-    env: HFACS="1.6,2,2.4"  SMOOTHS="3,4"  RATIOS="0"  COARSE="216"
+    env: HFACS="1.6,2,2.4"  SMOOTHS="3,4"  RATIOS="0"  COARSE="216"  JITTER=0.3 (bounded-quality mesh: jittered lattice)
 """
 import json
 import os
@@ -19,7 +19,8 @@ from glimslib_amd import workloads, _backend  # noqa: E402
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300000
     t0 = time.perf_counter()
-    w = workloads.config_unstructured(n, mechanics=True)
+    jit = os.environ.get("JITTER")
+    w = workloads.config_unstructured(n, mechanics=True, jitter=float(jit) if jit else None)
     print("mesh: %d nodes, %d cells (%.1f s)" % (w.mesh.num_vertices(), w.mesh.num_cells(), time.perf_counter() - t0),
           flush=True)
     h = _backend.Handle(w.mesh.points, w.mesh.cells, w.cell_label)
