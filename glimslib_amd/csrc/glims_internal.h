@@ -181,6 +181,32 @@ struct MgLevel {                           // one Cartesian level
   dvec<double> x, x2, r, d, res;           // [bs][nn] (component-major)
   double lam = 1.0;                        // estimate of lambda_max(Dinv A)
 };
+// Neighbour exchange that replaces the all-reduce of the first grid's restricted residual in a box-limited partitioned
+// cycle: rank p needs the sum on its work box only, and rank q's partial sums are nonzero only on q's core, so p receives
+// (box_p n core_q) from q and sends (box_q n core_p) -- boxes every rank derives from the all-gathered cores.
+struct GridRegion {
+  int lo[3], n[3];
+  int rank;              // the peer this region comes from / goes to
+  long long off;         // first node of the region in the message buffers (nodes, not doubles)
+};
+struct GridExchange {
+  bool ready = false;
+  int deg = 0;                               // smoother degree the boxes were sized for (a larger one falls back to the all-reduce)
+  std::vector<int32_t> peers;                // ascending rank
+  std::vector<int64_t> send_ptr, recv_ptr;   // per peer, in nodes
+  int n_send_reg = 0, n_recv_reg = 0;
+  long long n_send = 0, n_recv = 0;          // nodes
+  dvec<GridRegion> send_reg, recv_reg;       // ascending peer rank
+  dvec<double> sendbuf, recvbuf;             // [node][bs]
+  void reset() {
+    ready = false;
+    peers.clear();
+    send_ptr.clear();
+    recv_ptr.clear();
+    n_send_reg = n_recv_reg = 0;
+    n_send = n_recv = 0;
+  }
+};
 struct MgHierarchy {
   bool ready = false;
   // The operator this hierarchy preconditions (set by the caller of gl_mg_setup; borrowed pointers that must stay valid
@@ -216,6 +242,7 @@ struct MgHierarchy {
   int core[6] = {0, 0, 0, 0, 0, 0};        // this rank's core on the first grid: lo[3], hi[3] (inclusive) of the nodes its own mesh nodes interpolate from
   dvec<int> cores;                         // every rank's core [world][6] (owner rule of the first-grid -> second-grid restriction)
   double box_fraction = 1.0;               // work box / first grid at the set-up's smoother degree
+  GridExchange gx;                         // first-grid residual: neighbour exchange instead of the all-reduce (boxed only)
   dvec<double> sc;                         // level-0 scaling s = 1 / sqrt(diag K_el) per dof (1 on constrained dofs)
   dvec<float> dinv0;                       // inverse diagonal blocks of the scaled operator S K S, single precision
   dvec<float> vK32s;                       // single-precision scaled copy (GLIMS_FLAG_MG_FP32_SMOOTHER only)
@@ -512,6 +539,10 @@ void gl_launch_mg_fine(glims_ctx* h, MgHierarchy& mg, int mode, const double* xi
                        const double* r_full = nullptr, double* pv = nullptr, int part = 0);
 int gl_mg_fine_blocks(glims_ctx* h, bool split);
 bool gl_mg_split_level0(const glims_ctx* h, const MgHierarchy& mg);   // level-0 passes in two launches around the halo exchange
+// generic grouped exchange with the handle's transport: per peer p, sendbuf[send_ptr[p] .. send_ptr[p+1]) * bs doubles go
+// to peers[p] and recvbuf[recv_ptr[p] .. recv_ptr[p+1]) * bs come from it (empty directions are skipped on both sides)
+void gl_exchange(glims_ctx* h, const std::vector<int32_t>& peers, const std::vector<int64_t>& send_ptr,
+                 const std::vector<int64_t>& recv_ptr, const double* sendbuf, double* recvbuf, int bs);
 void gl_halo_start(glims_ctx* h, double* vec, int bs);
 void gl_halo_finish(glims_ctx* h);
 // symbolic.hip: device sort helpers (rocPRIM)

@@ -177,6 +177,61 @@ __global__ void k_mg_cell_bbox(int64_t n_own, GridDev g1, const int32_t* __restr
   }
 }
 
+// first-grid residual of a box-limited partitioned cycle (GridExchange): message packing and the ordered sum
+// sendbuf[(reg.off + local node) * BS + a] = r[a][node] over the nodes of every send region
+template <int BS>
+__global__ void k_gx_pack(GridDev g, int n_reg, const GridRegion* __restrict__ reg, long long n_send,
+                          const double* __restrict__ r, double* __restrict__ sendbuf, const int* __restrict__ done) {
+  if (done && *done) return;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_send) return;
+  int k = 0;
+  while (k + 1 < n_reg && reg[k + 1].off <= t) ++k;
+  const GridRegion q = reg[k];
+  const long long l = t - q.off;
+  const int iv[3] = {q.lo[0] + (int)(l % q.n[0]), q.lo[1] + (int)((l / q.n[0]) % q.n[1]),
+                     q.lo[2] + (int)(l / ((long long)q.n[0] * q.n[1]))};
+  const long long I = v2lin(iv, g);
+#pragma unroll
+  for (int a = 0; a < BS; ++a) sendbuf[t * BS + a] = r[(long long)a * g.nn + I];
+}
+// r[.][I] = sum over the ranks, in ascending rank order on every rank (the same bits wherever two work boxes overlap), of
+// their partial sums at I: this rank's own (already in r) and what the regions received hold; a thread per node of the box
+template <int BS>
+__global__ void k_gx_sum(GridDev g, BoxDev box, int my_rank, int n_reg, const GridRegion* __restrict__ reg,
+                         const double* __restrict__ recvbuf, double* __restrict__ r, const int* __restrict__ done) {
+  if (done && *done) return;
+  int iv[3];
+  long long I;
+  if (!box_node(box, g, (long long)blockIdx.x * blockDim.x + threadIdx.x, iv, &I)) return;
+  double own[BS], acc[BS];
+#pragma unroll
+  for (int a = 0; a < BS; ++a) {
+    own[a] = r[(long long)a * g.nn + I];
+    acc[a] = 0.0;
+  }
+  bool own_in = false;
+  for (int k = 0; k < n_reg; ++k) {
+    const GridRegion q = reg[k];
+    if (!own_in && q.rank > my_rank) {
+#pragma unroll
+      for (int a = 0; a < BS; ++a) acc[a] += own[a];
+      own_in = true;
+    }
+    const int d0 = iv[0] - q.lo[0], d1 = iv[1] - q.lo[1], d2 = iv[2] - q.lo[2];
+    if (d0 < 0 || d0 >= q.n[0] || d1 < 0 || d1 >= q.n[1] || d2 < 0 || d2 >= q.n[2]) continue;
+    const long long t = q.off + ((long long)d2 * q.n[1] + d1) * q.n[0] + d0;
+#pragma unroll
+    for (int a = 0; a < BS; ++a) acc[a] += recvbuf[t * BS + a];
+  }
+  if (!own_in) {
+#pragma unroll
+    for (int a = 0; a < BS; ++a) acc[a] += own[a];
+  }
+#pragma unroll
+  for (int a = 0; a < BS; ++a) r[(long long)a * g.nn + I] = acc[a];
+}
+
 // Galerkin product mesh -> first grid, A1 = P^T K P, in two gathers (no atomics, fixed summation orders).
 //
 // Step 1, T = K P restricted to a box: the parents of the neighbours of mesh node i lie in the (2R + 2)^D grid nodes
@@ -1810,6 +1865,69 @@ void mg_setup_t(glims_ctx* h, MgHierarchy& mg) {
     if (!mg.boxed) mg.box_fraction = 1.0;
     // per-rank operator entries: the box's share of the first grid
     mg.entries -= (int64_t)((1.0 - mg.box_fraction) * (double)mg.S * B2 * (double)g.nn);
+    // the first-grid residual by neighbour exchange (GridExchange): regions from the cores every rank holds
+    mg.gx.reset();
+    if (mg.boxed) {
+      GridExchange& x = mg.gx;
+      x.deg = deg0;
+      auto box_of = [&](int q, int* lo, int* hi) {   // work box of rank q, inclusive (whole grid if mg_work_box says so)
+        for (int a = 0; a < 6; ++a) probe.core[a] = all_cores[(size_t)q * 6 + a];
+        const BoxDev b = mg_work_box<D>(probe, g, deg0);
+        const int l3[3] = {b.lo0, b.lo1, b.lo2}, n3[3] = {b.n0, b.n1, b.n2};
+        for (int a = 0; a < 3; ++a) {
+          lo[a] = b.nn ? l3[a] : 0;
+          hi[a] = b.nn ? l3[a] + n3[a] - 1 : g.n[a] - 1;
+        }
+      };
+      auto cut = [&](const int* blo, const int* bhi, int q, GridRegion* out) {   // box n core_q
+        long long vol = 1;
+        for (int a = 0; a < 3; ++a) {
+          const int lo = std::max(blo[a], all_cores[(size_t)q * 6 + a]), hi = std::min(bhi[a], all_cores[(size_t)q * 6 + 3 + a]);
+          out->lo[a] = lo;
+          out->n[a] = hi - lo + 1;
+          if (hi < lo) return 0ll;
+          vol *= out->n[a];
+        }
+        out->rank = q;
+        return vol;
+      };
+      int mylo[3], myhi[3];
+      box_of(h->rank, mylo, myhi);
+      std::vector<GridRegion> sreg, rreg;
+      x.send_ptr.assign(1, 0);
+      x.recv_ptr.assign(1, 0);
+      for (int q = 0; q < h->world; ++q) {
+        if (q == h->rank) continue;
+        GridRegion rs, rr;
+        int qlo[3], qhi[3];
+        box_of(q, qlo, qhi);
+        const long long vs = cut(qlo, qhi, h->rank, &rs);   // what q needs of my partial sums: box_q n core_me
+        const long long vr = cut(mylo, myhi, q, &rr);        // what I need of q's: box_me n core_q
+        if (vs == 0 && vr == 0) continue;
+        x.peers.push_back(q);
+        if (vs > 0) {
+          rs.rank = q;
+          rs.off = x.n_send;
+          sreg.push_back(rs);
+          x.n_send += vs;
+        }
+        if (vr > 0) {
+          rr.off = x.n_recv;
+          rreg.push_back(rr);
+          x.n_recv += vr;
+        }
+        x.send_ptr.push_back(x.n_send);
+        x.recv_ptr.push_back(x.n_recv);
+      }
+      x.n_send_reg = (int)sreg.size();
+      x.n_recv_reg = (int)rreg.size();
+      if (!sreg.empty()) x.send_reg.upload(sreg, h->st);
+      if (!rreg.empty()) x.recv_reg.upload(rreg, h->st);
+      x.sendbuf.alloc((size_t)std::max<long long>(1, x.n_send) * BS);
+      x.recvbuf.alloc((size_t)std::max<long long>(1, x.n_recv) * BS);
+      GL_HIP(hipStreamSynchronize(h->st));
+      x.ready = true;
+    }
   }
   mg.complexity = 1.0 + (double)mg.entries / ((double)p.total_entries * B2);
   mg.ms_setup = 1e3 * (omp_get_wtime() - t_start);
@@ -1824,6 +1942,9 @@ void mg_setup_t(glims_ctx* h, MgHierarchy& mg) {
       fprintf(stderr, "glims multigrid, rank %d: level-0 passes %s (%d interior / %d boundary slices); first grid %s (work box %.0f %% of it)\n",
               h->rank, gl_mg_split_level0(h, mg) ? "split around the halo exchange" : "after the halo exchange",
               (int)p.n_interior, (int)p.n_boundary, mg.boxed ? "box-limited" : "whole on every rank", 100.0 * mg.box_fraction);
+    if (framed && mg.boxed && mg.gx.ready)
+      fprintf(stderr, "glims multigrid, rank %d: first-grid residual by neighbour exchange with %d peers, %.1f KB out / %.1f KB in per cycle (the all-reduce moves %.1f KB)\n",
+              h->rank, (int)mg.gx.peers.size(), mg.gx.n_send * BS * 8e-3, mg.gx.n_recv * BS * 8e-3, mg.lv[0]->g.nn * BS * 8e-3);
   }
 }
 
@@ -1958,7 +2079,22 @@ void mg_apply_t(glims_ctx* h, MgHierarchy& mg, int deg, const double* r, double*
                        mg.pt_w.p, (const double*)mg.res.p, L1.r.p, c2_1 != 0.0 ? L1.dinv.p : nullptr, sc1, L1.d.p,
                        L1.x.p, c2_1, done);
   GL_HIP(hipGetLastError());
-  if (reduce1) gl_allreduce_bulk(h, L1.r.p, (size_t)BS * L1.g.nn);
+  if (reduce1 && mg.boxed && mg.gx.ready && deg <= mg.gx.deg) {
+    // box-limited cycle: this rank needs the sum on its work box only -> neighbour exchange of (box n core) regions
+    GridExchange& x = mg.gx;
+    if (x.n_send > 0)
+      hipLaunchKernelGGL((k_gx_pack<BS>), dim3(gridn(x.n_send)), dim3(256), 0, h->st, g1, x.n_send_reg, x.send_reg.p, x.n_send,
+                         L1.r.p, x.sendbuf.p, done);
+    GL_HIP(hipGetLastError());
+    gl_exchange(h, x.peers, x.send_ptr, x.recv_ptr, x.sendbuf.p, x.recvbuf.p, BS);
+    const BoxDev box = mg_work_box<D>(mg, L1.g, deg);
+    if (x.n_recv_reg > 0)
+      hipLaunchKernelGGL((k_gx_sum<BS>), dim3(gridn(box.nn ? box.nn : g1.nn)), dim3(256), 0, h->st, g1, box, h->rank, x.n_recv_reg,
+                         x.recv_reg.p, x.recvbuf.p, L1.r.p, done);
+    GL_HIP(hipGetLastError());
+  } else if (reduce1) {
+    gl_allreduce_bulk(h, L1.r.p, (size_t)BS * L1.g.nn);
+  }
   mg_cycle_cart<D, BS>(h, mg, deg, 0, done, c2_1 != 0.0);
   if (x32)
     hipLaunchKernelGGL((k_mg_prolong0<D, BS, float>), dim3(gridn(n)), dim3(256), 0, h->st, g1, n, mg.cell0.p, mg.wgt.p, fx,

@@ -660,6 +660,30 @@ void gl_halo_exchange(glims_ctx* h, double* vec, int bs) {
   halo_start(h, vec, bs);
   halo_finish(h);
 }
+void gl_exchange(glims_ctx* h, const std::vector<int32_t>& peers, const std::vector<int64_t>& send_ptr,
+                 const std::vector<int64_t>& recv_ptr, const double* sendbuf, double* recvbuf, int bs) {
+  const int np = (int)peers.size();
+  if (h->world <= 1 || np == 0) return;
+  if (h->tr_halo) {
+    const int rc = h->tr_halo(h->tr_user, sendbuf, send_ptr.data(), recvbuf, recv_ptr.data(), np, peers.data(), bs, (void*)h->st);
+    if (rc != 0) throw glims_error(GLIMS_E_RCCL, "transport halo callback failed (" + std::to_string(rc) + ")");
+    return;
+  }
+  GL_REQUIRE(h->comm_halo, "world > 1 but no communicator: call glims_comm_init or glims_set_transport");
+  GL_HIP(hipEventRecord(h->ev_pack, h->st));
+  GL_HIP(hipStreamWaitEvent(h->st_comm, h->ev_pack, 0));
+  GL_NCCL(ncclGroupStart());
+  for (int p = 0; p < np; ++p) {
+    const int64_t ns = send_ptr[p + 1] - send_ptr[p], nr = recv_ptr[p + 1] - recv_ptr[p];
+    if (ns > 0)
+      GL_NCCL(ncclSend(sendbuf + send_ptr[p] * bs, (size_t)ns * bs, ncclDouble, peers[p], h->comm_halo, h->st_comm));
+    if (nr > 0)
+      GL_NCCL(ncclRecv(recvbuf + recv_ptr[p] * bs, (size_t)nr * bs, ncclDouble, peers[p], h->comm_halo, h->st_comm));
+  }
+  GL_NCCL(ncclGroupEnd());
+  GL_HIP(hipEventRecord(h->ev_halo, h->st_comm));
+  GL_HIP(hipStreamWaitEvent(h->st, h->ev_halo, 0));
+}
 void gl_halo_start(glims_ctx* h, double* vec, int bs) { halo_start(h, vec, bs); }
 void gl_halo_finish(glims_ctx* h) { halo_finish(h); }
 // Sum over ranks of the values reduce_partials / k_reduce_cg just left in `dev` (= h->red).  With the node mailbox

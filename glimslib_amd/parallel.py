@@ -135,11 +135,14 @@ class HostStagedTransport:
             reqs, rbufs = [], []
             for p in range(n_peers):
                 lo, hi = send_ptr[p] * bs, send_ptr[p + 1] * bs
-                sb = self.torch.from_numpy(self._d2h(sendbuf + lo * 8, hi - lo))
-                reqs.append(self.dist.isend(sb, int(peers[p]), group=self.group))
-                rb = self.torch.empty(int((recv_ptr[p + 1] - recv_ptr[p]) * bs), dtype=self.torch.float64)
-                reqs.append(self.dist.irecv(rb, int(peers[p]), group=self.group))
-                rbufs.append((recv_ptr[p] * bs, rb))
+                if hi > lo:      # (an empty direction is skipped on both sides: the two ranks derive the same counts)
+                    sb = self.torch.from_numpy(self._d2h(sendbuf + lo * 8, hi - lo))
+                    reqs.append(self.dist.isend(sb, int(peers[p]), group=self.group))
+                nr = int((recv_ptr[p + 1] - recv_ptr[p]) * bs)
+                if nr > 0:
+                    rb = self.torch.empty(nr, dtype=self.torch.float64)
+                    reqs.append(self.dist.irecv(rb, int(peers[p]), group=self.group))
+                    rbufs.append((recv_ptr[p] * bs, rb))
             for r in reqs:
                 r.wait()
             for off, rb in rbufs:
