@@ -215,16 +215,28 @@ def _free_port():
     return p
 
 
+def _partitioned_problem(n):
+    """n > 0: BASELINE config C2's unit cube; n < 0: the unit square with -n cells per edge, same coefficients."""
+    if n > 0:
+        return workloads.config_c2(n)
+    mesh = RectangleMesh((0.0, 0.0), (1.0, 1.0), -n, -n)
+    label = np.ones(mesh.num_cells(), dtype=np.int32)
+    tables = dict(D=[0.0, 0.1], rho=[0.0, 0.1], gamma=[0.0, 0.1], E=[1.0, 3e-3], nu=[0.3, 0.45])
+    c0 = np.exp(-1.0 * ((mesh.points - 0.5) ** 2).sum(axis=1))
+    return workloads.Workload("unit square n=%d" % -n, mesh, label, tables, c0, 1.0, 20, False)
+
+
 def _rd_worker(rank, world, port, out_dir, n):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["GLIMS_MG_BOX_MIN_NODES"] = "6001"   # first grids above 6 000 nodes (n = 48): box-limited, neighbour exchange
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from glimslib_amd import _backend
         from glimslib_amd.parallel import HostStagedTransport
         from glimslib_amd.partition import partition_mesh
-        w = workloads.config_c2(n)
+        w = _partitioned_problem(n)
         part = partition_mesh(w.mesh.points, w.mesh.cells, world, rank)
         h = _backend.Handle(part.points, part.cells, w.cell_label[part.cell_ids], n_own=part.n_own, device=0)
         tr = HostStagedTransport(dist)
@@ -246,10 +258,12 @@ def _rd_worker(rank, world, port, out_dir, n):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("n,world", [(24, 2), (32, 3)])
+@pytest.mark.parametrize("n,world", [(24, 2), (32, 3), (48, 2), (-200, 2)])
 def test_partitioned_rd_multigrid_equals_the_single_rank_run(tmp_path, backend, n, world):
+    """(n = 48 and the 200 x 200 square, n = -200: first grids above 6 000 nodes -- each rank smooths its work box only and
+    the first grid's residual travels by neighbour exchange, in 3-D and 2-D with one unknown per node)"""
     import torch.multiprocessing as mp
-    w = workloads.config_c2(n)
+    w = _partitioned_problem(n)
     # (a framed partitioned run lays a coarser first grid from three ranks on -- replicated levels do not shrink with the
     #  rank count: the single-rank reference uses the same spacing)
     h = _handle(backend, w.mesh, w.cell_label, w.tables, rd_precond=backend.RD_PRECOND_MULTIGRID,
