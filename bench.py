@@ -197,6 +197,9 @@ def main():
     ap.add_argument("--fp32-jacobian", type=int, default=0,
                     help="1: GLIMS_FLAG_FP32_JACOBIAN (study runs only; the line then says dtype f64/f32-jacobian)")
     ap.add_argument("--warm-start", type=int, default=None, help="override GLIMS_FLAG_WARM_START (tuning runs only)")
+    ap.add_argument("--full-newton", type=int, default=0,
+                    help="1: GLIMS_FLAG_FULL_NEWTON, a sweep after every linear solve (A/B against the default, which takes "
+                         "the residual after a solve from the quadratic structure)")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON result of rank 0.  Libraries below us write there too (gloo announces
@@ -288,6 +291,8 @@ def main():
         flags = (flags | 2) if args.warm_start else (flags & ~2)
     if args.fp32_jacobian:
         flags |= 4
+    if args.full_newton:
+        flags |= 128
     # HIP events around the Krylov SpMV launches of the timed steps (the dominant kernel's in-step roofline figure)
     h.set_options(dt=w.dt, flags=flags, time_kernels=1, **extra)
     # coupled configs (C5): the displacement is solved after EVERY step, as the reference's monolithic solve does; the
@@ -437,6 +442,11 @@ def main():
                      "4-byte column] + 32 per row)", 12 * st['n_corners'] + 20 * st['nnz_padded'] + 32 * st['n_rows'],
                      st_k['ms_sweep_steps'], st_k['n_sweep_steps'], st_k['us_sweep_median'], "k_rd_assemble", ks, kms,
                      where)
+        kernel_entry("k_rd_quad<4, 24, 1>", "Newton residual after a solve from the quadratic structure: r - dt N(a) delta "
+                     "over the (row, cell) incidences, neither S nor A touched (algorithmic bytes: 12 per incidence + 4 per "
+                     "stored entry [column] + 32 per row [a, delta gathered once, r read + written])",
+                     12 * st['n_corners'] + 4 * st['nnz_padded'] + 32 * st['n_rows'],
+                     st_k['ms_quad_steps'], st_k['n_quad_steps'], st_k['us_quad_median'], "k_rd_quad", ks, kms, where)
         kernel_entry("k_cg_update<1>", "PCG recurrence scalars + p, s, x, r, u update + next (r.u, r.r) partials "
                      "(algorithmic bytes: 12 vector passes x 8 B per row)", 96 * st['n_rows'],
                      st_k['ms_update_steps'], st_k['n_update_steps'], st_k['us_update_median'], "k_cg_update<1>", ks, kms,
@@ -561,6 +571,7 @@ def main():
                        "newton_its_per_step": st['newton_its'] / max(1, steps_done),
                        "cg_its_per_step": st['cg_its'] / max(1, steps_done),
                        "assemblies_per_step": st['rd_assemblies'] / max(1, steps_done),
+                       "quadratic_residual_updates_per_step": st['rd_quad_updates'] / max(1, steps_done),
                        "device_ms_per_step": st['ms_steps'] / max(1, steps_done),
                        "steps_completed": steps_done,
                        "solver_status": int(status)},

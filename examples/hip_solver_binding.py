@@ -32,7 +32,7 @@ LIB = os.environ.get("GLIMSHIP_LIB", os.path.join(HERE, "..", "glimslib_amd", "l
 dp, i32p, i64p = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
 
 
-class Options(C.Structure):      # glims_options, include/glims_hip.h (ABI 3)
+class Options(C.Structure):      # glims_options, include/glims_hip.h (ABI 4)
     _fields_ = [("dt", C.c_double), ("newton_rtol", C.c_double), ("newton_atol", C.c_double),
                 ("newton_maxit", C.c_int), ("cg_rtol", C.c_double), ("cg_atol", C.c_double), ("cg_maxit", C.c_int),
                 ("mech_rtol", C.c_double), ("mech_atol", C.c_double), ("mech_maxit", C.c_int),
@@ -46,7 +46,7 @@ def _load():
     lib = C.CDLL(LIB)
     h = C.c_void_p
     lib.glims_abi_version.restype = C.c_int
-    assert lib.glims_abi_version() == 3, "rebuild libglimship.so: this binding is written for ABI 3"
+    assert lib.glims_abi_version() == 4, "rebuild libglimship.so: this binding is written for ABI 4"
     lib.glims_create.argtypes = [C.POINTER(h), C.c_int, C.c_int64, C.c_int64, C.c_int64, dp, i32p, i32p, C.c_int]
     lib.glims_destroy.argtypes = [h]
     lib.glims_last_error.restype = C.c_char_p

@@ -24,9 +24,10 @@ FLAG_MG_FP32_SMOOTHER = 8
 FLAG_INT32_COLUMNS = 16
 FLAG_MG_FP64_VECTORS = 32
 FLAG_MG_WHOLE_GRID = 64
+FLAG_FULL_NEWTON = 128
 PRECOND_BLOCK_JACOBI, PRECOND_MULTIGRID = 0, 1
 RD_PRECOND_AUTO, RD_PRECOND_JACOBI, RD_PRECOND_MULTIGRID = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class BackendError(RuntimeError):
@@ -61,7 +62,9 @@ class Stats(C.Structure):
                 ("rd_precond_used", C.c_int64), ("rd_stiffness_ratio", C.c_double), ("rd_mg_levels", C.c_int64),
                 ("rd_mg_cycles", C.c_int64), ("rd_mg_complexity", C.c_double), ("ms_rd_mg_setup", C.c_double),
                 ("ms_mgfine_mech", C.c_double), ("n_mgfine_mech", C.c_int64), ("us_mgfine_median", C.c_double),
-                ("ms_spmvb_mech", C.c_double), ("n_spmvb_mech", C.c_int64), ("us_spmvb_median", C.c_double)]
+                ("ms_spmvb_mech", C.c_double), ("n_spmvb_mech", C.c_int64), ("us_spmvb_median", C.c_double),
+                ("rd_quad_updates", C.c_int64), ("ms_quad_steps", C.c_double), ("n_quad_steps", C.c_int64),
+                ("us_quad_median", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -395,7 +395,7 @@ struct glims_ctx {
   int64_t stats_defer_miss = 0;
   int64_t nnz_idx16_avail = 0;             // stored entries of slices that have 16-bit codes
   // glims_options.time_kernels: event pairs around the hot kernels of glims_step (bench.py's in-step roofline figures)
-  enum { TK_SPMV = 0, TK_SWEEP = 1, TK_UPDATE = 2, TK_MGFINE = 3, TK_SPMVB = 4, TK_COUNT = 5 };
+  enum { TK_SPMV = 0, TK_SWEEP = 1, TK_UPDATE = 2, TK_MGFINE = 3, TK_SPMVB = 4, TK_QUAD = 5, TK_COUNT = 6 };
   std::vector<hipEvent_t> tev;
   std::vector<uint8_t> tev_cat;             // category of pair q = events 2q, 2q+1
   size_t tev_used = 0;
@@ -403,8 +403,9 @@ struct glims_ctx {
   // kernels inside a timed region at 1 M rows); 2: all three categories
   // 3: the two dominant kernels of the elasticity solve instead (level-0 multigrid pass, block SpMV; eager launches)
   bool timing(int cat) const {
-    const bool on = cat >= TK_MGFINE ? opt.time_kernels == 3
-                                     : (opt.time_kernels == 2 || (opt.time_kernels == 1 && cat == TK_SPMV));
+    const bool on = (cat == TK_MGFINE || cat == TK_SPMVB)
+                        ? opt.time_kernels == 3
+                        : (opt.time_kernels == 2 || (opt.time_kernels == 1 && cat == TK_SPMV));
     return on && tev_used + 2 <= tev.size();
   }
   void timing_begin();                      // allocates the event pool on first use
@@ -428,6 +429,11 @@ struct glims_ctx {
   // vectors (internal numbering; length n_nodes unless noted)
   dvec<double> c, c_old, b, load_rd, dinv;
   dvec<double> cg_p, cg_s, cg_u, cg_w, cg_r, cg_r2, b2;     // scalar CG work vectors; r2/b2: speculative next step
+  // Newton residuals from the quadratic structure (k_rd_quad): the step's first iterate c_0 (whose Jacobian the solves
+  // use), the iterate before the last solve, and the two staged vectors a = c_new + c_k - 2 c_0, delta = c_new - c_k
+  dvec<double> nq_c0, nq_ck;
+  dvec<float> nq_ad;                                          // (a, delta) pairs, single precision (see k_rd_quad)
+  int nq_skip_steps = 0;                                      // steps left without cheap evaluations (after a poor contraction)
   int cg_hint[8] = {0, 0, 0, 0, 0, 0, 0, 0};                  // PCG iterations of the k-th Newton solve of the previous step
   int mech_hint = 0;
   // history of solved elasticity problems (right-hand side, free-dof solution): the operator is linear and time
@@ -494,6 +500,7 @@ struct glims_ctx {
 void gl_compute_egeo(glims_ctx* h, const double* d_xyz, const int32_t* d_cells);
 void gl_assemble_static(glims_ctx* h, int with_mechanics);
 int gl_rd_grid(const glims_ctx* h);
+void gl_rd_quad(glims_ctx* h, const float* ad /*[n_nodes][2] = (a, delta)*/, double* r, double* partials /*[gl_rd_grid][2]*/);
 int gl_spmv_grid(int n_launch);
 enum { GL_PART_ALL = 0, GL_PART_INTERIOR = 1, GL_PART_BOUNDARY = 2 };   // slices without / with ghost columns
 void gl_rd_assemble(glims_ctx* h, const double* c, const double* b, const double* b2, double* r_out, double* r2_out,

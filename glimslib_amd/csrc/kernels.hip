@@ -364,6 +364,95 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Newton residual WITHOUT a sweep.  The RD residual is exactly quadratic in c:
+//     R(c + delta) = R(c) + A(c) delta + dt N(delta) delta,      A(c) = S + 2 dt N(c),  N linear in its argument,
+// so after a linear solve  A0 delta = -R_k  with the Jacobian A0 = A(c_0) of the step's first iterate
+//     R_{k+1} = (R_k + A0 delta) + dt N(a) delta,     a = 2 (c_k - c_0) + delta,
+// and the bracket is minus the Krylov solver's final residual vector.  This kernel turns that vector (in r) into the next
+// right-hand side -R_{k+1} = r - dt N(a) delta: phases 1 and 2 of k_rd_assemble with two staged vectors (a, delta) and a
+// scalar accumulator per row -- the incidence records and the column codes are streamed, neither S nor A.
+// partials: [slice][2] = (|r_new|^2 of the slice's rows, 0).
+// ---------------------------------------------------------------------------------------------------
+template <int NV, int CU, int CIDX>
+__global__ __launch_bounds__(GL_WAVE) void k_rd_quad(
+    const int32_t* __restrict__ slice_list, int64_t n_own, const int64_t* __restrict__ slice_ptr,
+    const int32_t* __restrict__ cols, const uint16_t* __restrict__ cols16, const int32_t* __restrict__ win_base,
+    const uint8_t* __restrict__ win_ok, const int64_t* __restrict__ cslice_ptr, const uint32_t* __restrict__ cslots,
+    const double* __restrict__ cw, const uint8_t* __restrict__ diag_k, const float2* __restrict__ ad,
+    double* __restrict__ r, const uint8_t* __restrict__ fixed, double dt,
+    double* __restrict__ partials, int max_len, int remap) {
+  // (a, delta) pairs in single precision, one 8-byte LDS column per neighbour: the term is a correction of relative size
+  // dt rho |delta| to the residual, its rounding error 1e-7 of THAT -- far below the Newton target -- and half the LDS of
+  // two double columns means twice the waves per CU on a kernel that is bound by the incidence loop's LDS traffic
+  extern __shared__ float2 ldsq[];
+  const int lane = threadIdx.x;
+  const int s = slice_list[remap > 1 ? xcd_chunk_remap(blockIdx.x, gridDim.x, 4 * remap) : blockIdx.x];
+  const int64_t row = (int64_t)s * GL_WAVE + lane;
+  const int64_t base = slice_ptr[s], cbase = cslice_ptr[s];
+  const int len = (int)((slice_ptr[s + 1] - base) >> 6), clen = (int)((cslice_ptr[s + 1] - cbase) >> 6);
+  auto gather = [&](auto load_col) {
+    for (int k = 0; k < len; k += 8) {   // (ragged tail: slot index clamped, surplus stores skipped)
+      int32_t ci8[8];
+      float2 v8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ci8[j] = load_col(min(k + j, len - 1));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v8[j] = ad[ci8[j]];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (k + j < len) ldsq[(k + j) * GL_WAVE + lane] = v8[j];
+    }
+  };
+  if (CIDX && win_ok[s]) {
+    const uint16_t* c16 = cols16 + base + lane;
+    const int32_t wb = win_base[(int64_t)s * GL_N_WIN + (lane & (GL_N_WIN - 1))];
+    gather([&](int k) { return decode_col(c16[(int64_t)k * GL_WAVE], wb); });
+  } else {
+    const int32_t* cc = cols + base + lane;
+    gather([&](int k) { return cc[(int64_t)k * GL_WAVE]; });
+  }
+  const int dk = diag_k[row];
+  const float ai = ldsq[dk * GL_WAVE + lane].x;
+  const uint32_t* sl = cslots + cbase + lane;
+  const double* wp = cw + cbase + lane;
+  double q = 0.0;
+  auto corner = [&](double w, uint32_t slots) {
+    if (w == 0.0) return;
+    float2 v[NV];
+    int k[NV];
+    float sa = 0.0f, t = 0.0f;
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+      k[m] = (int)((slots >> (8 * m)) & 255u);
+      v[m] = ldsq[k[m] * GL_WAVE + lane];
+    }
+#pragma unroll
+    for (int m = 0; m < NV; ++m) sa += v[m].x;
+    // row i of N(a) restricted to this cell, applied to delta: N_ii = w (4 a_i + 2 s), N_ij = w (a_i + a_j + s)
+#pragma unroll
+    for (int m = 0; m < NV; ++m) t += ((k[m] == dk) ? (4.0f * ai + 2.0f * sa) : (ai + v[m].x + sa)) * v[m].y;
+    q += w * (double)t;
+  };
+  {
+    int qq = 0;
+    for (; qq + CU <= clen; qq += CU) corner_batch<CU, 0>(wp, sl, qq, corner);
+    for (; qq + 4 <= clen; qq += 4) corner_batch<4, 0>(wp, sl, qq, corner);
+    for (; qq < clen; ++qq) corner_batch<1, 0>(wp, sl, qq, corner);
+  }
+  double rr = 0.0;
+  if (row < n_own) {
+    const double rn = (fixed && fixed[row]) ? 0.0 : r[row] - dt * q;
+    r[row] = rn;
+    rr = rn * rn;
+  }
+  rr = wave_sum(rr);
+  if (lane == 0) {
+    partials[(size_t)s * 2 + 0] = rr;
+    partials[(size_t)s * 2 + 1] = 0.0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // MATRIX-FREE variant of y = A(c) x, for the A/B that SURVEY 7.1 step 5 asks for (glims_apply which = 7; the solver
 // does not use it): A(c) = S + 2 dt N(c) is never stored, N(c)'s row is rebuilt from the (row, cell) incidence lists
 // -- exactly the sweep's phase 2 -- and applied to the gathered x on the fly.  Per row it streams the incidence
@@ -998,6 +1087,33 @@ void gl_rd_assemble(glims_ctx* h, const double* c, const double* b, const double
   }
 #undef GL_RDV
 #undef GL_RD
+  GL_HIP(hipGetLastError());
+}
+
+// r <- r - dt N(a) delta and the partial sums of |r|^2 (k_rd_quad); same launch shape as the sweep
+void gl_rd_quad(glims_ctx* h, const float* ad, double* r, double* partials) {
+  const DevPattern& p = h->pat;
+  const uint8_t* fx = h->have_fixed_c ? h->fixed_c.p : nullptr;
+#define GL_RQ(NV, CIDX)                                                                                             \
+  do {                                                                                                             \
+    set_lds(k_rd_quad<NV, 24, CIDX>, lds);                                                                         \
+    hipLaunchKernelGGL((k_rd_quad<NV, 24, CIDX>), dim3(grid), dim3(GL_WAVE), lds, h->st, list, h->n_own,            \
+                       p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, p.win_ok.p, p.cslice_ptr.p, p.cslots.p,  \
+                       p.cw.p, p.diag_k.p, (const float2*)ad, r, fx, h->opt.dt, partials, cap, GL_XCD_CHUNK);       \
+  } while (0)
+  for (size_t bk = 0; bk < p.bucket_cap.size(); ++bk) {
+    const int cap = p.bucket_cap[bk];
+    const int grid = p.bucket_count[bk];
+    if (grid <= 0) continue;
+    const int32_t* list = p.bucket_slices[bk]->p;
+    const size_t lds = (size_t)cap * GL_WAVE * sizeof(float2);
+    if (h->nv == 3) {
+      if (h->use_idx16) GL_RQ(3, 1); else GL_RQ(3, 0);
+    } else {
+      if (h->use_idx16) GL_RQ(4, 1); else GL_RQ(4, 0);
+    }
+  }
+#undef GL_RQ
   GL_HIP(hipGetLastError());
 }
 

@@ -1125,6 +1125,34 @@ static void rd_sweep(glims_ctx* h, const double* b2, double* norms /*[2]*/, Mail
   h->stats.rd_assemblies++;
 }
 
+// a = c_new + c_k - 2 c_0 (= 2 (c_k - c_0) + delta),  delta = c_new - c_k   over all local nodes (ghosts included)
+__global__ void k_quad_prep(int64_t n, const double* __restrict__ cn, const double* __restrict__ ck,
+                            const double* __restrict__ c0, float2* __restrict__ ad) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double x = cn[i], y = ck[i], z = c0[i];
+  ad[i] = make_float2((float)((x - z) + (y - z)), (float)(x - y));   // differences in double, then rounded
+}
+
+// The Newton residual after a solve with the step's first Jacobian, from the quadratic structure (k_rd_quad): the Krylov
+// solver's final residual vector (in cg_r) becomes the next right-hand side, norms[0] its norm.  `krylov`: see rd_sweep.
+static void rd_quad_update(glims_ctx* h, const double* ck, double* norms /*[2]*/, Mail* krylov) {
+  gl_halo_exchange(h, h->c.p, 1);   // ghosts of the new iterate (those of c_k and c_0 came with their copies)
+  hipLaunchKernelGGL(k_quad_prep, dim3(grid_exact(h->n_nodes)), dim3(256), 0, h->st, h->n_nodes, h->c.p, ck,
+                     h->nq_c0.p, (float2*)h->nq_ad.p);
+  const bool timed = h->timing(glims_ctx::TK_QUAD);
+  if (timed) h->tick(glims_ctx::TK_QUAD);
+  gl_rd_quad(h, h->nq_ad.p, h->cg_r.p, h->partials.p);
+  if (timed) h->tick(glims_ctx::TK_QUAD);
+  reduce_partials(h, gl_rd_grid(h), 2, nullptr);
+  allreduce_sum(h, h->red.p, 2);
+  const Mail m = fetch(h, 2, krylov != nullptr);
+  norms[0] = std::sqrt(m.red[0]);
+  norms[1] = 0.0;
+  if (krylov) *krylov = m;
+  h->stats.rd_quad_updates++;
+}
+
 void glims_ctx::timing_begin() {
   if (opt.time_kernels && tev.empty()) {
     tev.resize(16384);
@@ -1144,11 +1172,11 @@ void glims_ctx::timing_collect() {
     d[std::min<int>(TK_COUNT - 1, tev_cat[q])].push_back(t);
   }
   double* sums[TK_COUNT] = {&stats.ms_spmv_steps, &stats.ms_sweep_steps, &stats.ms_update_steps, &stats.ms_mgfine_mech,
-                            &stats.ms_spmvb_mech};
+                            &stats.ms_spmvb_mech, &stats.ms_quad_steps};
   int64_t* cnts[TK_COUNT] = {&stats.n_spmv_steps, &stats.n_sweep_steps, &stats.n_update_steps, &stats.n_mgfine_mech,
-                             &stats.n_spmvb_mech};
+                             &stats.n_spmvb_mech, &stats.n_quad_steps};
   double* meds[TK_COUNT] = {&stats.us_spmv_median, &stats.us_sweep_median, &stats.us_update_median,
-                            &stats.us_mgfine_median, &stats.us_spmvb_median};
+                            &stats.us_mgfine_median, &stats.us_spmvb_median, &stats.us_quad_median};
   for (int c = 0; c < TK_COUNT; ++c) {
     if (d[c].empty()) continue;
     // reference duration = the 90th percentile (no-op launches are the SHORT ones; a single pair that straddles a
@@ -1214,6 +1242,28 @@ int gl_step(glims_ctx* h, int n_steps) {
     }
     const double r0 = nr;
     const double target = std::max(o.newton_atol, o.newton_rtol * r0);
+    // Residuals from the quadratic structure (default; GLIMS_FLAG_FULL_NEWTON: a sweep after every solve).  Between two
+    // sweeps the solves use A_0 = A(c_0), the Jacobian the last sweep assembled; after such a solve the residual is the
+    // Krylov residual plus dt N(a) delta (rd_quad_update: 48 % of a sweep's bytes, no Jacobian written).  A sweep runs
+    // after the step's first solve (see cheap_next), and
+    // (a) where convergence is expected -- it returns the TRUE residual and assembles the next step's system, as before;
+    // (b) when the cheap residual reports convergence without (a) having been predicted; (c) after an iteration whose
+    // residual is more than 5 x the linear solve's tolerance (strong nonlinearity: dt rho |c - c_0| is no longer small) --
+    // the sweep's Jacobian then becomes the new A_0.  Not combined with the extrapolated guess (no verifying sweep there).
+    // (nor with the single-precision Jacobian: the Krylov residual then belongs to the rounded operator)
+    // After a step in which (c) struck, the next eight steps run with sweeps only: where the nonlinearity is that strong a
+    // cheap evaluation buys an extra Newton iteration (dt rho = 0.6: 46 against 38 iterations in 8 steps without this).
+    if (h->nq_skip_steps > 0) --h->nq_skip_steps;
+    const bool quad = (o.flags & GLIMS_FLAG_FULL_NEWTON) == 0 && !extrapolate && !h->jac32 && h->nq_skip_steps == 0;
+    bool rebase = false;   // (c)
+    // Copies of iterates are made only where a cheap evaluation follows (known before the solve): after a sweep the base
+    // point c_0 IS the current iterate (`base_is_current`), so the first such copy serves as c_0 and as c_k (`ck_is_c0`);
+    // a second cheap evaluation in a row copies c_k into a buffer of its own.  One 8 B / node copy per cheap evaluation.
+    bool base_is_current = true, ck_is_c0 = false;
+    if (quad) {
+      for (dvec<double>* v : {&h->nq_c0, &h->nq_ck}) v->alloc((size_t)h->n_nodes);
+      h->nq_ad.alloc((size_t)2 * h->n_nodes);
+    }
     for (int it = 0;; ++it) {
       if (!std::isfinite(nr)) {
         status = GLIMS_NAN;
@@ -1226,6 +1276,21 @@ int gl_step(glims_ctx* h, int n_steps) {
       }
       // A(c_k) delta = -R(c_k);  the update is accumulated straight into c (x0 = 0  <=>  x = c_k)
       const double tol_lin = std::max(std::max(o.cg_atol, 0.5 * target), o.cg_rtol * nr);
+      // Newton converges quadratically here (the nonlinearity is exactly quadratic): once the residual before the
+      // solve was below ~sqrt(rtol) of the initial one, the next sweep will almost surely only confirm convergence,
+      // so let it also assemble the next step (costs one extra mass SpMV, saves a whole sweep per step).
+      // Otherwise the evaluation after this solve is the cheap one -- both known before the solve.
+      const bool speculate_next = !extrapolate && nr <= 1e-4 * std::sqrt(o.newton_rtol / 1e-10) * r0;
+      // (not after the step's FIRST solve, which takes the big step: its sweep moves A_0 to c_1, within ~1e-3 |delta_0| of
+      //  the step's solution -- with A(c^n) kept instead every later iteration contracts by dt rho |c - c^n| ~ 3e-3 only,
+      //  and the count per step rose from 3.35 to 3.65 at config C4)
+      const bool cheap_next = quad && !speculate_next && !rebase && it >= 1;
+      if (cheap_next) {   // c_k, the point the right-hand side belongs to (before a warm start moves c; ghosts are current)
+        ck_is_c0 = base_is_current;
+        base_is_current = false;
+        GL_HIP(hipMemcpyAsync(ck_is_c0 ? h->nq_c0.p : h->nq_ck.p, h->c.p, (size_t)h->n_nodes * sizeof(double),
+                              hipMemcpyDeviceToDevice, h->st));
+      }
       if (it == 0 && (o.flags & GLIMS_FLAG_WARM_START) && !extrapolate) {   // both options own the c_old buffer
         // initial guess of the first linear solve = the previous step's total increment: same linear system, same
         // solution, the Krylov iteration just starts closer.  One SpMV with the already assembled A(c^n).
@@ -1263,13 +1328,17 @@ int gl_step(glims_ctx* h, int n_steps) {
         status = cs;
         break;
       }
-      // Newton converges quadratically here (the nonlinearity is exactly quadratic): once the residual before the
-      // solve was below ~sqrt(rtol) of the initial one, the next sweep will almost surely only confirm convergence,
-      // so let it also assemble the next step (costs one extra mass SpMV, saves a whole sweep per step).
-      const bool speculate = !extrapolate && nr <= 1e-4 * std::sqrt(o.newton_rtol / 1e-10) * r0;
+      const bool speculate = speculate_next, cheap = cheap_next;   // (decided before the solve, see there)
       Mail km;
-      rd_sweep(h, speculate ? h->b2.p : nullptr, norms, deferred ? &km : nullptr, /*exchange_c=*/true,
-               /*mass_for_b2=*/speculate);
+      const double nr_before = nr;
+      if (cheap) {
+        rd_quad_update(h, ck_is_c0 ? h->nq_c0.p : h->nq_ck.p, norms, deferred ? &km : nullptr);
+      } else {
+        rd_sweep(h, speculate ? h->b2.p : nullptr, norms, deferred ? &km : nullptr, /*exchange_c=*/true,
+                 /*mass_for_b2=*/speculate);
+        base_is_current = true;   // a fresh Jacobian: A_0 = A(c) from here on
+        rebase = false;
+      }
       if (deferred) {
         // the linear solve's outcome arrives with the sweep: a solve that used up its hint + 2 iterations simply
         // was a slightly weaker Newton step (the residual below decides); give it more room next time
@@ -1284,6 +1353,26 @@ int gl_step(glims_ctx* h, int n_steps) {
         if (km.done == 3) h->cg_hint[slot] = 0;   // breakdown: next time take the polled path
       }
       nr = norms[0];
+      if (cheap && std::isfinite(nr)) {
+        if (nr <= target) {
+          // (b) converged by the cheap residual, unpredicted: the true residual and the next step's system from a sweep
+          rd_sweep(h, h->b2.p, norms, nullptr, /*exchange_c=*/false, /*mass_for_b2=*/true);
+          base_is_current = true;
+          nr = norms[0];
+          if (std::isfinite(nr) && nr <= target) {
+            std::swap(h->b.p, h->b2.p);
+            std::swap(h->cg_r.p, h->cg_r2.p);
+            h->pending = true;
+            h->pending_r0 = norms[1];
+            break;
+          }
+        } else if (nr > 5.0 * o.cg_rtol * nr_before) {
+          // (c): the solve was asked for cg_rtol (cheap evaluations only happen where that bound, not the Newton target,
+          // set its tolerance); a residual five times larger is the Jacobian's age showing
+          rebase = true;
+          h->nq_skip_steps = 9;
+        }
+      }
       if (speculate && std::isfinite(nr) && nr <= target) {
         std::swap(h->b.p, h->b2.p);
         std::swap(h->cg_r.p, h->cg_r2.p);

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GLIMS_ABI_VERSION 3
+#define GLIMS_ABI_VERSION 4
 
 enum {
   GLIMS_OK = 0,
@@ -137,6 +137,14 @@ typedef struct glims_options {
 #define GLIMS_FLAG_MG_FP64_VECTORS 32    /* OFF by default.  The level-0 cycle vectors of the elasticity multigrid (iterate,
                                            direction, scaled residual) are kept in double instead of single precision; the
                                            preconditioned residual handed to the Krylov solver is double either way */
+#define GLIMS_FLAG_FULL_NEWTON 128       /* OFF by default.  Every Newton iteration of the RD block re-assembles Jacobian and
+                                           residual in a sweep.  Default: in the middle of a time step (after its second,
+                                           third ... solve, unless convergence is expected) the residual follows from the
+                                           Krylov solver's final residual plus the exactly quadratic term dt N(a) delta -- one
+                                           pass over the incidence lists, the Jacobian of the previous sweep stays in use; the
+                                           sweep after the first solve and the one that confirms convergence (true residual,
+                                           next step's Jacobian) still run, and an iteration whose residual exceeds 5 x the
+                                           linear tolerance falls back to sweeps */
 #define GLIMS_FLAG_MG_WHOLE_GRID 64      /* OFF by default.  Partitioned runs with glims_set_mg_frame: every rank smooths the
                                            WHOLE replicated first grid instead of its work box (its part plus the smoothers'
                                            dependency margin) -- the same preconditioner up to rounding, more work per rank */
@@ -194,6 +202,11 @@ typedef struct glims_stats {
   double  ms_spmvb_mech;    /* block SpMV of the Krylov iteration (k_spmv_block2) */
   int64_t n_spmvb_mech;
   double  us_spmvb_median;
+  /* ---- ABI 4: Newton residuals from the quadratic structure of the RD residual (see GLIMS_FLAG_FULL_NEWTON) */
+  int64_t rd_quad_updates;  /* residual evaluations through the incidence lists only (no sweep, no Jacobian) */
+  double  ms_quad_steps;    /* time_kernels = 2: those passes (k_rd_quad), HIP events */
+  int64_t n_quad_steps;
+  double  us_quad_median;
 } glims_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------------------- */

@@ -1,0 +1,87 @@
+"""Newton residuals from the quadratic structure of the RD residual (default) against a sweep after every solve
+(GLIMS_FLAG_FULL_NEWTON).  R(c + delta) = R(c) + A(c) delta + dt N(delta) delta holds exactly for the logistic term of
+simulation_tumor_growth.py:115-120, so after a solve with the Jacobian A_0 = A(c_0) the next residual is the Krylov
+solver's final residual plus dt N(2 (c_k - c_0) + delta) delta -- one pass over the incidence lists (k_rd_quad)."""
+import numpy as np
+import pytest
+
+from glimslib_amd import workloads
+from glimslib_amd.mesh import RectangleMesh
+from oracle.glims_oracle import OracleTumorGrowth, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(backend, w, tables, steps, flags, **opts):
+    h = backend.Handle(w.mesh.points, w.mesh.cells, w.cell_label)
+    h.set_materials(tables['D'], tables['rho'], tables['gamma'], tables['E'], tables['nu'])
+    h.set_options(dt=w.dt, flags=flags, **opts)
+    h.setup(False)
+    h.set_state(w.c0)
+    status = h.step(steps)
+    c = h.get_state(want_u=False)[0]
+    st = h.stats()
+    h.close()
+    return status, c, st
+
+
+def _c3_reduced(n):
+    w = workloads.config_c3(n)
+    hx = 240.0 / n
+    w.c0 = np.exp(-((w.mesh.points - np.array([118.0, -109.0, 72.0])) ** 2).sum(axis=1) / (2.0 * (2.5 * hx) ** 2))
+    return w
+
+
+def test_same_newton_counts_and_fields_with_fewer_sweeps(backend):
+    """BASELINE config C3's parameters (dt rho = 0.05) on a reduced mesh, 12 steps: the same Newton and Krylov iteration
+    counts as the full-Newton path, one sweep per step replaced by the cheap pass, fields equal to solver tolerance, and
+    equal to the oracle's Newton + LU."""
+    w = _c3_reduced(24)
+    s1, c1, st1 = _run(backend, w, w.tables, 12, backend.FLAG_WARM_START)
+    s2, c2, st2 = _run(backend, w, w.tables, 12, backend.FLAG_WARM_START | backend.FLAG_FULL_NEWTON)
+    assert s1 == 0 and s2 == 0
+    print("quadratic updates: Newton %d, PCG %d, sweeps %d, cheap passes %d | full Newton: %d, %d, %d, %d" %
+          (st1['newton_its'], st1['cg_its'], st1['rd_assemblies'], st1['rd_quad_updates'],
+           st2['newton_its'], st2['cg_its'], st2['rd_assemblies'], st2['rd_quad_updates']))
+    assert st2['rd_quad_updates'] == 0 and st1['rd_quad_updates'] >= 10
+    assert st1['rd_assemblies'] + st1['rd_quad_updates'] <= st2['rd_assemblies'] + 2
+    assert abs(st1['newton_its'] - st2['newton_its']) <= 2 and abs(st1['cg_its'] - st2['cg_its']) <= 12
+    assert rel_l2(c1, c2) < 1e-9
+    o = OracleTumorGrowth(w.mesh.points, w.mesh.cells, w.per_cell('D'), w.per_cell('rho'), w.per_cell('gamma'),
+                          w.per_cell('E'), w.per_cell('nu'), w.dt)
+    co = w.c0
+    for _ in range(12):
+        co, _ = o.rd_step(co)
+    assert rel_l2(c1, co) < 1e-8
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_strong_nonlinearity_falls_back_to_sweeps(backend, dim):
+    """dt rho = 0.6 with c near the carrying capacity: the Jacobian of the step's first iterate is a poor one for the later
+    solves; iterations that contract by less than 10 x are followed by a sweep (a fresh Jacobian), so the run converges to
+    the same fields with at most a few more Newton iterations than the full-Newton path."""
+    if dim == 3:
+        w = _c3_reduced(16)
+        tables = dict(w.tables, rho=[12.0 * r for r in w.tables['rho']])
+    else:
+        mesh = RectangleMesh((0.0, 0.0), (10.0, 8.0), 60, 48)
+        lab = np.ones(mesh.num_cells(), dtype=np.int32)
+        tables = dict(D=[0.0, 0.05], rho=[0.0, 0.6], gamma=[0.0, 0.1], E=[1.0, 3e-3], nu=[0.3, 0.45])
+        c0 = 0.9 * np.exp(-0.2 * ((mesh.points - np.array([5.0, 4.0])) ** 2).sum(axis=1))
+        w = workloads.Workload("square", mesh, lab, tables, c0, 1.0, 8, False)
+    s1, c1, st1 = _run(backend, w, tables, 8, backend.FLAG_WARM_START)
+    s2, c2, st2 = _run(backend, w, tables, 8, backend.FLAG_WARM_START | backend.FLAG_FULL_NEWTON)
+    print("dim %d, dt rho = 0.6: Newton %d (sweeps %d, cheap passes %d) against %d with a sweep after every solve; "
+          "max c %.3f" % (dim, st1['newton_its'], st1['rd_assemblies'], st1['rd_quad_updates'], st2['newton_its'], c1.max()))
+    assert s1 == 0 and s2 == 0
+    assert st1['newton_its'] <= st2['newton_its'] + 3       # (after such an iteration the next eight steps use sweeps only)
+    assert rel_l2(c1, c2) < 1e-7
+    assert st1['last_newton_res'] <= 1e-9 * max(1.0, st2['last_newton_res'] / 1e-13)
+
+
+def test_not_combined_with_the_extrapolated_guess_or_the_fp32_jacobian(backend):
+    """Those two options have no verifying sweep / a rounded operator: they keep a sweep after every solve."""
+    w = _c3_reduced(16)
+    for flags in (backend.FLAG_EXTRAPOLATE_GUESS, backend.FLAG_WARM_START | backend.FLAG_FP32_JACOBIAN):
+        s, c, st = _run(backend, w, w.tables, 4, flags)
+        assert s == 0 and st['rd_quad_updates'] == 0
