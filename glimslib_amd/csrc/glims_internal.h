@@ -433,6 +433,7 @@ struct glims_ctx {
   // use), the iterate before the last solve, and the two staged vectors a = c_new + c_k - 2 c_0, delta = c_new - c_k
   dvec<double> nq_c0, nq_ck;
   dvec<float> nq_ad;                                          // (a, delta) pairs, single precision (see k_rd_quad)
+  double nq_first_ratio = 1e-3;                               // residual contraction of the last step's first Newton iteration
   int nq_skip_steps = 0;                                      // steps left without cheap evaluations (after a poor contraction)
   int cg_hint[8] = {0, 0, 0, 0, 0, 0, 0, 0};                  // PCG iterations of the k-th Newton solve of the previous step
   int mech_hint = 0;

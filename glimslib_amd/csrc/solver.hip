@@ -1260,6 +1260,10 @@ int gl_step(glims_ctx* h, int n_steps) {
     // point c_0 IS the current iterate (`base_is_current`), so the first such copy serves as c_0 and as c_k (`ck_is_c0`);
     // a second cheap evaluation in a row copies c_k into a buffer of its own.  One 8 B / node copy per cheap evaluation.
     bool base_is_current = true, ck_is_c0 = false;
+    // (margin 3: with 1 the cheap pass reported convergence unpredicted -- pass + confirming sweep -- in 14-28 % of the steps
+    //  of C4 / C3, with 3 in 2 %; with 10 the failed confirmations are back)
+    const double spec_margin = 3.0;
+    double ratio_est = h->nq_first_ratio;   // contraction of the previous Newton iteration (first one: of the last step's first)
     if (quad) {
       for (dvec<double>* v : {&h->nq_c0, &h->nq_ck}) v->alloc((size_t)h->n_nodes);
       h->nq_ad.alloc((size_t)2 * h->n_nodes);
@@ -1280,7 +1284,12 @@ int gl_step(glims_ctx* h, int n_steps) {
       // solve was below ~sqrt(rtol) of the initial one, the next sweep will almost surely only confirm convergence,
       // so let it also assemble the next step (costs one extra mass SpMV, saves a whole sweep per step).
       // Otherwise the evaluation after this solve is the cheap one -- both known before the solve.
-      const bool speculate_next = !extrapolate && nr <= 1e-4 * std::sqrt(o.newton_rtol / 1e-10) * r0;
+      // With cheap evaluations a sweep that FAILS to confirm convergence is the expensive mistake (C4, steps 60-160 of the
+      // 500: four iterations per step, the third evaluation a sweep that did not converge), so the prediction there is
+      // "this iteration contracts like the previous one did": residual x last observed contraction <= target.
+      const bool speculate_next =
+          !extrapolate && (quad ? nr * std::min(0.5, std::max(1e-6, ratio_est)) <= spec_margin * target
+                                : nr <= 1e-4 * std::sqrt(o.newton_rtol / 1e-10) * r0);
       // (not after the step's FIRST solve, which takes the big step: its sweep moves A_0 to c_1, within ~1e-3 |delta_0| of
       //  the step's solution -- with A(c^n) kept instead every later iteration contracts by dt rho |c - c^n| ~ 3e-3 only,
       //  and the count per step rose from 3.35 to 3.65 at config C4)
@@ -1353,6 +1362,10 @@ int gl_step(glims_ctx* h, int n_steps) {
         if (km.done == 3) h->cg_hint[slot] = 0;   // breakdown: next time take the polled path
       }
       nr = norms[0];
+      if (std::isfinite(nr) && nr_before > 0.0) {
+        ratio_est = nr / nr_before;
+        if (it == 0) h->nq_first_ratio = ratio_est;
+      }
       if (cheap && std::isfinite(nr)) {
         if (nr <= target) {
           // (b) converged by the cheap residual, unpredicted: the true residual and the next step's system from a sweep

@@ -23,8 +23,10 @@ while done < total:
     s = h.stats()
     n = s['steps'] - prev['steps']
     c = h.get_state(want_u=False)[0] if (st != 0 or (done // chunk) % 10 == 9) else None
-    print("steps %4d..%4d status %d  newton/step %.2f  cg/step %.2f  |R| %.3e  cg res %.3e  ms/step %.2f%s" %
+    print("steps %4d..%4d status %d  newton/step %.2f (sweeps %.2f, cheap passes %.2f)  cg/step %.2f  |R| %.3e  cg res %.3e  ms/step %.2f%s" %
           (done, done + n, st, (s['newton_its'] - prev['newton_its']) / max(n, 1),
+           (s['rd_assemblies'] - prev['rd_assemblies']) / max(n, 1),
+           (s['rd_quad_updates'] - prev['rd_quad_updates']) / max(n, 1),
            (s['cg_its'] - prev['cg_its']) / max(n, 1), s['last_newton_res'], s['last_cg_res'],
            (s['ms_steps'] - prev['ms_steps']) / max(n, 1),
            "" if c is None else "  c in [%.3e, %.6f], mass %.6e" % (c.min(), c.max(), c.sum())), flush=True)
