@@ -501,7 +501,8 @@ struct glims_ctx {
 void gl_compute_egeo(glims_ctx* h, const double* d_xyz, const int32_t* d_cells);
 void gl_assemble_static(glims_ctx* h, int with_mechanics);
 int gl_rd_grid(const glims_ctx* h);
-void gl_rd_quad(glims_ctx* h, const float* ad /*[n_nodes][2] = (a, delta)*/, double* r, double* partials /*[gl_rd_grid][2]*/);
+void gl_rd_quad(glims_ctx* h, const float* ad /*[n_nodes][2] = (a, delta)*/, double* r, double* partials /*[gl_rd_grid][2]*/,
+                int part = 0 /*GL_PART_ALL*/);
 int gl_spmv_grid(int n_launch);
 enum { GL_PART_ALL = 0, GL_PART_INTERIOR = 1, GL_PART_BOUNDARY = 2 };   // slices without / with ghost columns
 void gl_rd_assemble(glims_ctx* h, const double* c, const double* b, const double* b2, double* r_out, double* r2_out,

@@ -1091,7 +1091,7 @@ void gl_rd_assemble(glims_ctx* h, const double* c, const double* b, const double
 }
 
 // r <- r - dt N(a) delta and the partial sums of |r|^2 (k_rd_quad); same launch shape as the sweep
-void gl_rd_quad(glims_ctx* h, const float* ad, double* r, double* partials) {
+void gl_rd_quad(glims_ctx* h, const float* ad, double* r, double* partials, int part) {
   const DevPattern& p = h->pat;
   const uint8_t* fx = h->have_fixed_c ? h->fixed_c.p : nullptr;
 #define GL_RQ(NV, CIDX)                                                                                             \
@@ -1103,9 +1103,11 @@ void gl_rd_quad(glims_ctx* h, const float* ad, double* r, double* partials) {
   } while (0)
   for (size_t bk = 0; bk < p.bucket_cap.size(); ++bk) {
     const int cap = p.bucket_cap[bk];
-    const int grid = p.bucket_count[bk];
+    const int n_int = p.bucket_interior[bk];
+    const int grid = part == GL_PART_ALL ? p.bucket_count[bk]
+                     : part == GL_PART_INTERIOR ? n_int : p.bucket_count[bk] - n_int;
     if (grid <= 0) continue;
-    const int32_t* list = p.bucket_slices[bk]->p;
+    const int32_t* list = p.bucket_slices[bk]->p + (part == GL_PART_BOUNDARY ? n_int : 0);
     const size_t lds = (size_t)cap * GL_WAVE * sizeof(float2);
     if (h->nv == 3) {
       if (h->use_idx16) GL_RQ(3, 1); else GL_RQ(3, 0);

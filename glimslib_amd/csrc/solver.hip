@@ -1126,9 +1126,9 @@ static void rd_sweep(glims_ctx* h, const double* b2, double* norms /*[2]*/, Mail
 }
 
 // a = c_new + c_k - 2 c_0 (= 2 (c_k - c_0) + delta),  delta = c_new - c_k   over all local nodes (ghosts included)
-__global__ void k_quad_prep(int64_t n, const double* __restrict__ cn, const double* __restrict__ ck,
+__global__ void k_quad_prep(int64_t i0, int64_t n, const double* __restrict__ cn, const double* __restrict__ ck,
                             const double* __restrict__ c0, float2* __restrict__ ad) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = i0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double x = cn[i], y = ck[i], z = c0[i];
   ad[i] = make_float2((float)((x - z) + (y - z)), (float)(x - y));   // differences in double, then rounded
@@ -1137,13 +1137,29 @@ __global__ void k_quad_prep(int64_t n, const double* __restrict__ cn, const doub
 // The Newton residual after a solve with the step's first Jacobian, from the quadratic structure (k_rd_quad): the Krylov
 // solver's final residual vector (in cg_r) becomes the next right-hand side, norms[0] its norm.  `krylov`: see rd_sweep.
 static void rd_quad_update(glims_ctx* h, const double* ck, double* norms /*[2]*/, Mail* krylov) {
-  gl_halo_exchange(h, h->c.p, 1);   // ghosts of the new iterate (those of c_k and c_0 came with their copies)
-  hipLaunchKernelGGL(k_quad_prep, dim3(grid_exact(h->n_nodes)), dim3(256), 0, h->st, h->n_nodes, h->c.p, ck,
-                     h->nq_c0.p, (float2*)h->nq_ad.p);
-  const bool timed = h->timing(glims_ctx::TK_QUAD);
-  if (timed) h->tick(glims_ctx::TK_QUAD);
-  gl_rd_quad(h, h->nq_ad.p, h->cg_r.p, h->partials.p);
-  if (timed) h->tick(glims_ctx::TK_QUAD);
+  // the ghosts of the new iterate travel while the slices without ghost columns are processed (those of c_k and c_0 came
+  // with their copies), as in rd_sweep
+  const bool split = h->world > 1 && h->n_peers > 0;
+  auto prep = [&](int64_t i0, int64_t i1) {
+    if (i1 > i0)
+      hipLaunchKernelGGL(k_quad_prep, dim3(grid_exact(i1 - i0)), dim3(256), 0, h->st, i0, i1, h->c.p, ck, h->nq_c0.p,
+                         (float2*)h->nq_ad.p);
+  };
+  if (!split) {
+    gl_halo_exchange(h, h->c.p, 1);
+    prep(0, h->n_nodes);
+    const bool timed = h->timing(glims_ctx::TK_QUAD);
+    if (timed) h->tick(glims_ctx::TK_QUAD);
+    gl_rd_quad(h, h->nq_ad.p, h->cg_r.p, h->partials.p);
+    if (timed) h->tick(glims_ctx::TK_QUAD);
+  } else {
+    halo_start(h, h->c.p, 1);
+    prep(0, h->n_own);
+    gl_rd_quad(h, h->nq_ad.p, h->cg_r.p, h->partials.p, GL_PART_INTERIOR);
+    halo_finish(h);
+    prep(h->n_own, h->n_nodes);
+    gl_rd_quad(h, h->nq_ad.p, h->cg_r.p, h->partials.p, GL_PART_BOUNDARY);
+  }
   reduce_partials(h, gl_rd_grid(h), 2, nullptr);
   allreduce_sum(h, h->red.p, 2);
   const Mail m = fetch(h, 2, krylov != nullptr);
