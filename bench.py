@@ -443,9 +443,10 @@ def main():
                      st_k['ms_sweep_steps'], st_k['n_sweep_steps'], st_k['us_sweep_median'], "k_rd_assemble", ks, kms,
                      where)
         kernel_entry("k_rd_quad<4, 24, 1>", "Newton residual after a solve from the quadratic structure: r - dt N(a) delta "
-                     "over the (row, cell) incidences, neither S nor A touched (algorithmic bytes: 12 per incidence + 4 per "
-                     "stored entry [column] + 32 per row [a, delta gathered once, r read + written])",
-                     12 * st['n_corners'] + 4 * st['nnz_padded'] + 32 * st['n_rows'],
+                     "over the (row, cell) incidences, neither S nor A touched (algorithmic bytes: 8 per incidence [slot "
+                     "word + single-precision weight] + 4 per stored entry [column] + 24 per row [(a, delta) pair gathered "
+                     "once, r read + written])",
+                     8 * st['n_corners'] + 4 * st['nnz_padded'] + 24 * st['n_rows'],
                      st_k['ms_quad_steps'], st_k['n_quad_steps'], st_k['us_quad_median'], "k_rd_quad", ks, kms, where)
         kernel_entry("k_cg_update<1>", "PCG recurrence scalars + p, s, x, r, u update + next (r.u, r.r) partials "
                      "(algorithmic bytes: 12 vector passes x 8 B per row)", 96 * st['n_rows'],

@@ -136,6 +136,7 @@ struct DevPattern {
   dvec<uint32_t> cslots;
   dvec<int32_t> celem;
   dvec<double> cw;                         // per-incidence reaction weight rho_T |T| d!/(d+3)!
+  dvec<uint32_t> cq;                       // [incidence][2] = (slot word, weight as float bits): k_rd_quad's 8-byte records
   dvec<int32_t> interior_slices, boundary_slices;
   int32_t n_interior = 0, n_boundary = 0;
   std::vector<int> bucket_cap;

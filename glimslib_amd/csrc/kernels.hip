@@ -98,13 +98,18 @@ __global__ void k_egeo(int64_t n_cells, const double* __restrict__ xyz, const in
 template <int D>
 __global__ void k_corner_weights(int64_t n, const int32_t* __restrict__ celem, const uint8_t* __restrict__ label,
                                  const double* __restrict__ egeo, const double* __restrict__ mat,
-                                 double* __restrict__ cw) {
+                                 double* __restrict__ cw, const uint32_t* __restrict__ cslots,
+                                 uint2* __restrict__ cq) {
   constexpr int GE = 1 + (D + 1) * D;
   constexpr double fact = D == 2 ? 1.0 / 60.0 : 1.0 / 120.0;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int32_t e = celem[i];
-  cw[i] = e < 0 ? 0.0 : mat[1 * GL_MAX_LABELS + label[e]] * egeo[(int64_t)e * GE] * fact;
+  const double w = e < 0 ? 0.0 : mat[1 * GL_MAX_LABELS + label[e]] * egeo[(int64_t)e * GE] * fact;
+  cw[i] = w;
+  // the same record for k_rd_quad: slot word + the weight in single precision, 8 B instead of 12 (the quadratic term it
+  // feeds is itself a 1e-3 correction)
+  cq[i] = make_uint2(cslots[i], __float_as_uint((float)w));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -377,8 +382,8 @@ template <int NV, int CU, int CIDX>
 __global__ __launch_bounds__(GL_WAVE) void k_rd_quad(
     const int32_t* __restrict__ slice_list, int64_t n_own, const int64_t* __restrict__ slice_ptr,
     const int32_t* __restrict__ cols, const uint16_t* __restrict__ cols16, const int32_t* __restrict__ win_base,
-    const uint8_t* __restrict__ win_ok, const int64_t* __restrict__ cslice_ptr, const uint32_t* __restrict__ cslots,
-    const double* __restrict__ cw, const uint8_t* __restrict__ diag_k, const float2* __restrict__ ad,
+    const uint8_t* __restrict__ win_ok, const int64_t* __restrict__ cslice_ptr, const uint2* __restrict__ cq,
+    const uint8_t* __restrict__ diag_k, const float2* __restrict__ ad,
     double* __restrict__ r, const uint8_t* __restrict__ fixed, double dt,
     double* __restrict__ partials, int max_len, int remap) {
   // (a, delta) pairs in single precision, one 8-byte LDS column per neighbour: the term is a correction of relative size
@@ -413,11 +418,10 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_quad(
   }
   const int dk = diag_k[row];
   const float ai = ldsq[dk * GL_WAVE + lane].x;
-  const uint32_t* sl = cslots + cbase + lane;
-  const double* wp = cw + cbase + lane;
+  const uint2* rec = cq + cbase + lane;
   double q = 0.0;
-  auto corner = [&](double w, uint32_t slots) {
-    if (w == 0.0) return;
+  auto corner = [&](float w, uint32_t slots) {
+    if (w == 0.0f) return;
     float2 v[NV];
     int k[NV];
     float sa = 0.0f, t = 0.0f;
@@ -431,13 +435,15 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_quad(
     // row i of N(a) restricted to this cell, applied to delta: N_ii = w (4 a_i + 2 s), N_ij = w (a_i + a_j + s)
 #pragma unroll
     for (int m = 0; m < NV; ++m) t += ((k[m] == dk) ? (4.0f * ai + 2.0f * sa) : (ai + v[m].x + sa)) * v[m].y;
-    q += w * (double)t;
+    q += (double)(w * t);
   };
-  {
-    int qq = 0;
-    for (; qq + CU <= clen; qq += CU) corner_batch<CU, 0>(wp, sl, qq, corner);
-    for (; qq + 4 <= clen; qq += 4) corner_batch<4, 0>(wp, sl, qq, corner);
-    for (; qq < clen; ++qq) corner_batch<1, 0>(wp, sl, qq, corner);
+  for (int qq = 0; qq < clen; qq += CU) {   // CU records in flight (index clamped past the end: padding has weight 0)
+    uint2 rb[CU];
+#pragma unroll
+    for (int j = 0; j < CU; ++j) rb[j] = rec[(int64_t)min(qq + j, clen - 1) * GL_WAVE];
+#pragma unroll
+    for (int j = 0; j < CU; ++j)
+      if (qq + j < clen) corner(__uint_as_float(rb[j].y), rb[j].x);
   }
   double rr = 0.0;
   if (row < n_own) {
@@ -1016,11 +1022,12 @@ static void assemble_static_t(glims_ctx* h, int with_mechanics) {
     GL_HIP(hipGetLastError());
   }
   p.cw.alloc((size_t)p.total_corners);
+  p.cq.alloc((size_t)2 * p.total_corners);
   {
     const int bs = 256;
     const unsigned grid = (unsigned)((p.total_corners + bs - 1) / bs);
     hipLaunchKernelGGL(k_corner_weights<D>, dim3(grid), dim3(bs), 0, h->st, p.total_corners, p.celem.p, h->label.p,
-                       h->egeo.p, h->mat.p, p.cw.p);
+                       h->egeo.p, h->mat.p, p.cw.p, p.cslots.p, (uint2*)p.cq.p);
     GL_HIP(hipGetLastError());
   }
   if (with_mechanics) {
@@ -1098,8 +1105,9 @@ void gl_rd_quad(glims_ctx* h, const float* ad, double* r, double* partials, int 
   do {                                                                                                             \
     set_lds(k_rd_quad<NV, 24, CIDX>, lds);                                                                         \
     hipLaunchKernelGGL((k_rd_quad<NV, 24, CIDX>), dim3(grid), dim3(GL_WAVE), lds, h->st, list, h->n_own,            \
-                       p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, p.win_ok.p, p.cslice_ptr.p, p.cslots.p,  \
-                       p.cw.p, p.diag_k.p, (const float2*)ad, r, fx, h->opt.dt, partials, cap, GL_XCD_CHUNK);       \
+                       p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, p.win_ok.p, p.cslice_ptr.p,              \
+                       (const uint2*)p.cq.p, p.diag_k.p, (const float2*)ad, r, fx, h->opt.dt, partials, cap,        \
+                       GL_XCD_CHUNK);                                                                              \
   } while (0)
   for (size_t bk = 0; bk < p.bucket_cap.size(); ++bk) {
     const int cap = p.bucket_cap[bk];
