@@ -389,7 +389,7 @@ def main():
     # a measurement of this run: only reported when this run's operator is the one the passes measured, and
     # `traffic_source` names the file.
     pmc, pmc_file = None, None
-    for cand in ("r03_e_pmc_c4.json", "r03_d_pmc_c4.json", "r03_c_pmc_c4.json", "r03_b_pmc_c4.json", "r02_pmc_c4.json", "r01_pmc_c4.json"):
+    for cand in ("r03_f_pmc_c4.json", "r03_e_pmc_c4.json", "r03_d_pmc_c4.json", "r03_c_pmc_c4.json", "r03_b_pmc_c4.json", "r02_pmc_c4.json", "r01_pmc_c4.json"):
         try:
             q = json.load(open(os.path.join(HERE, "profiles", cand)))
             if world == 1 and q["n_rows"] == st['n_rows'] and q["nnz"] == st['nnz']:

@@ -4,7 +4,7 @@
 # Kernel traces and PMC passes are SEPARATE runs (MI355X_MICROARCH.md, HBM / rocprofv3 section); the program follows `--`
 # directly (no env / bash -c hop under the profiler).
 set -o pipefail
-tag=${1:-r03_e}
+tag=${1:-r03_f}
 out=gpurun_out/r03
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
