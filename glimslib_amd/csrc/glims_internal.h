@@ -435,6 +435,8 @@ struct glims_ctx {
   dvec<double> nq_c0, nq_ck;
   dvec<float> nq_ad;                                          // (a, delta) pairs, single precision (see k_rd_quad)
   double nq_first_ratio = 1e-3;                               // residual contraction of the last step's first Newton iteration
+  bool mid_on = false;                                        // midpoint correction of the first right-hand side (gl_step)
+  int mid_cooldown = 0, mid_streak = 0;
   int nq_skip_steps = 0;                                      // steps left without cheap evaluations (after a poor contraction)
   int cg_hint[8] = {0, 0, 0, 0, 0, 0, 0, 0};                  // PCG iterations of the k-th Newton solve of the previous step
   int mech_hint = 0;

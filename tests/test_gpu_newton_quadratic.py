@@ -32,10 +32,10 @@ def _c3_reduced(n):
     return w
 
 
-def test_same_newton_counts_and_fields_with_fewer_sweeps(backend):
-    """BASELINE config C3's parameters (dt rho = 0.05) on a reduced mesh, 12 steps: the same Newton and Krylov iteration
-    counts as the full-Newton path, one sweep per step replaced by the cheap pass, fields equal to solver tolerance, and
-    equal to the oracle's Newton + LU."""
+def test_no_more_newton_iterations_and_fewer_sweeps_same_fields(backend):
+    """BASELINE config C3's parameters (dt rho = 0.05) on a reduced mesh, 12 steps: no more Newton and Krylov iterations
+    than the full-Newton path, mid-step sweeps replaced by cheap passes, fields equal to solver tolerance, and equal to the
+    oracle's Newton + LU."""
     w = _c3_reduced(24)
     s1, c1, st1 = _run(backend, w, w.tables, 12, backend.FLAG_WARM_START)
     s2, c2, st2 = _run(backend, w, w.tables, 12, backend.FLAG_WARM_START | backend.FLAG_FULL_NEWTON)
@@ -45,7 +45,9 @@ def test_same_newton_counts_and_fields_with_fewer_sweeps(backend):
            st2['newton_its'], st2['cg_its'], st2['rd_assemblies'], st2['rd_quad_updates']))
     assert st2['rd_quad_updates'] == 0 and st1['rd_quad_updates'] >= 10
     assert st1['rd_assemblies'] + st1['rd_quad_updates'] <= st2['rd_assemblies'] + 2
-    assert abs(st1['newton_its'] - st2['newton_its']) <= 2 and abs(st1['cg_its'] - st2['cg_its']) <= 12
+    # (never more than the full-Newton path; fewer where the midpoint correction of the first right-hand side saves a
+    #  step's fourth iteration: 37 against 48 on this problem)
+    assert st1['newton_its'] <= st2['newton_its'] + 2 and st1['cg_its'] <= st2['cg_its'] + 12
     assert rel_l2(c1, c2) < 1e-9
     o = OracleTumorGrowth(w.mesh.points, w.mesh.cells, w.per_cell('D'), w.per_cell('rho'), w.per_cell('gamma'),
                           w.per_cell('E'), w.per_cell('nu'), w.dt)
