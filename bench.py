@@ -179,6 +179,74 @@ def alt_c5(Handle, device, steps=10, warmup=10):
     return out
 
 
+def alt_unstructured(Handle, device, steps=10, warmup=2, n_points=1000000):
+    """The brain-like unstructured mesh (workloads.config_brain_like: ~1 M nodes, quality-controlled Delaunay tetrahedra,
+    curved two-tissue interface, config C3's parameters) under the driver's clock -- the stand-in for the CGAL atlas
+    meshes the reference's 3-D cases load (test_case_comparison_3D_atlas.py:84-121): ms per step, iterations, and the
+    per-kernel roofline list (Krylov SpMV timed inside the timed steps, the other kernels in a short pass after them)."""
+    from glimslib_amd import workloads
+    tm = time.perf_counter()
+    w = workloads.config_brain_like(n_points, isolate=True)
+    t_mesh = time.perf_counter() - tm
+    n = w.mesh.num_vertices()
+    ts = time.perf_counter()
+    h = Handle(w.mesh.points, w.mesh.cells, w.cell_label, device=device)
+    t = w.tables
+    h.set_materials(t['D'], t['rho'], t['gamma'], t['E'], t['nu'])
+    h.set_options(dt=w.dt, time_kernels=1)
+    h.setup(with_mechanics=False)
+    h.set_state(w.c0)
+    t_setup = time.perf_counter() - ts
+    st = h.step(warmup)
+    h.reset_stats()
+    t0 = time.perf_counter()
+    st |= h.step(steps)
+    el = time.perf_counter() - t0
+    s = h.stats()
+    out = {"workload": w.name, "dofs": n, "cells": w.mesh.num_cells(), "steps": steps, "warmup": warmup,
+           "ms_per_step": 1e3 * el / steps, "value": n * steps / el, "solver_status": int(st),
+           "newton_its_per_step": s['newton_its'] / steps, "pcg_its_per_step": s['cg_its'] / steps,
+           "assemblies_per_step": s['rd_assemblies'] / steps, "quadratic_residual_updates_per_step": s['rd_quad_updates'] / steps,
+           "preconditioner": {1: "jacobi", 2: "multigrid"}.get(int(s['rd_precond_used']), "?"),
+           "nnz": int(s['nnz']), "nnz_padded": int(s['nnz_padded']), "n_corners": int(s['n_corners']),
+           "mesh_seconds": t_mesh, "setup_seconds": t_setup}
+    k_steps = 5
+    h.set_options(time_kernels=2)
+    h.reset_stats()
+    st |= h.step(k_steps)
+    k = h.stats()
+    kms = k['ms_steps'] / k_steps
+    kernels = []
+
+    def entry(name, what, alg, ms, cnt, med, n_steps, step_ms, where):
+        if cnt <= 0:
+            return
+        mean_us = 1e3 * ms / cnt
+        kernels.append({"name": name, "does": what, "algorithmic_bytes_per_launch": alg, "median_us": med,
+                        "mean_us": mean_us, "launches_per_step": cnt / float(n_steps),
+                        "achieved_GBps": alg / (mean_us * 1e-6) / 1e9, "frac": alg / (mean_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                        "share_of_step": ms / (step_ms * n_steps), "timed": where})
+
+    entry("k_spmv<1, 16, 1, 1, double>", "y = A(c) x, SELL-64 with 16-bit column codes, fused w.u partials (algorithmic "
+          "bytes: CSR with 4-byte columns, 12 nnz + 20 rows)", workloads.b_spmv_bytes(s['nnz'], s['n_rows']),
+          s['ms_spmv_steps'], s['n_spmv_steps'], s['us_spmv_median'], steps, 1e3 * el / steps,
+          "HIP events inside the %d timed steps" % steps)
+    where = "HIP events in a separate pass of %d steps right after the timed ones" % k_steps
+    entry("k_rd_assemble<4, ...>", "Jacobian + Newton residual(s) in one sweep over the (row, cell) incidences "
+          "(algorithmic bytes: 12 per incidence + 20 per stored entry + 32 per row; unpadded counts)",
+          12 * s['n_corners'] + 20 * s['nnz'] + 32 * s['n_rows'],
+          k['ms_sweep_steps'], k['n_sweep_steps'], k['us_sweep_median'], k_steps, kms, where)
+    entry("k_rd_quad<4, ...>", "Newton residual from the quadratic structure (algorithmic bytes: 8 per incidence + 4 per "
+          "stored entry + 24 per row)", 8 * s['n_corners'] + 4 * s['nnz'] + 24 * s['n_rows'],
+          k['ms_quad_steps'], k['n_quad_steps'], k['us_quad_median'], k_steps, kms, where)
+    entry("k_cg_update<1>", "PCG recurrence + vector update (96 B per row)", 96 * s['n_rows'],
+          k['ms_update_steps'], k['n_update_steps'], k['us_update_median'], k_steps, kms, where)
+    out["kernels"] = kernels
+    out["solver_status"] = int(st)
+    h.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -532,7 +600,7 @@ def main():
     # solves) and C5 (coupled, 1 M nodes) under the same clock, each a few seconds; the headline handle is released first
     if world == 1 and not args.no_alt and args.workload.lower() == "c4" and not args.n:
         h.close()
-        for key, fn in (("c2", alt_c2), ("c5_coupled", alt_c5)):
+        for key, fn in (("unstructured", alt_unstructured), ("c2", alt_c2), ("c5_coupled", alt_c5)):
             try:
                 ta = time.perf_counter()
                 res = fn(Handle, local_rank)

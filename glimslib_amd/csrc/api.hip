@@ -565,8 +565,9 @@ int glims_apply(glims_ctx* h, int which, const double* x, double* y, int reps, d
   return guarded(h, [&]() {
     GL_REQUIRE(h->is_setup, "glims_apply before glims_setup");
     GL_REQUIRE(x && y && reps >= 1, "bad arguments");
-    GL_REQUIRE(which >= 0 && which <= 7 && which != 6, "unknown operator");
+    GL_REQUIRE(which >= 0 && which <= 9 && which != 6, "unknown operator");
     if (which == 7) GL_REQUIRE(h->have_state, "the matrix-free product needs the state c (glims_set_state)");
+    if (which >= 8) h->pending = false;   // the sweep rewrites A(c), dinv and the Krylov work vectors
     const int d = h->dim;
     const bool blk_in = which == 3, blk_out = which == 3 || which == 4;
     if (blk_out) GL_REQUIRE(h->have_mech, "mechanics operators not assembled");
@@ -576,10 +577,19 @@ int glims_apply(glims_ctx* h, int which, const double* x, double* y, int reps, d
     to_device_perm(h, x, xin.p, blk_in ? d : 1);
     const bool saved_mload = h->have_mload;
     h->have_mload = false;
+    dvec<double> zero_b;
+    if (which == 8) zero_b.alloc_zero((size_t)h->n_nodes, h->st);
     GL_HIP(hipEventRecord(h->ev_a, h->st));
     for (int r = 0; r < reps; ++r) {
       if (which == 7)   // matrix-free A(c) x from the incidence lists (measurement only)
         gl_rd_matfree(h, h->c.p, xin.p, yout.p);
+      else if (which == 8)   // the assembly sweep at c = x with b = 0: y = -1/2 (A(x) + S) x; A(x) and its diagonal are left in place
+        gl_rd_assemble(h, xin.p, zero_b.p, nullptr, yout.p, h->cg_r2.p, h->partials.p);
+      else if (which == 9) {   // the quadratic-term pass with a = delta = x: y -= dt N(x) x per repetition
+        h->nq_ad.alloc((size_t)2 * h->n_nodes);
+        gl_pair_of(h, xin.p, h->nq_ad.p);
+        gl_rd_quad(h, h->nq_ad.p, yout.p, h->partials.p);
+      }
       else if (which == 5)   // A x with the fused dot product of the Krylov iteration (timing studies)
         gl_launch_spmv(h, h->st, h->pat.n_slices, nullptr, h->vA.p, xin.p, yout.p, nullptr, nullptr, xin.p,
                        h->partials.p, 0, nullptr, h->jac32 ? h->vA32.p : nullptr);

@@ -121,6 +121,24 @@ int gl_host_threads();   // OpenMP team the host phases may use (affinity mask, 
 void build_host_pattern(HostPattern& hp, int dim, int64_t n_nodes, int64_t n_own, int64_t n_cells,
                         const double* xyz, const int32_t* cells);
 
+// Everything a wave of the incidence-list kernels needs to know about its slice, in ONE 32-byte scalar load (the chain
+// slice list -> slice offsets -> incidence offsets -> window flag was four dependent memory round trips before a wave could
+// issue its first useful load)
+struct SliceDesc {
+  int64_t base, cbase;     // first entry / first incidence record of the slice
+  int32_t s;               // slice
+  int32_t len, clen;       // entries / incidence records per lane
+  int32_t ok;              // the slice has 16-bit column codes
+};
+
+// Slices of similar length that the incidence-list kernels launch together (kernels.hip, ensure_classes)
+struct SliceClass {
+  int cap = 0;                 // longest slice of the class, entries per lane (= LDS columns of its launches)
+  int n = 0, n_interior = 0;   // slices; the interior ones (no ghost column) come first
+  dvec<SliceDesc> desc;        // ... as descriptors (straight-line kernels)
+  dvec<int32_t> list;          // ... as plain slice ids (looped kernels, classes of more than 32 entries per row)
+};
+
 // Device-resident SELL-64 sparsity + incidence lists.
 struct DevPattern {
   int32_t n_slices = 0;
@@ -136,14 +154,19 @@ struct DevPattern {
   dvec<uint32_t> cslots;
   dvec<int32_t> celem;
   dvec<double> cw;                         // per-incidence reaction weight rho_T |T| d!/(d+3)!
-  dvec<uint32_t> cq;                       // [incidence][2] = (slot word, weight as float bits): k_rd_quad's 8-byte records
+  dvec<uint32_t> cs2;                      // slot word re-ordered for the hot kernels: byte 0 = the row's own (diagonal) slot, then the cell's other vertices
+  dvec<uint32_t> cq;                       // [incidence][2] = (re-ordered slot word, weight as float bits): the quadratic-term pass's 8-byte records
   dvec<int32_t> interior_slices, boundary_slices;
   int32_t n_interior = 0, n_boundary = 0;
   std::vector<int> bucket_cap;
   std::vector<int32_t> bucket_count;
   std::vector<int32_t> bucket_interior;
   std::vector<dvec<int32_t>*> bucket_slices;   // owned; released in ~DevPattern
-  ~DevPattern() { for (auto* b : bucket_slices) delete b; }
+  std::vector<SliceClass*> classes;            // launch classes of the incidence-list kernels (built on first use, kernels.hip)
+  ~DevPattern() {
+    for (auto* b : bucket_slices) delete b;
+    for (auto* c : classes) delete c;
+  }
   int64_t total_entries = 0, total_corners = 0;
 };
 
@@ -532,6 +555,7 @@ int gl_mailbox_selftest(glims_ctx* h);
 int gl_project(glims_ctx* h, double* rhs_dev /*[n_nodes], overwritten*/, double* x_dev /*[n_nodes]*/, double rtol);
 double gl_dot(glims_ctx* h, const double* a, const double* b, int64_t n, bool global = true);   // deterministic; host value
 void gl_allreduce_bulk(glims_ctx* h, double* dev, size_t n);   // in-place sum over ranks of a device vector (RCCL / transport)
+void gl_pair_of(glims_ctx* h, const double* u, float* ad /*[n_nodes][2]*/);   // (a, delta) = (u, u)
 void gl_apply_dirichlet_c(glims_ctx* h);                                     // c[fixed] = stored values (+ halo)
 void gl_block_dinv(glims_ctx* h);                                            // m_dinv of the constrained K_el
 

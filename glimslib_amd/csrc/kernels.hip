@@ -94,22 +94,49 @@ __global__ void k_egeo(int64_t n_cells, const double* __restrict__ xyz, const in
   }
 }
 
-// reaction weight of each (row, cell) incidence: rho_T |T| d!/(d+3)!
+// Per (row, cell) incidence: the reaction weight rho_T |T| d!/(d+3)! and the slot word RE-ORDERED for the hot kernels --
+// byte 0 = the slot of the row's own node in its row (the diagonal slot), bytes 1.. = the other vertices of the cell in their
+// cell order.  The sweep and the quadratic-term pass then need no "is this vertex the row's own" test: the own vertex's
+// contribution (the diagonal formula) goes to a register, the others (the off-diagonal formula) to their slots.  (`cslots`
+// keeps the cell's vertex order, which the static assembly needs to find the vertex's gradient.)  One wave per slice.
 template <int D>
-__global__ void k_corner_weights(int64_t n, const int32_t* __restrict__ celem, const uint8_t* __restrict__ label,
-                                 const double* __restrict__ egeo, const double* __restrict__ mat,
-                                 double* __restrict__ cw, const uint32_t* __restrict__ cslots,
-                                 uint2* __restrict__ cq) {
-  constexpr int GE = 1 + (D + 1) * D;
+__global__ __launch_bounds__(GL_WAVE) void k_corner_weights(const int64_t* __restrict__ cslice_ptr,
+                                                             const int32_t* __restrict__ celem,
+                                                             const uint8_t* __restrict__ label,
+                                                             const double* __restrict__ egeo, const double* __restrict__ mat,
+                                                             const uint8_t* __restrict__ diag_k,
+                                                             const uint32_t* __restrict__ cslots, double* __restrict__ cw,
+                                                             uint32_t* __restrict__ cs2, uint2* __restrict__ cq) {
+  constexpr int NV = D + 1, GE = 1 + NV * D;
   constexpr double fact = D == 2 ? 1.0 / 60.0 : 1.0 / 120.0;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int32_t e = celem[i];
-  const double w = e < 0 ? 0.0 : mat[1 * GL_MAX_LABELS + label[e]] * egeo[(int64_t)e * GE] * fact;
-  cw[i] = w;
-  // the same record for k_rd_quad: slot word + the weight in single precision, 8 B instead of 12 (the quadratic term it
-  // feeds is itself a 1e-3 correction)
-  cq[i] = make_uint2(cslots[i], __float_as_uint((float)w));
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const int64_t cbase = cslice_ptr[s];
+  const int clen = (int)((cslice_ptr[s + 1] - cbase) >> 6);
+  const uint32_t dk = diag_k[(int64_t)s * GL_WAVE + lane];
+  for (int q = 0; q < clen; ++q) {
+    const int64_t i = cbase + (int64_t)q * GL_WAVE + lane;
+    const int32_t e = celem[i];
+    const double w = e < 0 ? 0.0 : mat[1 * GL_MAX_LABELS + label[e]] * egeo[(int64_t)e * GE] * fact;
+    const uint32_t sl = cslots[i];
+    uint32_t out = dk, pos = 1;
+    if (e < 0) {
+      out = 0u;   // padding: weight 0, every slot 0
+    } else {
+#pragma unroll
+      for (int m = 0; m < NV; ++m) {
+        const uint32_t k = (sl >> (8 * m)) & 255u;
+        if (k != dk) {
+          out |= k << (8 * pos);
+          ++pos;
+        }
+      }
+    }
+    cw[i] = w;
+    cs2[i] = out;
+    // the same record for the quadratic-term pass: slot word + the weight in single precision, 8 B instead of 12 (the term it
+    // feeds is itself a 1e-3 correction)
+    cq[i] = make_uint2(out, __float_as_uint((float)w));
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -216,6 +243,13 @@ __device__ __forceinline__ void corner_batch(const double* __restrict__ wp, cons
   for (int j = 0; j < B; ++j) corner(wb[j], sb[j]);
 }
 
+// this lane's LDS accumulator += v as ONE LDS instruction (ds_add_f64, no return value): the same IEEE addition in the same
+// order as read - add - write (LDS instructions of a wave execute in order and every lane owns its column), but the
+// incidence loop no longer waits for an accumulator to come back before the next record can start
+__device__ __forceinline__ void lds_add(double* p, double v) {
+  (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 template <int NV, int NT, int CU, int CIDX, class AT = double>
 __global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
     const int32_t* __restrict__ slice_list, int64_t n_own, const int64_t* __restrict__ slice_ptr,
@@ -287,21 +321,23 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
     const double* wp = cw + cbase + lane;
     // phase 2: element contributions, CU incidence records in flight per lane (24 = a whole interior row of a
     // tetrahedral mesh; measured 4 -> 8 -> 24: 15.65 -> 15.3 -> 14.7 ms/step at C4)
+    // (records carry the row's own slot in byte 0, k_corner_weights: the diagonal accumulator is a register, the others are
+    //  bumped in LDS; the same expressions as in k_rd_assemble_s, so that both kernels produce the same bits)
+    const double ci4 = 4.0 * ci;
+    double acc_d = 0.0;
     auto corner = [&](double w, uint32_t slots) {
-      if (w == 0.0) return;   // padding, or a cell without proliferation: contributes nothing to N(c)
       int k[NV];
-      double cv[NV], av[NV], st = 0.0;
+      double cv[NV], st = ci;
 #pragma unroll
-      for (int m = 0; m < NV; ++m) {
+      for (int m = 1; m < NV; ++m) {
         k[m] = (int)((slots >> (8 * m)) & 255u);
         cv[m] = cn[k[m] * GL_WAVE + lane];
-        av[m] = acc[k[m] * GL_WAVE + lane];   // the NV slots of one cell are distinct: read all, then write all
       }
 #pragma unroll
-      for (int m = 0; m < NV; ++m) st += cv[m];
+      for (int m = 1; m < NV; ++m) st += cv[m];
+      acc_d += w * (ci4 + 2.0 * st);
 #pragma unroll
-      for (int m = 0; m < NV; ++m)
-        acc[k[m] * GL_WAVE + lane] = av[m] + ((k[m] == dk) ? w * (4.0 * ci + 2.0 * st) : w * (ci + cv[m] + st));
+      for (int m = 1; m < NV; ++m) lds_add(&acc[k[m] * GL_WAVE + lane], w * (ci + cv[m] + st));
     };
     {
       int q = 0;
@@ -322,7 +358,8 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
           S8[j] = NT ? __builtin_nontemporal_load(sv + (int64_t)(k + j) * GL_WAVE) : sv[(int64_t)(k + j) * GL_WAVE];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const double Av = S8[j] + two_dt * acc[(k + j) * GL_WAVE + lane];
+          const double a_k = (k + j == dk) ? acc_d : acc[(k + j) * GL_WAVE + lane];
+          const double Av = S8[j] + two_dt * a_k;
           if (NT) __builtin_nontemporal_store((AT)Av, av + (int64_t)(k + j) * GL_WAVE);
           else av[(int64_t)(k + j) * GL_WAVE] = (AT)Av;
           r += 0.5 * (Av + S8[j]) * cn[(k + j) * GL_WAVE + lane];
@@ -339,7 +376,8 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_assemble(
 #pragma unroll
         for (int j = 0; j < 8; ++j)
           if (k + j < len) {
-            const double Av = S8[j] + two_dt * acc[(k + j) * GL_WAVE + lane];
+            const double a_k = (k + j == dk) ? acc_d : acc[(k + j) * GL_WAVE + lane];
+            const double Av = S8[j] + two_dt * a_k;
             if (NT) __builtin_nontemporal_store((AT)Av, av + (int64_t)(k + j) * GL_WAVE);
             else av[(int64_t)(k + j) * GL_WAVE] = (AT)Av;
             r += 0.5 * (Av + S8[j]) * cn[(k + j) * GL_WAVE + lane];
@@ -417,25 +455,22 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_quad(
     gather([&](int k) { return cc[(int64_t)k * GL_WAVE]; });
   }
   const int dk = diag_k[row];
-  const float ai = ldsq[dk * GL_WAVE + lane].x;
+  const float2 own_v = ldsq[dk * GL_WAVE + lane];
+  const float ai = own_v.x, di = own_v.y;
   const uint2* rec = cq + cbase + lane;
-  double q = 0.0;
+  float q = 0.0f;
+  // (records carry the row's own slot in byte 0; same expressions as k_rd_quad_s)
   auto corner = [&](float w, uint32_t slots) {
-    if (w == 0.0f) return;
     float2 v[NV];
-    int k[NV];
-    float sa = 0.0f, t = 0.0f;
+    float sa = ai;
 #pragma unroll
-    for (int m = 0; m < NV; ++m) {
-      k[m] = (int)((slots >> (8 * m)) & 255u);
-      v[m] = ldsq[k[m] * GL_WAVE + lane];
-    }
+    for (int m = 1; m < NV; ++m) v[m] = ldsq[(int)((slots >> (8 * m)) & 255u) * GL_WAVE + lane];
 #pragma unroll
-    for (int m = 0; m < NV; ++m) sa += v[m].x;
-    // row i of N(a) restricted to this cell, applied to delta: N_ii = w (4 a_i + 2 s), N_ij = w (a_i + a_j + s)
+    for (int m = 1; m < NV; ++m) sa += v[m].x;
+    float t = (4.0f * ai + 2.0f * sa) * di;
 #pragma unroll
-    for (int m = 0; m < NV; ++m) t += ((k[m] == dk) ? (4.0f * ai + 2.0f * sa) : (ai + v[m].x + sa)) * v[m].y;
-    q += (double)(w * t);
+    for (int m = 1; m < NV; ++m) t += (ai + v[m].x + sa) * v[m].y;
+    q += w * t;
   };
   for (int qq = 0; qq < clen; qq += CU) {   // CU records in flight (index clamped past the end: padding has weight 0)
     uint2 rb[CU];
@@ -447,7 +482,7 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_quad(
   }
   double rr = 0.0;
   if (row < n_own) {
-    const double rn = (fixed && fixed[row]) ? 0.0 : r[row] - dt * q;
+    const double rn = (fixed && fixed[row]) ? 0.0 : r[row] - dt * (double)q;
     r[row] = rn;
     rr = rn * rn;
   }
@@ -456,6 +491,251 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_quad(
     partials[(size_t)s * 2 + 0] = rr;
     partials[(size_t)s * 2 + 1] = 0.0;
   }
+}
+
+
+// The same pass with the wave's memory round trips cut from ~13 to 4.  A wave of the kernel above walks a chain of dependent
+// loads -- slice list, slice offsets, window flag, window bases, then per batch of 8 entries codes -> gather, incidence
+// offsets, incidence records, r -- and lives ~20 us however little the memory system has to do; the kernel's rate is
+// (resident waves) / (that lifetime), 2.4 TB/s on a general mesh.  Here: (1) one 32-byte scalar load of the slice's
+// descriptor; (2) EVERY stream that depends on it alone is requested at once -- the first RB incidence records, r, the
+// Dirichlet flag, the diagonal slot, window bases and all column codes of the row (CAP of them, compile-time: straight-line
+// code, indices clamped instead of predicated so that no branch separates the loads); (3) all gathers of the row; (4) records
+// beyond RB.  Records carry the row's own slot in byte 0 (k_corner_weights), so the own vertex's term needs neither an LDS
+// read nor a test; the row sum is accumulated in single precision like its terms.
+// Uniform base + lane offset: the compiler then addresses every stream as SGPR base + 32-bit VGPR offset.
+#define GL_STREAM(ptr, base, k) ((ptr) + (base) + (int64_t)(k) * GL_WAVE)[lane_u]
+template <int NV, int CAP, int RB, int CIDX>
+__global__ __launch_bounds__(GL_WAVE) void k_rd_quad_s(
+    const SliceDesc* __restrict__ desc, int64_t n_own, const int32_t* __restrict__ cols,
+    const uint16_t* __restrict__ cols16, const int32_t* __restrict__ win_base, const uint2* __restrict__ cq,
+    const uint8_t* __restrict__ diag_k, const float2* __restrict__ ad, double* __restrict__ r,
+    const uint8_t* __restrict__ fixed, double dt, double* __restrict__ partials, int ldscap, int remap) {
+  extern __shared__ float2 ldsq[];   // [ldscap][64], ldscap <= CAP = the longest slice of the launch
+  const int lane = threadIdx.x;
+  const uint32_t lane_u = threadIdx.x;
+  const SliceDesc d = desc[remap > 1 ? xcd_chunk_remap(blockIdx.x, gridDim.x, 4 * remap) : blockIdx.x];
+  const int s = d.s, len = d.len, clen = d.clen;
+  const int64_t row = (int64_t)s * GL_WAVE + lane;
+  // ---- round trip 2: everything that needs the descriptor only.  Program order = issue order: the column codes come
+  // LAST, because the next round trip waits for them -- and with them, the counter being in order, for everything before
+  uint2 rb[RB];
+#pragma unroll
+  for (int j = 0; j < RB; ++j) rb[j] = GL_STREAM(cq, d.cbase, min(j, clen - 1));
+  const bool own = row < n_own;
+  const int64_t rowc = own ? row : n_own - 1;   // (padding rows of the last slice read a valid address, nothing is stored)
+  const double r_old = r[rowc];
+  uint32_t fxv = 0;
+  if (fixed) fxv = fixed[rowc];
+  const int dk = diag_k[row];
+  int32_t cu[CAP];
+  const bool comp = CIDX && d.ok;   // wave-uniform
+  int32_t wb = 0;
+  if (comp) {
+    wb = win_base[(int64_t)s * GL_N_WIN + (lane & (GL_N_WIN - 1))];
+#pragma unroll
+    for (int k = 0; k < CAP; ++k) cu[k] = (int32_t)GL_STREAM(cols16, d.base, min(k, len - 1));
+  } else {
+#pragma unroll
+    for (int k = 0; k < CAP; ++k) cu[k] = GL_STREAM(cols, d.base, min(k, len - 1));
+  }
+  // ---- round trip 3: the row's neighbour values
+  if (comp) {
+#pragma unroll
+    for (int k = 0; k < CAP; ++k) cu[k] = decode_col((uint32_t)cu[k], wb);
+  }
+  float2 v8[CAP];
+#pragma unroll
+  for (int k = 0; k < CAP; ++k) v8[k] = ad[cu[k]];
+#pragma unroll
+  for (int k = 0; k < CAP; ++k)
+    if (k < ldscap) ldsq[k * GL_WAVE + lane] = v8[k];   // slots >= len hold a copy of the last entry, never read
+  const float2 own_v = ldsq[dk * GL_WAVE + lane];
+  const float ai = own_v.x, di = own_v.y;
+  float q = 0.0f;
+  // Row i of N(a) restricted to the cell, applied to delta: N_ii = w (4 a_i + 2 s), N_ij = w (a_i + a_j + s), s = sum of a
+  // over the cell.  Padding records (shorter rows of the slice) have weight 0 and slots 0.
+  auto corner = [&](float w, uint32_t slots) {
+    float2 v[NV];
+    float sa = ai;
+#pragma unroll
+    for (int m = 1; m < NV; ++m) v[m] = ldsq[(int)((slots >> (8 * m)) & 255u) * GL_WAVE + lane];
+#pragma unroll
+    for (int m = 1; m < NV; ++m) sa += v[m].x;
+    float t = (4.0f * ai + 2.0f * sa) * di;
+#pragma unroll
+    for (int m = 1; m < NV; ++m) t += (ai + v[m].x + sa) * v[m].y;
+    q += w * t;
+  };
+  for (int qq = 0; qq < clen; qq += RB) {
+    if (qq > 0) {   // ---- round trip 4 (rows with more than RB incidences only)
+#pragma unroll
+      for (int j = 0; j < RB; ++j) rb[j] = GL_STREAM(cq, d.cbase, min(qq + j, clen - 1));
+    }
+#pragma unroll
+    for (int j = 0; j < RB; ++j)
+      if (qq + j < clen) corner(__uint_as_float(rb[j].y), rb[j].x);   // (wave-uniform)
+  }
+  double rr = 0.0;
+  asm volatile("" : "+v"(fxv));   // the flag is looked at HERE, not where it was requested (a wait for it up there would
+                                  // serialise the whole second round trip)
+  if (own) {
+    const double rn = fxv ? 0.0 : r_old - dt * (double)q;
+    r[row] = rn;
+    rr = rn * rn;
+  }
+  rr = wave_sum(rr);
+  if (lane == 0) {
+    partials[(size_t)s * 2 + 0] = rr;
+    partials[(size_t)s * 2 + 1] = 0.0;
+  }
+}
+
+// The assembly sweep in the same shape: one descriptor load; then the first RB incidence records, right-hand side(s), flags
+// and column codes; then the row's gathers; then its entries of S (in flight while the records are worked through).  The
+// diagonal accumulator lives in a register, the off-diagonal ones are bumped with ds_add_f64 (one LDS instruction per
+// contribution, no read - add - write round trip): a record costs 3 LDS reads + 3 LDS adds (NV = 4) instead of 8 + 4.
+// Every term is added to its accumulator in the same order as in k_rd_assemble.
+template <int NV, int CAP, int RB, int CIDX, class AT>
+__global__ __launch_bounds__(GL_WAVE) void k_rd_assemble_s(
+    const SliceDesc* __restrict__ desc, int64_t n_own, const int32_t* __restrict__ cols,
+    const uint16_t* __restrict__ cols16, const int32_t* __restrict__ win_base, const uint32_t* __restrict__ cs2,
+    const double* __restrict__ cw, const uint8_t* __restrict__ diag_k, const double* __restrict__ vS,
+    AT* __restrict__ vA, const double* __restrict__ c, const double* __restrict__ b, const double* __restrict__ b2,
+    double* __restrict__ r_out, double* __restrict__ r2_out, double* __restrict__ dinv,
+    const uint8_t* __restrict__ fixed, double two_dt, double* __restrict__ partials, int ldscap, int remap) {
+  extern __shared__ double lds[];
+  double* acc = lds;                             // [ldscap][64], ldscap <= CAP = the longest slice of the launch
+  double* cn = lds + (size_t)ldscap * GL_WAVE;   // [ldscap][64]
+  const int lane = threadIdx.x;
+  const uint32_t lane_u = threadIdx.x;
+  const SliceDesc d = desc[remap > 1 ? xcd_chunk_remap(blockIdx.x, gridDim.x, 4 * remap) : blockIdx.x];
+  const int s = d.s, len = d.len, clen = d.clen;
+  const int64_t row = (int64_t)s * GL_WAVE + lane;
+  // ---- round trip 2 (program order = issue order; the column codes last, the next round trip waits for them)
+  double wb_[RB];
+  uint32_t sb_[RB];
+#pragma unroll
+  for (int j = 0; j < RB; ++j) {
+    wb_[j] = GL_STREAM(cw, d.cbase, min(j, clen - 1));
+    sb_[j] = GL_STREAM(cs2, d.cbase, min(j, clen - 1));
+  }
+  const bool own = row < n_own;
+  const int64_t rowc = own ? row : n_own - 1;
+  const double b_row = b[rowc];
+  double b2_row = 0.0;
+  if (b2) b2_row = b2[rowc];
+  uint32_t fxv = 0;
+  if (fixed) fxv = fixed[rowc];
+  const int dk = diag_k[row];
+  int32_t cu[CAP];
+  const bool comp = CIDX && d.ok;   // wave-uniform
+  int32_t wb = 0;
+  if (comp) {
+    wb = win_base[(int64_t)s * GL_N_WIN + (lane & (GL_N_WIN - 1))];
+#pragma unroll
+    for (int k = 0; k < CAP; ++k) cu[k] = (int32_t)GL_STREAM(cols16, d.base, min(k, len - 1));
+  } else {
+#pragma unroll
+    for (int k = 0; k < CAP; ++k) cu[k] = GL_STREAM(cols, d.base, min(k, len - 1));
+  }
+  // ---- round trip 3: the row's neighbour values of c
+  if (comp) {
+#pragma unroll
+    for (int k = 0; k < CAP; ++k) cu[k] = decode_col((uint32_t)cu[k], wb);
+  }
+  {
+    double x8[CAP];
+#pragma unroll
+    for (int k = 0; k < CAP; ++k) x8[k] = c[cu[k]];
+#pragma unroll
+    for (int k = 0; k < CAP; ++k)
+      if (k < ldscap) {
+        cn[k * GL_WAVE + lane] = x8[k];   // slots >= len hold a copy of the last entry, never read
+        acc[k * GL_WAVE + lane] = 0.0;
+      }
+  }
+  // ---- the row's entries of S: requested now, needed after the records
+  double S8[CAP];
+#pragma unroll
+  for (int k = 0; k < CAP; ++k) S8[k] = GL_STREAM(vS, d.base, min(k, len - 1));
+  const double ci = cn[dk * GL_WAVE + lane];
+  const double ci4 = 4.0 * ci;
+  double acc_d = 0.0;
+  auto corner = [&](double w, uint32_t slots) {
+    int k[NV];
+    double cv[NV], st = ci;
+#pragma unroll
+    for (int m = 1; m < NV; ++m) {
+      k[m] = (int)((slots >> (8 * m)) & 255u);
+      cv[m] = cn[k[m] * GL_WAVE + lane];
+    }
+#pragma unroll
+    for (int m = 1; m < NV; ++m) st += cv[m];
+    acc_d += w * (ci4 + 2.0 * st);
+#pragma unroll
+    for (int m = 1; m < NV; ++m) lds_add(&acc[k[m] * GL_WAVE + lane], w * (ci + cv[m] + st));
+  };
+  for (int qq = 0; qq < clen; qq += RB) {
+    if (qq > 0) {   // rows with more than RB incidences
+#pragma unroll
+      for (int j = 0; j < RB; ++j) {
+        wb_[j] = GL_STREAM(cw, d.cbase, min(qq + j, clen - 1));
+        sb_[j] = GL_STREAM(cs2, d.cbase, min(qq + j, clen - 1));
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < RB; ++j)
+      if (qq + j < clen) corner(wb_[j], sb_[j]);   // (wave-uniform; a padding record of a shorter row has weight 0 and slots 0)
+  }
+  // phase 3: A = S + 2 dt N(c), residual 1/2 (A + S) c, diagonal
+  double r = 0.0, dg = 1.0;
+#pragma unroll
+  for (int k = 0; k < CAP; ++k)
+    if (k < len) {
+      const double a_k = (k == dk) ? acc_d : acc[k * GL_WAVE + lane];
+      const double Av = S8[k] + two_dt * a_k;
+      GL_STREAM(vA, d.base, k) = (AT)Av;
+      r += 0.5 * (Av + S8[k]) * cn[k * GL_WAVE + lane];
+      if (k == dk) dg = Av;
+    }
+  double rr = 0.0, rr2 = 0.0;
+  asm volatile("" : "+v"(fxv));
+  if (own) {
+    const bool fx = fxv != 0;
+    const double res = fx ? 0.0 : b_row - r;
+    r_out[row] = res;
+    dinv[row] = fx ? 1.0 : 1.0 / dg;
+    rr = res * res;
+    if (b2) {
+      const double res2 = fx ? 0.0 : b2_row - r;
+      r2_out[row] = res2;
+      rr2 = res2 * res2;
+    }
+  }
+  rr = wave_sum(rr);
+  rr2 = wave_sum(rr2);
+  if (lane == 0) {
+    partials[(size_t)s * 2 + 0] = rr;
+    partials[(size_t)s * 2 + 1] = rr2;
+  }
+}
+#undef GL_STREAM
+
+__global__ void k_make_desc(int n, const int32_t* __restrict__ list, const int64_t* __restrict__ slice_ptr,
+                            const int64_t* __restrict__ cslice_ptr, const uint8_t* __restrict__ win_ok,
+                            SliceDesc* __restrict__ desc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int s = list[i];
+  SliceDesc d;
+  d.base = slice_ptr[s];
+  d.cbase = cslice_ptr[s];
+  d.s = s;
+  d.len = (int)((slice_ptr[s + 1] - d.base) >> 6);
+  d.clen = (int)((cslice_ptr[s + 1] - d.cbase) >> 6);
+  d.ok = win_ok[s];
+  desc[i] = d;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -501,23 +781,23 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_matfree(
   }
   const int dk = diag_k[row];
   const double ci = cn[dk * GL_WAVE + lane];
-  const uint32_t* sl = cslots + cbase + lane;
+  const uint32_t* sl = cslots + cbase + lane;   // (the re-ordered slot words: the row's own slot in byte 0)
   const double* wp = cw + cbase + lane;
-  auto corner = [&](double w, uint32_t slots) {
-    if (w == 0.0) return;
+  const double ci4 = 4.0 * ci;
+  double acc_d = 0.0;
+  auto corner = [&](double w, uint32_t slots) {   // the sweep's expressions, so that the two products agree bit for bit
     int k[NV];
-    double cv[NV], av[NV], st = 0.0;
+    double cv[NV], st = ci;
 #pragma unroll
-    for (int m = 0; m < NV; ++m) {
+    for (int m = 1; m < NV; ++m) {
       k[m] = (int)((slots >> (8 * m)) & 255u);
       cv[m] = cn[k[m] * GL_WAVE + lane];
-      av[m] = acc[k[m] * GL_WAVE + lane];
     }
 #pragma unroll
-    for (int m = 0; m < NV; ++m) st += cv[m];
+    for (int m = 1; m < NV; ++m) st += cv[m];
+    acc_d += w * (ci4 + 2.0 * st);
 #pragma unroll
-    for (int m = 0; m < NV; ++m)
-      acc[k[m] * GL_WAVE + lane] = av[m] + ((k[m] == dk) ? w * (4.0 * ci + 2.0 * st) : w * (ci + cv[m] + st));
+    for (int m = 1; m < NV; ++m) lds_add(&acc[k[m] * GL_WAVE + lane], w * (ci + cv[m] + st));
   };
   {
     int q = 0;
@@ -533,7 +813,7 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_matfree(
     for (int j = 0; j < 8; ++j) S8[j] = sv[(int64_t)min(k + j, len - 1) * GL_WAVE];
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-      if (k + j < len) r += (S8[j] + two_dt * acc[(k + j) * GL_WAVE + lane]) * xn[(k + j) * GL_WAVE + lane];
+      if (k + j < len) r += (S8[j] + two_dt * ((k + j == dk) ? acc_d : acc[(k + j) * GL_WAVE + lane])) * xn[(k + j) * GL_WAVE + lane];
   }
   if (row < n_own) y[row] = r;
 }
@@ -1022,14 +1302,11 @@ static void assemble_static_t(glims_ctx* h, int with_mechanics) {
     GL_HIP(hipGetLastError());
   }
   p.cw.alloc((size_t)p.total_corners);
+  p.cs2.alloc((size_t)p.total_corners);
   p.cq.alloc((size_t)2 * p.total_corners);
-  {
-    const int bs = 256;
-    const unsigned grid = (unsigned)((p.total_corners + bs - 1) / bs);
-    hipLaunchKernelGGL(k_corner_weights<D>, dim3(grid), dim3(bs), 0, h->st, p.total_corners, p.celem.p, h->label.p,
-                       h->egeo.p, h->mat.p, p.cw.p, p.cslots.p, (uint2*)p.cq.p);
-    GL_HIP(hipGetLastError());
-  }
+  hipLaunchKernelGGL(k_corner_weights<D>, dim3(p.n_slices), dim3(GL_WAVE), 0, h->st, p.cslice_ptr.p, p.celem.p, h->label.p,
+                     h->egeo.p, h->mat.p, p.diag_k.p, p.cslots.p, p.cw.p, p.cs2.p, (uint2*)p.cq.p);
+  GL_HIP(hipGetLastError());
   if (with_mechanics) {
     h->vKel.alloc(ne * D * D);
     h->vG.alloc(ne * D);
@@ -1057,65 +1334,160 @@ void gl_assemble_static(glims_ctx* h, int with_mechanics) {
 
 int gl_rd_grid(const glims_ctx* h) { return h->pat.n_slices; }
 
+// ---- slice classes ------------------------------------------------------------------------------------------------------
+// The incidence-list kernels are launched per class of slice length: their LDS footprint (16 B x length per row for the
+// sweep) decides how many waves a CU holds, so the (few) long rows of an unstructured mesh must not size it for everybody;
+// and the straight-line kernels unroll to a compile-time bound (16 / 20 / 24 / 32 entries; classes of longer slices take the
+// looped kernels).  Built once per handle from the symbolic phase's length classes: a class of fewer than 1024 slices (less
+// than half a round of waves: it costs a launch tail of one wave lifetime, ~14 us, for nothing) joins the next shorter one
+// unless that would cost the shorter class a resident wave per CU.
+static int sweep_waves_per_cu(int cap) { return std::max(1, std::min(16, 160 / std::max(1, cap))); }   // 160 KB LDS, cap KB per wave
+
+static void ensure_classes(glims_ctx* h) {
+  DevPattern& p = h->pat;
+  if (!p.classes.empty() || p.bucket_cap.empty()) return;
+  struct HostClass {
+    int cap;
+    std::vector<int32_t> interior, boundary;
+  };
+  std::vector<HostClass> hc;
+  for (size_t bk = 0; bk < p.bucket_cap.size(); ++bk) {
+    const int n = p.bucket_count[bk], ni = p.bucket_interior[bk];
+    if (n <= 0) continue;
+    std::vector<int32_t> all((size_t)n);
+    GL_HIP(hipMemcpyAsync(all.data(), p.bucket_slices[bk]->p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, h->st));
+    GL_HIP(hipStreamSynchronize(h->st));
+    HostClass c;
+    c.cap = p.bucket_cap[bk];
+    c.interior.assign(all.begin(), all.begin() + ni);
+    c.boundary.assign(all.begin() + ni, all.end());
+    hc.push_back(std::move(c));
+  }
+  for (size_t i = hc.size(); i-- > 1;) {
+    HostClass &hi = hc[i], &lo = hc[i - 1];
+    const size_t n_hi = hi.interior.size() + hi.boundary.size(), n_lo = lo.interior.size() + lo.boundary.size();
+    const bool same_kind = (hi.cap <= 32) == (lo.cap <= 32);
+    const bool cheap = sweep_waves_per_cu(hi.cap) >= sweep_waves_per_cu(lo.cap) - (n_lo < 4096 ? 1 : 0);
+    if (n_hi >= 1024 || !same_kind || !cheap) continue;
+    lo.cap = std::max(lo.cap, hi.cap);
+    lo.interior.insert(lo.interior.end(), hi.interior.begin(), hi.interior.end());
+    lo.boundary.insert(lo.boundary.end(), hi.boundary.begin(), hi.boundary.end());
+    hc.erase(hc.begin() + (long)i);
+  }
+  for (const HostClass& c : hc) {
+    auto* sc = new SliceClass();
+    sc->cap = c.cap;
+    sc->n_interior = (int)c.interior.size();
+    sc->n = (int)(c.interior.size() + c.boundary.size());
+    std::vector<int32_t> all(c.interior);
+    all.insert(all.end(), c.boundary.begin(), c.boundary.end());
+    sc->list.upload(all, h->st);
+    sc->desc.alloc((size_t)sc->n);
+    hipLaunchKernelGGL(k_make_desc, dim3((unsigned)((sc->n + 255) / 256)), dim3(256), 0, h->st, sc->n, sc->list.p,
+                       p.slice_ptr.p, p.cslice_ptr.p, p.win_ok.p, sc->desc.p);
+    GL_HIP(hipGetLastError());
+    GL_HIP(hipStreamSynchronize(h->st));   // `all` is a stack object
+    p.classes.push_back(sc);
+    if (getenv("GLIMS_VERBOSE"))
+      fprintf(stderr, "glims slice class: %d slices (%d interior) of at most %d entries: %s kernels, %d waves per CU in the sweep\n",
+              sc->n, sc->n_interior, sc->cap, sc->cap <= 32 ? "straight-line" : "looped", sweep_waves_per_cu(sc->cap));
+  }
+}
+
+// what a launch of class `sc` covers for the given part of the mesh (all / interior / boundary slices)
+struct ClassLaunch {
+  int grid;
+  const SliceDesc* desc;
+  const int32_t* list;
+};
+static ClassLaunch class_launch(const SliceClass& sc, int part) {
+  const int n_int = sc.n_interior;
+  const int off = part == GL_PART_BOUNDARY ? n_int : 0;
+  return {part == GL_PART_ALL ? sc.n : part == GL_PART_INTERIOR ? n_int : sc.n - n_int, sc.desc.p + off, sc.list.p + off};
+}
+
 // Assembles A(c) and the Newton right-hand side(s).  partials: [gl_rd_grid][2] = (|b - ..|^2, |b2 - ..|^2).
+// Kernel configuration (measured): classes of at most 32 entries per row take the straight-line kernel
+// (k_rd_assemble_s), longer ones the looped one with 24 incidence records in flight per lane; one slice per block dealt to
+// the XCDs in chunks; cached (not non-temporal) streams.  AT: the Newton Jacobian is written in fp64 or
+// (GLIMS_FLAG_FP32_JACOBIAN) fp32.
 void gl_rd_assemble(glims_ctx* h, const double* c, const double* b, const double* b2, double* r_out, double* r2_out,
                     double* partials, int part) {
+  ensure_classes(h);
   const DevPattern& p = h->pat;
   const uint8_t* fx = h->have_fixed_c ? h->fixed_c.p : nullptr;
-  // Kernel configuration (measured best): cached (not non-temporal) streams, 24 incidence records
-  // in flight per lane, one slice per block dealt to the XCDs in chunks.  AT: the Newton Jacobian is written in fp64 or
-  // (GLIMS_FLAG_FP32_JACOBIAN) fp32.
 #define GL_RD(NV, CIDX, AT, APTR)                                                                                   \
   do {                                                                                                             \
     set_lds(k_rd_assemble<NV, 0, 24, CIDX, AT>, lds);                                                              \
-    hipLaunchKernelGGL((k_rd_assemble<NV, 0, 24, CIDX, AT>), dim3(grid), dim3(GL_WAVE), lds, h->st, list,           \
+    hipLaunchKernelGGL((k_rd_assemble<NV, 0, 24, CIDX, AT>), dim3(cl.grid), dim3(GL_WAVE), lds, h->st, cl.list,     \
                        h->n_own, p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, p.win_ok.p, p.cslice_ptr.p,     \
-                       p.cslots.p, p.cw.p, p.diag_k.p, h->vS.p, APTR, c, b, b2, r_out, r2_out, h->dinv.p, fx,        \
+                       p.cs2.p, p.cw.p, p.diag_k.p, h->vS.p, APTR, c, b, b2, r_out, r2_out, h->dinv.p, fx,           \
                        2.0 * h->opt.dt, partials, cap, GL_XCD_CHUNK);                                              \
+  } while (0)
+#define GL_RDS3(NV, CAP, RB, CIDX, AT, APTR)                                                                        \
+  do {                                                                                                             \
+    set_lds(k_rd_assemble_s<NV, CAP, RB, CIDX, AT>, lds);                                                          \
+    hipLaunchKernelGGL((k_rd_assemble_s<NV, CAP, RB, CIDX, AT>), dim3(cl.grid), dim3(GL_WAVE), lds, h->st, cl.desc,  \
+                       h->n_own, p.cols.p, p.cols16.p, p.win_base.p, p.cs2.p, p.cw.p, p.diag_k.p, h->vS.p, APTR, c,  \
+                       b, b2, r_out, r2_out, h->dinv.p, fx, 2.0 * h->opt.dt, partials, cap, GL_XCD_CHUNK);          \
+  } while (0)
+  // (incidence records of the first round trip: an interior row of a tetrahedral mesh with n entries has 2 n - 6 of them)
+#define GL_RDS2(NV, CIDX, AT, APTR)                                                                                 \
+  do {                                                                                                             \
+    if (cap <= 16) GL_RDS3(NV, 16, 26, CIDX, AT, APTR);                                                            \
+    else if (cap <= 20) GL_RDS3(NV, 20, 24, CIDX, AT, APTR);                                                       \
+    else if (cap <= 24) GL_RDS3(NV, 24, 24, CIDX, AT, APTR);                                                       \
+    else if (cap <= 32) GL_RDS3(NV, 32, 24, CIDX, AT, APTR);                                                       \
+    else GL_RD(NV, CIDX, AT, APTR);                                                                                \
   } while (0)
 #define GL_RDV(NV)                                                                                                  \
   do {                                                                                                             \
-    if (h->jac32 && h->use_idx16) GL_RD(NV, 1, float, h->vA32.p);                                                  \
-    else if (h->jac32) GL_RD(NV, 0, float, h->vA32.p);                                                             \
-    else if (h->use_idx16) GL_RD(NV, 1, double, h->vA.p);                                                          \
-    else GL_RD(NV, 0, double, h->vA.p);                                                                            \
+    if (h->jac32 && h->use_idx16) GL_RDS2(NV, 1, float, h->vA32.p);                                                \
+    else if (h->jac32) GL_RDS2(NV, 0, float, h->vA32.p);                                                           \
+    else if (h->use_idx16) GL_RDS2(NV, 1, double, h->vA.p);                                                        \
+    else GL_RDS2(NV, 0, double, h->vA.p);                                                                          \
   } while (0)
-  // one launch per row-length class: the LDS footprint (2 * cap * 512 B per wave) decides the occupancy, so the
-  // (few) long rows of an unstructured mesh must not size it for everybody
-  for (size_t bk = 0; bk < p.bucket_cap.size(); ++bk) {
-    const int cap = p.bucket_cap[bk];
-    const int n_int = p.bucket_interior[bk];
-    const int grid = part == GL_PART_ALL ? p.bucket_count[bk]
-                     : part == GL_PART_INTERIOR ? n_int : p.bucket_count[bk] - n_int;
-    if (grid <= 0) continue;
-    const int32_t* list = p.bucket_slices[bk]->p + (part == GL_PART_BOUNDARY ? n_int : 0);
+  for (const SliceClass* sc : p.classes) {
+    const ClassLaunch cl = class_launch(*sc, part);
+    if (cl.grid <= 0) continue;
+    const int cap = sc->cap;
     const size_t lds = (size_t)2 * cap * GL_WAVE * sizeof(double);
     if (h->nv == 3) GL_RDV(3); else GL_RDV(4);
   }
 #undef GL_RDV
+#undef GL_RDS2
+#undef GL_RDS3
 #undef GL_RD
   GL_HIP(hipGetLastError());
 }
 
-// r <- r - dt N(a) delta and the partial sums of |r|^2 (k_rd_quad); same launch shape as the sweep
+// r <- r - dt N(a) delta and the partial sums of |r|^2; same launch shape as the sweep
 void gl_rd_quad(glims_ctx* h, const float* ad, double* r, double* partials, int part) {
+  ensure_classes(h);
   const DevPattern& p = h->pat;
   const uint8_t* fx = h->have_fixed_c ? h->fixed_c.p : nullptr;
+#define GL_RQS(NV, CAP, RB, CIDX)                                                                                    \
+  hipLaunchKernelGGL((k_rd_quad_s<NV, CAP, RB, CIDX>), dim3(cl.grid), dim3(GL_WAVE), lds, h->st, cl.desc, h->n_own,   \
+                     p.cols.p, p.cols16.p, p.win_base.p, (const uint2*)p.cq.p, p.diag_k.p, (const float2*)ad, r, fx,  \
+                     h->opt.dt, partials, cap, GL_XCD_CHUNK)
 #define GL_RQ(NV, CIDX)                                                                                             \
   do {                                                                                                             \
-    set_lds(k_rd_quad<NV, 24, CIDX>, lds);                                                                         \
-    hipLaunchKernelGGL((k_rd_quad<NV, 24, CIDX>), dim3(grid), dim3(GL_WAVE), lds, h->st, list, h->n_own,            \
-                       p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, p.win_ok.p, p.cslice_ptr.p,              \
-                       (const uint2*)p.cq.p, p.diag_k.p, (const float2*)ad, r, fx, h->opt.dt, partials, cap,        \
-                       GL_XCD_CHUNK);                                                                              \
+    if (cap <= 16) GL_RQS(NV, 16, 28, CIDX);                                                                       \
+    else if (cap <= 20) GL_RQS(NV, 20, 32, CIDX);                                                                  \
+    else if (cap <= 24) GL_RQS(NV, 24, 32, CIDX);                                                                  \
+    else if (cap <= 32) GL_RQS(NV, 32, 32, CIDX);                                                                  \
+    else {                                                                                                         \
+      set_lds(k_rd_quad<NV, 24, CIDX>, lds);                                                                       \
+      hipLaunchKernelGGL((k_rd_quad<NV, 24, CIDX>), dim3(cl.grid), dim3(GL_WAVE), lds, h->st, cl.list, h->n_own,     \
+                         p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, p.win_ok.p, p.cslice_ptr.p,            \
+                         (const uint2*)p.cq.p, p.diag_k.p, (const float2*)ad, r, fx, h->opt.dt, partials, cap,      \
+                         GL_XCD_CHUNK);                                                                            \
+    }                                                                                                              \
   } while (0)
-  for (size_t bk = 0; bk < p.bucket_cap.size(); ++bk) {
-    const int cap = p.bucket_cap[bk];
-    const int n_int = p.bucket_interior[bk];
-    const int grid = part == GL_PART_ALL ? p.bucket_count[bk]
-                     : part == GL_PART_INTERIOR ? n_int : p.bucket_count[bk] - n_int;
-    if (grid <= 0) continue;
-    const int32_t* list = p.bucket_slices[bk]->p + (part == GL_PART_BOUNDARY ? n_int : 0);
+  for (const SliceClass* sc : p.classes) {
+    const ClassLaunch cl = class_launch(*sc, part);
+    if (cl.grid <= 0) continue;
+    const int cap = sc->cap;
     const size_t lds = (size_t)cap * GL_WAVE * sizeof(float2);
     if (h->nv == 3) {
       if (h->use_idx16) GL_RQ(3, 1); else GL_RQ(3, 0);
@@ -1124,6 +1496,7 @@ void gl_rd_quad(glims_ctx* h, const float* ad, double* r, double* partials, int 
     }
   }
 #undef GL_RQ
+#undef GL_RQS
   GL_HIP(hipGetLastError());
 }
 
@@ -1341,22 +1714,20 @@ void gl_make_smoother_copy(glims_ctx* h, MgHierarchy& mg, bool half, bool exchan
 
 // y = (S + 2 dt N(c)) x without the assembled Jacobian (measurement only, see k_rd_matfree)
 void gl_rd_matfree(glims_ctx* h, const double* c, const double* x, double* y) {
+  ensure_classes(h);
   const DevPattern& p = h->pat;
-  for (size_t bk = 0; bk < p.bucket_cap.size(); ++bk) {
-    const int cap = p.bucket_cap[bk];
-    const int grid = p.bucket_count[bk];
-    if (grid <= 0) continue;
+  for (const SliceClass* sc : p.classes) {
+    if (sc->n <= 0) continue;
+    const int cap = sc->cap;
     const size_t lds = (size_t)3 * cap * GL_WAVE * sizeof(double);
     if (h->nv == 3) {
       set_lds(k_rd_matfree<3>, lds);
-      hipLaunchKernelGGL(k_rd_matfree<3>, dim3(grid), dim3(GL_WAVE), lds, h->st, p.bucket_slices[bk]->p, h->n_own,
-                         p.slice_ptr.p, p.cols.p, p.cslice_ptr.p, p.cslots.p, p.cw.p, p.diag_k.p, h->vS.p, c, x, y,
-                         2.0 * h->opt.dt, cap);
+      hipLaunchKernelGGL(k_rd_matfree<3>, dim3(sc->n), dim3(GL_WAVE), lds, h->st, sc->list.p, h->n_own, p.slice_ptr.p,
+                         p.cols.p, p.cslice_ptr.p, p.cs2.p, p.cw.p, p.diag_k.p, h->vS.p, c, x, y, 2.0 * h->opt.dt, cap);
     } else {
       set_lds(k_rd_matfree<4>, lds);
-      hipLaunchKernelGGL(k_rd_matfree<4>, dim3(grid), dim3(GL_WAVE), lds, h->st, p.bucket_slices[bk]->p, h->n_own,
-                         p.slice_ptr.p, p.cols.p, p.cslice_ptr.p, p.cslots.p, p.cw.p, p.diag_k.p, h->vS.p, c, x, y,
-                         2.0 * h->opt.dt, cap);
+      hipLaunchKernelGGL(k_rd_matfree<4>, dim3(sc->n), dim3(GL_WAVE), lds, h->st, sc->list.p, h->n_own, p.slice_ptr.p,
+                         p.cols.p, p.cslice_ptr.p, p.cs2.p, p.cw.p, p.diag_k.p, h->vS.p, c, x, y, 2.0 * h->opt.dt, cap);
     }
   }
   GL_HIP(hipGetLastError());

@@ -351,7 +351,7 @@ void build_host_pattern(HostPattern& hp, int dim, int64_t n_nodes, int64_t n_own
   hp.n_compressed = n_comp;
   lap("16-bit column codes");
   // length classes for the assembly sweep (its LDS footprint is 2 * cap * 64 * 8 B per wave)
-  hp.bucket_cap = {16, 24, 32, 48, 64, 96, 128, 255};
+  hp.bucket_cap = {16, 20, 24, 32, 48, 64, 96, 128, 255};
   hp.bucket_slices.assign(hp.bucket_cap.size(), {});
   // inside a class the interior slices (no ghost column) come first, so that a partitioned run can sweep them while
   // the halo of c is still in flight (bucket_interior[b] of them), then the rest

@@ -1130,6 +1130,10 @@ __global__ void k_pair_of(int64_t n, const double* __restrict__ u, float2* __res
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) ad[i] = make_float2((float)u[i], (float)u[i]);
 }
+void gl_pair_of(glims_ctx* h, const double* u, float* ad) {
+  hipLaunchKernelGGL(k_pair_of, dim3((unsigned)((h->n_nodes + 255) / 256)), dim3(256), 0, h->st, h->n_nodes, u, (float2*)ad);
+  GL_HIP(hipGetLastError());
+}
 // a = c_new + c_k - 2 c_0 (= 2 (c_k - c_0) + delta),  delta = c_new - c_k   over all local nodes (ghosts included)
 __global__ void k_quad_prep(int64_t i0, int64_t n, const double* __restrict__ cn, const double* __restrict__ ck,
                             const double* __restrict__ c0, float2* __restrict__ ad) {

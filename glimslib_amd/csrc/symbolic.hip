@@ -663,7 +663,7 @@ void gl_build_pattern_device(glims_ctx* h, const double* d_xyz, const int32_t* d
   h->nnz_idx16_avail = 0;
   for (int32_t s = 0; s < n_slices; ++s)
     if (h_ok[s]) h->nnz_idx16_avail += slice_ptr[s + 1] - slice_ptr[s];
-  const std::vector<int> caps = {16, 24, 32, 48, 64, 96, 128, 255};
+  const std::vector<int> caps = {16, 20, 24, 32, 48, 64, 96, 128, 255};
   std::vector<std::vector<int32_t>> bucket(caps.size());
   std::vector<int32_t> bucket_interior(caps.size(), 0);
   for (int pass = 0; pass < 2; ++pass)

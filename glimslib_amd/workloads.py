@@ -208,9 +208,155 @@ def by_name(name, n=None):
         return config_c5(*([n] if n else []))
     if name in ('u', 'unstructured'):
         return config_unstructured(*([n] if n else []))
+    if name in ('bl', 'brain_like', 'brain-like'):     # n = number of points here
+        return config_brain_like(*([n] if n else []), isolate=True)
     raise KeyError(name)
 
 
 def b_spmv_bytes(nnz, n_rows):
     """Algorithmic bytes of one CSR SpMV, fp64 values + int32 columns."""
     return 12 * int(nnz) + 20 * int(n_rows)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# A quality-controlled unstructured tetrahedral mesh at brain extent ("brain-like"): stand-in for the CGAL / MeshTool
+# atlas meshes the reference's 3-D cases load (glimslib/utils/meshing.py:7-43,
+# test_cases/test_simulation_tumor_growth_brain/test_case_comparison_3D_atlas.py:84-121; the bundled files are git-LFS
+# stubs).  Nodes of a lattice moved by up to `jitter` x spacing per axis (boundary nodes only inside their face / along
+# their edge, so the hull stays the box), Delaunay-tetrahedralised: node spacing and cell quality are bounded as in the
+# output of a Delaunay-refinement mesher, row lengths vary (about 8-30, mean ~15.5) and nothing is lattice-aligned.
+# Qhull needs ~35 us per point, so the point set is cut into bricks of lattice layers that are triangulated side by side
+# in worker processes: brick B keeps the tetrahedra whose circumcentre lies in B.  With a margin of two lattice layers
+# around every brick that union IS the Delaunay triangulation of the whole point set (an empty sphere centred inside the
+# domain has radius < 1.4 spacings here; tests/test_workloads.py compares with the one-piece triangulation).
+# ---------------------------------------------------------------------------------------------------------------------
+_BL_EXT = np.array([240.0, 240.0, 155.0])
+_BL_ORG = np.array([0.0, -240.0, 0.0])
+
+
+def _bl_points(n_points, jitter, seed):
+    hsp = (_BL_EXT.prod() / float(n_points)) ** (1.0 / 3.0)
+    m = np.maximum(2, np.round(_BL_EXT / hsp).astype(int))
+    idx = np.stack(np.meshgrid(*[np.arange(m[a] + 1) for a in range(3)], indexing='ij'), axis=-1).reshape(-1, 3)
+    h = _BL_EXT / m
+    rng = np.random.default_rng(seed)
+    disp = (rng.random(idx.shape) - 0.5) * (2.0 * float(jitter))
+    free = (idx > 0) & (idx < m[None, :])            # a boundary node moves inside its face / along its edge only
+    pts = (idx + disp * free) * h[None, :] + _BL_ORG[None, :]
+    return np.ascontiguousarray(pts), idx.astype(np.int32), m, h
+
+
+def _circumcentres(X):
+    """Circumcentres of tetrahedra X [T, 4, 3] (vertices in a canonical order: the same bits whoever computes them)."""
+    a = X[:, 1:] - X[:, :1]                                         # [T, 3, 3]
+    rhs = 0.5 * (a * a).sum(axis=2)
+    det = np.linalg.det(a)
+    ok = np.abs(det) > 0.0
+    cc = np.zeros((len(X), 3))
+    cc[ok] = np.linalg.solve(a[ok], rhs[ok][..., None])[..., 0]
+    return cc + X[:, 0], ok
+
+
+_BL_SHARED = {}
+
+
+def _bl_brick(job):
+    """Delaunay triangulation of one brick (+ margin); returns the tetrahedra (global vertex ids) this brick owns."""
+    from scipy.spatial import Delaunay
+    lo, hi, margin, nb_lo, nb_hi = job
+    pts, idx, m, h = (_BL_SHARED[k] for k in ('pts', 'idx', 'm', 'h'))
+    sel = np.ones(len(pts), dtype=bool)
+    for a in range(3):
+        sel &= (idx[:, a] >= lo[a] - margin) & (idx[:, a] <= hi[a] + margin)
+    ids = np.flatnonzero(sel)
+    tets = ids[Delaunay(pts[ids]).simplices]
+    tets.sort(axis=1)                                               # canonical vertex order
+    cc, ok = _circumcentres(pts[tets])
+    # ownership: the brick whose half-open coordinate box holds the circumcentre (clamped into the domain; the bricks
+    # at the upper faces are closed there)
+    rel = (cc - _BL_ORG[None, :]) / h[None, :]
+    own = ok.copy()
+    for a in range(3):
+        r = np.clip(rel[:, a], 0.0, float(m[a]))
+        own &= (r >= lo[a]) & ((r < hi[a]) | (nb_hi[a] & (r <= hi[a])))
+    tets = tets[own]
+    X = pts[tets]
+    vol = np.abs(np.linalg.det(X[:, 1:] - X[:, :1])) / 6.0
+    # flat tetrahedra among the exactly coplanar hull nodes (volume at rounding level of the cell scale h^3 / 6) are dropped
+    return tets[vol > 1e-9 * float(h.prod()) / 6.0].astype(np.int32)
+
+
+def brain_like_mesh(n_points=1000000, jitter=0.3, seed=0, workers=None, bricks=None):
+    """(points [N, 3], cells [M, 4]) of the jittered-lattice Delaunay mesh; deterministic for given arguments (the brick
+    layout depends on n_points only, the number of worker processes does not change the result)."""
+    import multiprocessing as mp
+    import os
+    pts, idx, m, h = _bl_points(n_points, jitter, seed)
+    if bricks is None:   # ~30 k points per brick
+        per_axis = np.maximum(1, np.round(m / max(1.0, (30000.0) ** (1.0 / 3.0))).astype(int))
+        bricks = tuple(int(b) for b in np.minimum(per_axis, np.maximum(1, m // 8)))
+    edges = [np.linspace(0, m[a], bricks[a] + 1).round().astype(int) for a in range(3)]
+    jobs = []
+    for i in range(bricks[0]):
+        for j in range(bricks[1]):
+            for k in range(bricks[2]):
+                lo = (edges[0][i], edges[1][j], edges[2][k])
+                hi = (edges[0][i + 1], edges[1][j + 1], edges[2][k + 1])
+                last = (i == bricks[0] - 1, j == bricks[1] - 1, k == bricks[2] - 1)
+                jobs.append((lo, hi, 2, None, last))
+    _BL_SHARED.update(pts=pts, idx=idx, m=m, h=h)
+    try:
+        if workers is None:
+            workers = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+        workers = max(1, min(int(workers), len(jobs)))
+        if workers == 1:
+            parts = [_bl_brick(j) for j in jobs]
+        else:   # fork: the children inherit the point set; only the owned tetrahedra travel back
+            with mp.get_context('fork').Pool(workers) as pool:
+                parts = pool.map(_bl_brick, jobs, chunksize=1)
+    finally:
+        _BL_SHARED.clear()
+    return pts, np.ascontiguousarray(np.concatenate(parts, axis=0))
+
+
+def _brain_like_labels(mid):
+    """White matter inside a gyrified (undulating) ellipsoid, grey matter around it: a CURVED interface that no lattice
+    plane follows."""
+    x, y, z = mid[:, 0] - 120.0, mid[:, 1] + 120.0, mid[:, 2] - 77.5
+    q = (x / 80.0) ** 2 + (y / 80.0) ** 2 + (z / 50.0) ** 2
+    wave = 1.0 + 0.12 * np.sin(0.21 * x + 0.5) * np.sin(0.17 * y - 0.3) * np.cos(0.19 * z + 0.2)
+    return np.where(q < wave * wave, WM, GM).astype(np.int32)
+
+
+def config_brain_like(n_points=1000000, mechanics=False, jitter=0.3, seed=0, workers=None, isolate=False):
+    """
+    The unstructured counterpart of config C3: ~n_points nodes at brain extent, quality-controlled Delaunay tetrahedra
+    (brain_like_mesh), white matter inside an undulating ellipsoid, parameters and seed of
+    test_case_comparison_3D_atlas.py:71-72,87-121 (as C3), Gaussian a = 0.5, dt = 1, 50 steps.
+    isolate: build the mesh in a child interpreter (its worker processes are forked there) -- for callers that have
+    already initialised the GPU runtime, e.g. bench.py after its timed region.
+    """
+    from .mesh import Mesh
+    if isolate:
+        import os
+        import subprocess
+        import sys
+        import tempfile
+        with tempfile.TemporaryDirectory(prefix="glims_bl_") as d:
+            code = ("import sys, numpy as np; sys.path.insert(0, %r); from glimslib_amd import workloads as w; "
+                    "p, c = w.brain_like_mesh(%d, %r, %d, %r); np.save(%r, p); np.save(%r, c)" %
+                    (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), int(n_points), float(jitter), int(seed),
+                     workers, os.path.join(d, "p.npy"), os.path.join(d, "c.npy")))
+            subprocess.run([sys.executable, "-c", code], check=True)
+            pts, cells = np.load(os.path.join(d, "p.npy")), np.load(os.path.join(d, "c.npy"))
+    else:
+        pts, cells = brain_like_mesh(n_points, jitter, seed, workers)
+    mesh = Mesh(pts, cells)
+    label = _brain_like_labels(mesh.cell_midpoints())
+    tables = dict(D=[0.0, 0.0, 0.01, 0.05, 0.0], rho=[0.0, 0.0, 0.05, 0.05, 0.0],
+                  gamma=[0.0, 0.1, 0.1, 0.1, 0.1], E=[1.0, 1000e-6, 3000e-6, 3000e-6, 1000e-6],
+                  nu=[0.3, 0.45, 0.45, 0.45, 0.3])
+    d2 = ((pts - np.array([118.0, -109.0, 72.0])) ** 2).sum(axis=1)
+    c0 = np.exp(-0.5 * d2)
+    return Workload("brain-like unstructured mesh (jittered-lattice Delaunay, %.2f h), %d nodes, 2 tissues" % (jitter, len(pts)),
+                    mesh, label, tables, c0, 1.0, 50, mechanics, _exterior_nodes(mesh) if mechanics else None)

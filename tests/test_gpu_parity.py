@@ -706,3 +706,55 @@ def test_matrix_free_product_equals_the_assembled_one(backend, dim):
     ref = o.rd_jacobian(c) @ x
     assert rel_l2(ym, ref) < 1e-14 and rel_l2(ya, ref) < 1e-14
     h.close()
+
+
+def test_brain_like_mesh_reduced_matches_the_numpy_oracle(backend):
+    """The brain-like unstructured workload (jittered-lattice Delaunay mesh, curved two-tissue interface, config C3's
+    parameters; stand-in for the CGAL atlas meshes of test_case_comparison_3D_atlas.py:84-121) at reduced size: operators
+    and 5 coupled steps against the numpy oracle's split loop (Newton + sparse LU), displacement clamped on the hull."""
+    w = workloads.config_brain_like(4000, mechanics=True, workers=2)
+    n = w.mesh.num_vertices()
+    dofs = (w.dirichlet_nodes[:, None] * 3 + np.arange(3)).ravel()
+    # a wider seed than the workload's (node spacing is ~13 mm at this size): the front must cross the tissue interface
+    c0 = np.exp(-0.002 * ((w.mesh.points - np.array([118.0, -109.0, 72.0])) ** 2).sum(axis=1))
+    o = OracleTumorGrowth(w.mesh.points, w.mesh.cells, w.per_cell('D'), w.per_cell('rho'), w.per_cell('gamma'),
+                          w.per_cell('E'), w.per_cell('nu'), w.dt, dirichlet_u=(dofs, np.zeros(len(dofs))))
+    h = _handle(backend, w.mesh, w.cell_label, w.dt, w.tables)
+    h.set_dirichlet_u(dofs, np.zeros(len(dofs)))
+    x = np.random.default_rng(3).standard_normal(n)
+    assert rel_l2(h.apply(2, x)[0], o.M @ x) < 1e-13 and rel_l2(h.apply(1, x)[0], o.S @ x) < 1e-13
+    h.set_state(c0)
+    u_ref, c_ref = o.run(c0, 5 * w.dt)
+    assert h.step(5) == 0 and h.solve_mechanics() == 0
+    c, u = h.get_state()
+    assert rel_l2(c, c_ref) < 1e-9
+    assert rel_l2(u, u_ref) < 1e-7
+    h.close()
+
+
+def test_brain_like_mesh_full_size_matches_the_c_oracle(backend):
+    """The same workload at the size bench.py times it (alt.unstructured: ~1.04 M nodes, 6.8 M tetrahedra): 5 steps and the
+    static operators against the C/OpenMP oracle, plus size-independent properties (symmetry of S, row sums of M = nodal
+    volumes adding up to the box)."""
+    from oracle.c_port import COracle
+    w = workloads.config_brain_like(1000000)
+    n = w.mesh.num_vertices()
+    co = COracle(w.mesh.points, w.mesh.cells, w.per_cell('D'), w.per_cell('rho'), w.dt)
+    ref = co.step(w.c0, 5, rtol=1e-11, cg_rtol=1e-4)
+    h = _handle(backend, w.mesh, w.cell_label, w.dt, w.tables, mechanics=False)
+    h.set_state(w.c0)
+    assert h.step(5) == 0
+    c = h.get_state(want_u=False)[0]
+    err = rel_l2(c, ref)
+    print("brain-like, %d nodes: 5 steps, rel-L2 vs C oracle %.2e" % (n, err))
+    assert err < 1e-9
+    rng = np.random.default_rng(0)
+    x, y = rng.standard_normal(n), rng.standard_normal(n)
+    Sx, Sy = h.apply(1, x)[0], h.apply(1, y)[0]
+    assert rel_l2(h.apply(2, x)[0], co.apply(2, x)) < 1e-13 and rel_l2(Sx, co.apply(1, x)) < 1e-13
+    assert abs(y @ Sx - x @ Sy) < 1e-11 * abs(y @ Sx)
+    assert abs(h.apply(2, np.ones(n))[0].sum() - 240.0 * 240.0 * 155.0) < 1e-7 * 240.0 * 240.0 * 155.0
+    st = h.stats()
+    assert st["nnz_padded"] < 1.25 * st["nnz"]
+    h.close()
+    co.close()
