@@ -46,7 +46,7 @@ def _load():
     lib = C.CDLL(LIB)
     h = C.c_void_p
     lib.glims_abi_version.restype = C.c_int
-    assert lib.glims_abi_version() == 4, "rebuild libglimship.so: this binding is written for ABI 4"
+    assert lib.glims_abi_version() == 5, "rebuild libglimship.so: this binding is written for ABI 5"
     lib.glims_create.argtypes = [C.POINTER(h), C.c_int, C.c_int64, C.c_int64, C.c_int64, dp, i32p, i32p, C.c_int]
     lib.glims_destroy.argtypes = [h]
     lib.glims_last_error.restype = C.c_char_p

@@ -27,7 +27,7 @@ FLAG_MG_WHOLE_GRID = 64
 FLAG_FULL_NEWTON = 128
 PRECOND_BLOCK_JACOBI, PRECOND_MULTIGRID = 0, 1
 RD_PRECOND_AUTO, RD_PRECOND_JACOBI, RD_PRECOND_MULTIGRID = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class BackendError(RuntimeError):
@@ -64,7 +64,11 @@ class Stats(C.Structure):
                 ("ms_mgfine_mech", C.c_double), ("n_mgfine_mech", C.c_int64), ("us_mgfine_median", C.c_double),
                 ("ms_spmvb_mech", C.c_double), ("n_spmvb_mech", C.c_int64), ("us_spmvb_median", C.c_double),
                 ("rd_quad_updates", C.c_int64), ("ms_quad_steps", C.c_double), ("n_quad_steps", C.c_int64),
-                ("us_quad_median", C.c_double)]
+                ("us_quad_median", C.c_double),
+                ("midpoint_steps", C.c_int64), ("rebase_events", C.c_int64),
+                ("halo_exchanges", C.c_int64), ("halo_bytes", C.c_int64), ("ms_exchange", C.c_double),
+                ("ms_exchange_exposed", C.c_double), ("allreduces", C.c_int64), ("reduce_transport", C.c_int64),
+                ("mg_grid1_bytes", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

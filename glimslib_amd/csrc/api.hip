@@ -497,6 +497,17 @@ int glims_set_state(glims_ctx* h, const double* c, const double* u) {
     GL_REQUIRE(c, "null concentration");
     h->pending = false;
     h->have_c_old = false;
+    // A new state starts a new run (FenicsSimulation.run() may be called again on the same object, simulation_base.py:166-168,
+    // run_for_adjoint does): what the Newton iteration has learnt from the previous run's steps is forgotten, so that the run
+    // takes the iteration path -- and produces the bits -- of a fresh handle.  (What stays: the operators, both multigrid
+    // hierarchies and the preconditioner `auto` has settled on; they depend on the mesh and the parameters, not on the run.)
+    h->mid_on = false;
+    h->mid_cooldown = h->mid_streak = 0;
+    h->nq_first_ratio = 1e-3;
+    h->nq_skip_steps = 0;
+    for (int& hint : h->cg_hint) hint = 0;
+    h->mech_hint = 0;
+    h->mh_count = h->mh_next = 0;   // ... and the elasticity solver's history of right-hand sides
     to_device_perm(h, c, h->c.p, 1);
     h->have_state = true;
     h->dirichlet_c_dirty = h->have_fixed_c;

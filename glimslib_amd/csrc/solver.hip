@@ -1354,6 +1354,7 @@ int gl_step(glims_ctx* h, int n_steps) {
                                (float2*)h->nq_ad.p);
             gl_rd_quad(h, h->nq_ad.p, h->cg_r.p, h->partials.p);
             h->stats.rd_quad_updates++;
+            h->stats.midpoint_steps++;
           }
         }
         h->have_c_old = true;
@@ -1428,6 +1429,7 @@ int gl_step(glims_ctx* h, int n_steps) {
           // set its tolerance); a residual five times larger is the Jacobian's age showing
           rebase = true;
           h->nq_skip_steps = 9;
+          h->stats.rebase_events++;
         }
       }
       if (speculate && std::isfinite(nr) && nr <= target) {

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GLIMS_ABI_VERSION 4
+#define GLIMS_ABI_VERSION 5
 
 enum {
   GLIMS_OK = 0,
@@ -207,6 +207,21 @@ typedef struct glims_stats {
   double  ms_quad_steps;    /* time_kernels = 2: those passes (k_rd_quad), HIP events */
   int64_t n_quad_steps;
   double  us_quad_median;
+  /* ---- ABI 5: which paths of the Newton iteration ran (the re-entrancy / parity tests assert on these) */
+  int64_t midpoint_steps;   /* time steps whose first right-hand side carried the midpoint correction -dt N(u) u */
+  int64_t rebase_events;    /* Newton iterations after which a cheap residual exceeded 5 x the linear tolerance: fresh Jacobian,
+                               sweeps only for the next steps */
+  /* ---- ABI 5: partitioned runs, per rank (what the first multi-GPU run needs to say where its time went) */
+  int64_t halo_exchanges;   /* neighbour exchanges started by glims_step / glims_solve_mechanics (mesh halos and first-grid boxes) */
+  int64_t halo_bytes;       /* bytes this rank SENT in them */
+  double  ms_exchange;      /* time_kernels != 0: duration of the exchanges on the communication stream (pack -> last receive),
+                               HIP events; 0 with a host transport (glims_set_transport: the callback is synchronous) */
+  double  ms_exchange_exposed; /* time_kernels != 0: part of it the compute stream really waited for (not hidden behind the
+                               interior slices) */
+  int64_t allreduces;       /* scalar all-reduces of the Krylov / Newton iterations */
+  int64_t reduce_transport; /* how they travel: 0 single rank, 1 node mailbox (inside the reduction kernel), 2 ncclAllReduce,
+                               3 host callback */
+  int64_t mg_grid1_bytes;   /* elasticity multigrid: bytes of the first Cartesian grid's operator held by this rank */
 } glims_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------------------- */

@@ -87,3 +87,49 @@ def test_not_combined_with_the_extrapolated_guess_or_the_fp32_jacobian(backend):
     for flags in (backend.FLAG_EXTRAPOLATE_GUESS, backend.FLAG_WARM_START | backend.FLAG_FP32_JACOBIAN):
         s, c, st = _run(backend, w, w.tables, 4, flags)
         assert s == 0 and st['rd_quad_updates'] == 0
+
+
+def test_a_second_run_on_the_same_handle_is_bitwise_the_run_of_a_fresh_handle(backend):
+    """FenicsSimulation.run() may be called again on the same object (simulation_base.py:166-168; run_for_adjoint does so):
+    glims_set_state forgets what the Newton iteration learnt from the previous run (iteration-count hints, contraction
+    estimate, midpoint state machine, sweep-only penalty, elasticity solve history), so the second run takes the iteration
+    path of a fresh handle and produces the same bits -- concentration, displacement, and the iteration counters."""
+    from glimslib_amd import workloads
+    w = workloads.config_c3(n=40, mechanics=True)
+    n = w.mesh.num_vertices()
+    dofs = (np.asarray(w.dirichlet_nodes)[:, None] * 3 + np.arange(3)).ravel()
+    c0 = np.exp(-0.01 * ((w.mesh.points - np.array([118.0, -109.0, 72.0])) ** 2).sum(axis=1))
+
+    def fresh():
+        h = backend.Handle(w.mesh.points, w.mesh.cells, w.cell_label)
+        t = w.tables
+        # rho x 4 (and D x 200, so that the front stays resolved on this coarse mesh): a strong reaction term makes steps of
+        # four Newton iterations, which switch the midpoint correction on
+        h.set_materials([200.0 * d for d in t['D']], [4.0 * r for r in t['rho']], t['gamma'], t['E'], t['nu'])
+        h.set_options(dt=w.dt)
+        h.set_dirichlet_u(dofs, np.zeros(len(dofs)))
+        h.setup(True)
+        return h
+
+    def run(h):
+        h.set_state(c0)
+        h.reset_stats()
+        for _ in range(3):
+            assert h.step(8) == 0 and h.solve_mechanics() == 0
+        c, u = h.get_state()
+        st = h.stats()
+        return c, u, {k: st[k] for k in ("newton_its", "cg_its", "rd_assemblies", "rd_quad_updates", "midpoint_steps",
+                                         "rebase_events", "mech_cg_its")}
+
+    h1 = fresh()
+    c1, u1, s1 = run(h1)
+    c2, u2, s2 = run(h1)            # same handle, second run
+    h2 = fresh()
+    c3, u3, s3 = run(h2)            # fresh handle
+    h1.close()
+    h2.close()
+    print("iteration counters of the three runs:", s1, s2, s3)
+    assert s1 == s2 == s3
+    assert np.array_equal(c1, c3) and np.array_equal(u1, u3)      # run-to-run reproducibility of a fresh handle
+    assert np.array_equal(c2, c3) and np.array_equal(u2, u3)      # the re-run
+    assert s1["rd_quad_updates"] > 0
