@@ -87,6 +87,39 @@ def cpu_baseline(w_headline=None, budget_s=12.0):
     return out
 
 
+def cpu_reference_like(n_c2=18):
+    """
+    The reference-LIKE CPU path (baseline 2a): Newton with a sparse direct solve (scipy SuperLU, one
+    core) of the whole system per iteration -- what DOLFIN's default linear_solver='default' = LU does under
+    simulation_tumor_growth.py:126-130 -- through the numpy oracle, on BASELINE config C1 (coupled, monolithic (d+1)N
+    system, its 10 steps) and on config C2 reduced to n_c2 cells per edge (RD block, 2 steps; at C2's real size one 3-D
+    factorisation no longer fits a bench run).  FEniCS itself is not installed; bounded to ~15 s.
+    """
+    from glimslib_amd import workloads
+    from oracle.glims_oracle import OracleTumorGrowth
+    out = {"unit": "DoF-updates/s", "cores": 1, "kind": "port",
+           "what": "Newton + sparse LU (SuperLU) of the whole system per iteration, oracle/glims_oracle.py"}
+    for key, w, steps in (("c1", workloads.config_c1(), 10), ("c2_reduced", workloads.config_c2(n_c2), 2)):
+        per = {k: w.per_cell(k) for k in ('D', 'rho', 'gamma', 'E', 'nu')}
+        dim = w.mesh.points.shape[1]
+        kw = {}
+        if w.dirichlet_nodes is not None:
+            dofs = (w.dirichlet_nodes[:, None] * dim + np.arange(dim)).ravel()
+            kw['dirichlet_u'] = (dofs, np.zeros(len(dofs)))
+        o = OracleTumorGrowth(w.mesh.points, w.mesh.cells, per['D'], per['rho'], per['gamma'], per['E'], per['nu'], w.dt, **kw)
+        n = w.mesh.num_vertices()
+        t0 = time.perf_counter()
+        if w.mechanics:
+            o.run(w.c0, steps * w.dt, mechanics=True, monolithic=True)
+            unknowns = (dim + 1) * n
+        else:
+            o.run(w.c0, steps * w.dt, mechanics=False, linear='lu')
+            unknowns = n
+        el = time.perf_counter() - t0
+        out[key] = {"workload": w.name, "unknowns": unknowns, "steps": steps, "seconds": el, "value": unknowns * steps / el}
+    return out
+
+
 def alt_c2(Handle, device, steps=20, warmup=2):
     """BASELINE config C2 (unit cube n=46, D = rho = 0.1, dt = 1: a STIFF step, dt D / h^2 = 211) under the driver's
     clock: ms per step and Krylov iterations with the preconditioner `auto` picks, and with Jacobi for comparison."""
@@ -491,13 +524,14 @@ def main():
                         "achieved_real_GBps": None if tb is None else tb / (mean_us * 1e-6) / 1e9,
                         "timed": where})
 
+    spmv_name = "k_spmv<1, %d, 1, 1, double>" % (16 if args.workload.lower() in ("bl", "brain_like", "brain-like", "u", "unstructured") else 8)
     if world == 1 and in_step:
-        kernel_entry("k_spmv<1, 8, 1, 1, double>", "y = A(c) x, SELL-64 with 16-bit column codes, fused w.u partials "
+        kernel_entry(spmv_name, "y = A(c) x, SELL-64 with 16-bit column codes, fused w.u partials "
                      "(algorithmic bytes: CSR with 4-byte columns, 12 nnz + 20 rows)", b_alg,
                      st['ms_spmv_steps'], st['n_spmv_steps'], st['us_spmv_median'], "k_spmv<1", steps_n, ms_step,
                      "HIP events inside the %d timed steps" % steps_n)
     elif world == 1 and post_pass:
-        kernel_entry("k_spmv<1, 8, 1, 1, double>", "y = A(c) x, SELL-64 with 16-bit column codes, fused w.u partials "
+        kernel_entry(spmv_name, "y = A(c) x, SELL-64 with 16-bit column codes, fused w.u partials "
                      "(algorithmic bytes: CSR with 4-byte columns, 12 nnz + 20 rows)", b_alg,
                      st_k['ms_spmv_steps'], st_k['n_spmv_steps'], st_k['us_spmv_median'], "k_spmv<1", st_k['_steps'],
                      st_k['ms_steps'] / st_k['_steps'],
@@ -505,12 +539,12 @@ def main():
     if st_k is not None:
         ks, kms = st_k['_steps'], st_k['ms_steps'] / st_k['_steps']
         where = "HIP events in a separate pass of %d steps right after the timed region" % ks
-        kernel_entry("k_rd_assemble<4, 0, 24, 1, double>", "Jacobian + Newton residual(s) in one sweep over the "
+        kernel_entry("k_rd_assemble_s<4, CAP, RB, 1, double> (one launch per slice class)", "Jacobian + Newton residual(s) in one sweep over the "
                      "(row, cell) incidences (algorithmic bytes: 12 per incidence + 20 per stored entry [S read, A write, "
                      "4-byte column] + 32 per row)", 12 * st['n_corners'] + 20 * st['nnz_padded'] + 32 * st['n_rows'],
                      st_k['ms_sweep_steps'], st_k['n_sweep_steps'], st_k['us_sweep_median'], "k_rd_assemble", ks, kms,
                      where)
-        kernel_entry("k_rd_quad<4, 24, 1>", "Newton residual after a solve from the quadratic structure: r - dt N(a) delta "
+        kernel_entry("k_rd_quad_s<4, CAP, RB, 1> (one launch per slice class)", "Newton residual after a solve from the quadratic structure: r - dt N(a) delta "
                      "over the (row, cell) incidences, neither S nor A touched (algorithmic bytes: 8 per incidence [slot "
                      "word + single-precision weight] + 4 per stored entry [column] + 24 per row [(a, delta) pair gathered "
                      "once, r read + written])",
@@ -643,13 +677,28 @@ def main():
                        "quadratic_residual_updates_per_step": st['rd_quad_updates'] / max(1, steps_done),
                        "device_ms_per_step": st['ms_steps'] / max(1, steps_done),
                        "steps_completed": steps_done,
-                       "solver_status": int(status)},
+                       "solver_status": int(status),
+                       # the config's FULL length (test_case_comparison_3D_atlas.py:84: 500 steps) as measured on this path
+                       "full_run": ({"steps_requested": 500, "steps_completed": 482, "final_status": 1,
+                                     "cause": "consistent-mass P1 scheme without a discrete maximum principle: the front "
+                                              "(sqrt(D/rho) = 0.45 mm) is under-resolved on the 1.1 mm mesh, undershoots "
+                                              "grow through rho c (1 - c) until A(c) turns indefinite at step 483; the C "
+                                              "oracle breaks at the same step (tests/test_gpu_parity.py::test_long_run_"
+                                              "breakdown_...); handled as the reference does (warn, stop, return the last "
+                                              "solution, simulation_base.py:301-305)",
+                                     "ms_per_step_range_over_the_run": [9.5, 15.0],
+                                     "source": "profiles/r03_d_long_c4_run.txt"}
+                                    if (args.workload.lower() == "c4" and not args.n and not coupled) else None)},
             "roofline": roofline,
         }
         if alt is not None:
             out["alt"] = alt
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(None if coupled else w)
+            try:
+                out["cpu_baseline"]["reference_like"] = cpu_reference_like()
+            except Exception as e:   # noqa: BLE001 -- informational only
+                log("[bench] reference-like CPU baseline skipped: %r" % (e,))
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     h.close()

@@ -171,7 +171,7 @@ int glims_create(glims_ctx** out, int dim, int64_t n_nodes, int64_t n_own, int64
     // caller's mesh to the device: the symbolic phase and the per-cell geometry read it there; coordinates and
     // connectivity in the caller's numbering are not kept
     dvec<double> d_xyz;
-    dvec<int32_t> d_cells;
+    dvec<int32_t> d_cells, cells_p;
     d_xyz.upload(xyz, (size_t)n_nodes * dim, h->st);
     d_cells.upload(cells, (size_t)n_cells * (dim + 1), h->st);
     DevPattern& p = h->pat;
@@ -223,13 +223,22 @@ int glims_create(glims_ctx** out, int dim, int64_t n_nodes, int64_t n_own, int64
         if (hp.win_ok[sl]) h->nnz_idx16_avail += hp.slice_ptr[sl + 1] - hp.slice_ptr[sl];
       lap("pattern upload");
     } else {
-      gl_build_pattern_device(h, d_xyz.p, d_cells.p);
+      gl_build_pattern_device(h, d_xyz.p, d_cells.p, cells_p);
       lap("symbolic phase on the device (total)");
     }
     std::vector<uint8_t> lab(n_cells);
     for (int64_t e = 0; e < n_cells; ++e) lab[e] = (uint8_t)cell_label[e];
-    h->label.upload(lab, h->st);
-    gl_compute_egeo(h, d_xyz.p, d_cells.p);
+    if (h->cell_new2old.p) {   // labels and geometry in the internal cell order
+      dvec<uint8_t> lab_caller;
+      lab_caller.upload(lab, h->st);
+      h->label.alloc((size_t)n_cells);
+      gl_gather_u8(h, n_cells, h->cell_new2old.p, lab_caller.p, h->label.p);
+      GL_HIP(hipStreamSynchronize(h->st));
+    } else {
+      h->label.upload(lab, h->st);
+    }
+    gl_compute_egeo(h, d_xyz.p, cells_p.p ? cells_p.p : d_cells.p);
+    cells_p.release();
     GL_HIP(hipStreamSynchronize(h->st));
     d_xyz.release();
     d_cells.release();
@@ -665,7 +674,14 @@ int glims_pattern_checksum(glims_ctx* h, uint64_t out[13]) {
     out[5] = fnv_of(h, p.diag_k.p, (size_t)p.n_slices * GL_WAVE);
     out[6] = fnv_of(h, p.cslice_ptr.p, (size_t)p.n_slices + 1);
     out[7] = fnv_of(h, p.cslots.p, (size_t)p.total_corners);
-    out[8] = fnv_of(h, p.celem.p, (size_t)p.total_corners);
+    if (h->cell_new2old.p) {   // the incidences' cells in the CALLER's numbering, as the host version stores them
+      dvec<int32_t> tmp;
+      tmp.alloc((size_t)p.total_corners);
+      gl_translate_cells(h, (int64_t)p.total_corners, p.celem.p, h->cell_new2old.p, tmp.p);
+      out[8] = fnv_of(h, tmp.p, (size_t)p.total_corners);
+    } else {
+      out[8] = fnv_of(h, p.celem.p, (size_t)p.total_corners);
+    }
     out[9] = fnv_of(h, p.interior_slices.p, (size_t)p.n_interior);
     out[10] = fnv_of(h, p.boundary_slices.p, (size_t)p.n_boundary);
     out[11] = fnv_of(h, h->d_old2new.p, (size_t)h->n_nodes);

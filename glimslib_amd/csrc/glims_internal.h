@@ -116,7 +116,8 @@ struct HostPattern {
 
 struct glims_ctx;
 // symbolic.hip: the same phase on the device (the default; the host version above stays as its cross-check)
-void gl_build_pattern_device(glims_ctx* h, const double* d_xyz, const int32_t* d_cells);
+// cells_p (out): the connectivity in the internal cell order (caller's vertex indices), for the per-cell geometry
+void gl_build_pattern_device(glims_ctx* h, const double* d_xyz, const int32_t* d_cells, dvec<int32_t>& cells_p);
 int gl_host_threads();   // OpenMP team the host phases may use (affinity mask, cgroup quota, ranks per host)
 void build_host_pattern(HostPattern& hp, int dim, int64_t n_nodes, int64_t n_own, int64_t n_cells,
                         const double* xyz, const int32_t* cells);
@@ -407,7 +408,8 @@ struct glims_ctx {
   DevPattern pat;
   int64_t nnz = 0, n_corners = 0;
 
-  dvec<uint8_t> label;
+  dvec<uint8_t> label;                     // per cell, INTERNAL cell order (= celem's indices)
+  dvec<int32_t> cell_new2old;              // internal cell index -> caller's (device-side symbolic phase: cells sorted by first owner; empty = identity)
   dvec<double> egeo;                       // per cell: |T|, grad(lambda_a) [nv][dim]
   dvec<double> mat;                        // [5][GL_MAX_LABELS]: D, rho, gamma, mu, lambda
   bool have_materials = false, is_setup = false, have_mech = false, have_state = false;
@@ -525,6 +527,8 @@ struct glims_ctx {
 
 // kernels.hip ---------------------------------------------------------------------------------------
 void gl_compute_egeo(glims_ctx* h, const double* d_xyz, const int32_t* d_cells);
+void gl_gather_u8(glims_ctx* h, int64_t n, const int32_t* idx, const uint8_t* in, uint8_t* out);   // out[i] = in[idx[i]]
+void gl_translate_cells(glims_ctx* h, int64_t n, const int32_t* celem, const int32_t* new2old, int32_t* out);
 void gl_assemble_static(glims_ctx* h, int with_mechanics);
 int gl_rd_grid(const glims_ctx* h);
 void gl_rd_quad(glims_ctx* h, const float* ad /*[n_nodes][2] = (a, delta)*/, double* r, double* partials /*[gl_rd_grid][2]*/,

@@ -40,7 +40,8 @@ __device__ __forceinline__ void spmv_dot_partial(double pd, int b, double* __res
 // ---------------------------------------------------------------------------------------------------
 template <int D>
 __global__ void k_egeo(int64_t n_cells, const double* __restrict__ xyz, const int32_t* __restrict__ cells,
-                       double* __restrict__ egeo, unsigned long long* __restrict__ bad /*[2]: count, first index + 1*/) {
+                       double* __restrict__ egeo, unsigned long long* __restrict__ bad /*[2]: count, first (caller's) index*/,
+                       const int32_t* __restrict__ cell_new2old /*internal -> caller's cell index, or null*/) {
   constexpr int NV = D + 1, GE = 1 + NV * D;
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_cells) return;
@@ -90,7 +91,7 @@ __global__ void k_egeo(int64_t n_cells, const double* __restrict__ xyz, const in
   }
   if (!(g[0] > 0.0) || !isfinite(1.0 / g[0])) {   // degenerate (zero-volume) or non-finite cell
     atomicAdd(bad, 1ull);
-    atomicMin(bad + 1, (unsigned long long)e);
+    atomicMin(bad + 1, (unsigned long long)(cell_new2old ? cell_new2old[e] : e));
   }
 }
 
@@ -1258,9 +1259,9 @@ void gl_compute_egeo(glims_ctx* h, const double* d_xyz, const int32_t* d_cells) 
   const int bs = 256;
   const unsigned grid = (unsigned)((h->n_cells + bs - 1) / bs);
   if (h->dim == 2)
-    hipLaunchKernelGGL(k_egeo<2>, dim3(grid), dim3(bs), 0, h->st, h->n_cells, d_xyz, d_cells, h->egeo.p, bad.p);
+    hipLaunchKernelGGL(k_egeo<2>, dim3(grid), dim3(bs), 0, h->st, h->n_cells, d_xyz, d_cells, h->egeo.p, bad.p, h->cell_new2old.p);
   else
-    hipLaunchKernelGGL(k_egeo<3>, dim3(grid), dim3(bs), 0, h->st, h->n_cells, d_xyz, d_cells, h->egeo.p, bad.p);
+    hipLaunchKernelGGL(k_egeo<3>, dim3(grid), dim3(bs), 0, h->st, h->n_cells, d_xyz, d_cells, h->egeo.p, bad.p, h->cell_new2old.p);
   GL_HIP(hipGetLastError());
   unsigned long long res[2];
   GL_HIP(hipMemcpyAsync(res, bad.p, sizeof(res), hipMemcpyDeviceToHost, h->st));
@@ -1268,6 +1269,24 @@ void gl_compute_egeo(glims_ctx* h, const double* d_xyz, const int32_t* d_cells) 
   if (res[0] != 0)
     throw glims_error(GLIMS_E_USAGE, std::to_string(res[0]) + " degenerate cell(s) (zero volume or non-finite geometry), "
                                          "the first one is cell " + std::to_string(res[1]));
+}
+
+__global__ void k_gather_u8(int64_t n, const int32_t* __restrict__ idx, const uint8_t* __restrict__ in, uint8_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[idx[i]];
+}
+__global__ void k_translate_cells(int64_t n, const int32_t* __restrict__ celem, const int32_t* __restrict__ new2old,
+                                  int32_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = celem[i] < 0 ? -1 : new2old[celem[i]];
+}
+void gl_gather_u8(glims_ctx* h, int64_t n, const int32_t* idx, const uint8_t* in, uint8_t* out) {
+  hipLaunchKernelGGL(k_gather_u8, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->st, n, idx, in, out);
+  GL_HIP(hipGetLastError());
+}
+void gl_translate_cells(glims_ctx* h, int64_t n, const int32_t* celem, const int32_t* new2old, int32_t* out) {
+  hipLaunchKernelGGL(k_translate_cells, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->st, n, celem, new2old, out);
+  GL_HIP(hipGetLastError());
 }
 
 __global__ void k_to_float(int64_t n, const double* __restrict__ a, float* __restrict__ b) {

@@ -120,14 +120,42 @@ __global__ void k_invert(int64_t n, const int32_t* __restrict__ fwd, int32_t* __
   if (i < n) inv[fwd[i]] = (int32_t)i;
 }
 
-// one (row, cell) pair per cell vertex: row = Morton index of the vertex, n_own for vertices that are not owned rows
+// Cells in the order of their first owner: key = smallest Morton index among the cell's owned vertices.  The set-up
+// kernels reach the cells through the rows' incidence lists -- in the caller's cell order that is a scattered 16-byte read
+// per (row, cell) pair plus a scattered look-up per vertex (343 + 130 GB of fabric fetches to build 3.5 GB of structures at
+// 10 M nodes, profiles/r03_f_pmc_rdmg_10m.json); in this order the cells of neighbouring rows are neighbours in memory, and
+// so are their geometry records and labels for the assembly of the static operators.
+__global__ void k_cell_keys(int64_t n_cells, int nv, int64_t n_own, const int32_t* __restrict__ cells,
+                            const int32_t* __restrict__ o2m, uint32_t* __restrict__ key, int32_t* __restrict__ val) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_cells) return;
+  uint32_t k = (uint32_t)n_own;
+  for (int m = 0; m < nv; ++m) {
+    const int32_t v = cells[e * nv + m];
+    if (v < n_own) k = min(k, (uint32_t)o2m[v]);
+  }
+  key[e] = k;
+  val[e] = (int32_t)e;
+}
+__global__ void k_permute_cells(int64_t n_cells, int nv, const int32_t* __restrict__ new2old,
+                                const int32_t* __restrict__ cells, int32_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_cells * nv) return;
+  const int64_t e = i / nv;
+  out[i] = cells[(int64_t)new2old[e] * nv + (i - e * nv)];
+}
+
+// one (row, cell) pair per cell vertex, generated in the CALLER's cell order (the stable sort by row then lists a row's
+// cells in ascending caller index, as the host version does): row = Morton index of the vertex, n_own for vertices that are
+// not owned rows; the cell is named by its internal index
 __global__ void k_corner_pairs(int64_t n, int nv, int64_t n_own, const int32_t* __restrict__ cells,
-                               const int32_t* __restrict__ o2m, uint32_t* __restrict__ key, int32_t* __restrict__ val) {
+                               const int32_t* __restrict__ o2m, const int32_t* __restrict__ c_old2new,
+                               uint32_t* __restrict__ key, int32_t* __restrict__ val) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int32_t v = cells[i];
   key[i] = v < n_own ? (uint32_t)o2m[v] : (uint32_t)n_own;
-  val[i] = (int32_t)(i / nv);
+  val[i] = c_old2new[i / nv];
 }
 
 // adj_ptr[i] = first position of a key >= i in the sorted keys, i = 0 .. n_own
@@ -143,29 +171,49 @@ __global__ void k_row_offsets(int64_t n_own, int64_t n_pairs, const uint32_t* __
   adj_ptr[i] = lo;
 }
 
-// sorted list of distinct values, kept in the thread's private memory
-__device__ __forceinline__ int insert_sorted(int32_t* a, int n, int32_t v) {
-  int lo = 0, hi = n;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (a[mid] < v) lo = mid + 1;
-    else hi = mid;
+// Sorted list of a row's distinct neighbours while the row is being built.  The first LIST_LDS entries live in the
+// thread's LDS column (entry k of lane l at [k][l]: conflict-free), the rest -- rows of more than LIST_LDS neighbours,
+// which tetrahedral meshes do not have -- in private memory.  (Entirely in private memory, i.e. scratch, as until round 4,
+// the two kernels below moved 343 + 130 GB through the fabric at 10 M nodes: every probe of the binary search and every
+// shifted entry was a scratch access.)
+constexpr int LIST_LDS = 48;
+struct RowList {
+  int32_t* lds;                       // this lane's column, stride GL_WAVE
+  int32_t priv[ROW_CAP - LIST_LDS];
+  __device__ __forceinline__ int32_t get(int k) const { return k < LIST_LDS ? lds[k * GL_WAVE] : priv[k - LIST_LDS]; }
+  __device__ __forceinline__ void set(int k, int32_t v) {
+    if (k < LIST_LDS) lds[k * GL_WAVE] = v;
+    else priv[k - LIST_LDS] = v;
   }
-  if (lo < n && a[lo] == v) return n;
-  if (n >= ROW_CAP) return n + 1;   // overflow: reported by the caller, the list stays as it is
-  for (int k = n; k > lo; --k) a[k] = a[k - 1];
-  a[lo] = v;
-  return n + 1;
-}
+  __device__ __forceinline__ int lower_bound(int n, int32_t v) const {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (get(mid) < v) lo = mid + 1;
+      else hi = mid;
+    }
+    return lo;
+  }
+  __device__ __forceinline__ int insert(int n, int32_t v) {   // returns the new length; n + 1 > ROW_CAP = overflow, list unchanged
+    const int lo = lower_bound(n, v);
+    if (lo < n && get(lo) == v) return n;
+    if (n >= ROW_CAP) return n + 1;
+    for (int k = n; k > lo; --k) set(k, get(k - 1));
+    set(lo, v);
+    return n + 1;
+  }
+};
 
 // distinct neighbours (the row itself included) and adjacent cells of the row with Morton index i
-__global__ __launch_bounds__(256) void k_row_lengths(int64_t n_own, int nv, const int64_t* __restrict__ adj_ptr,
-                                                      const int32_t* __restrict__ adj, const int32_t* __restrict__ cells,
-                                                      int32_t* __restrict__ len, int32_t* __restrict__ clen,
-                                                      const int32_t* __restrict__ m2o, int* __restrict__ flags) {
+__global__ __launch_bounds__(GL_WAVE) void k_row_lengths(int64_t n_own, int nv, const int64_t* __restrict__ adj_ptr,
+                                                          const int32_t* __restrict__ adj, const int32_t* __restrict__ cells,
+                                                          int32_t* __restrict__ len, int32_t* __restrict__ clen,
+                                                          const int32_t* __restrict__ m2o, int* __restrict__ flags) {
+  __shared__ int32_t sl[LIST_LDS * GL_WAVE];
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_own) return;
-  int32_t a[ROW_CAP];
+  RowList a;
+  a.lds = sl + threadIdx.x;
   int n = 0;
   const int64_t q0 = adj_ptr[i], q1 = adj_ptr[i + 1];
   if (q1 == q0) {
@@ -174,9 +222,7 @@ __global__ __launch_bounds__(256) void k_row_lengths(int64_t n_own, int nv, cons
   }
   for (int64_t q = q0; q < q1; ++q) {
     const int32_t* cv = cells + (int64_t)adj[q] * nv;
-    for (int m = 0; m < nv; ++m) {
-      n = insert_sorted(a, min(n, ROW_CAP), cv[m]);
-    }
+    for (int m = 0; m < nv; ++m) n = a.insert(min(n, ROW_CAP), cv[m]);
   }
   if (n > ROW_CAP) flags[4] = 1;
   len[i] = n;
@@ -245,6 +291,7 @@ __global__ __launch_bounds__(GL_WAVE) void k_fill_pattern(int64_t n_own, int nv,
                                                            uint8_t* __restrict__ rlen,
                                                            uint32_t* __restrict__ cslots, int32_t* __restrict__ celem,
                                                            uint8_t* __restrict__ is_boundary) {
+  __shared__ int32_t sl[LIST_LDS * GL_WAVE];
   const int s = blockIdx.x, l = threadIdx.x;
   const int64_t r = (int64_t)s * GL_WAVE + l;
   const int64_t base = slice_ptr[s], cbase = cslice_ptr[s];
@@ -259,18 +306,20 @@ __global__ __launch_bounds__(GL_WAVE) void k_fill_pattern(int64_t n_own, int nv,
     diag_k[r] = 0;
     rlen[r] = 0;
   } else {
-    int32_t a[ROW_CAP];
+    RowList a;
+    a.lds = sl + l;
     int n = 0;
     const int64_t i = row_m[r];
     const int64_t q0 = adj_ptr[i], q1 = adj_ptr[i + 1];
     for (int64_t q = q0; q < q1; ++q) {
       const int32_t* cv = cells + (int64_t)adj[q] * nv;
-      for (int m = 0; m < nv; ++m) n = insert_sorted(a, n, old2new[cv[m]]);
+      for (int m = 0; m < nv; ++m) n = a.insert(n, old2new[cv[m]]);
     }
     for (int k = 0; k < n; ++k) {
-      cols[base + (int64_t)k * GL_WAVE + l] = a[k];
-      if (a[k] == (int32_t)r) diag_k[r] = (uint8_t)k;
-      bnd = bnd || a[k] >= n_own;
+      const int32_t ak = a.get(k);
+      cols[base + (int64_t)k * GL_WAVE + l] = ak;
+      if (ak == (int32_t)r) diag_k[r] = (uint8_t)k;
+      bnd = bnd || ak >= n_own;
     }
     for (int k = n; k < len; ++k) cols[base + (int64_t)k * GL_WAVE + l] = (int32_t)r;
     rlen[r] = (uint8_t)n;
@@ -280,13 +329,7 @@ __global__ __launch_bounds__(GL_WAVE) void k_fill_pattern(int64_t n_own, int nv,
       uint32_t packed = 0;
       for (int m = 0; m < nv; ++m) {
         const int32_t vn = old2new[cells[(int64_t)e * nv + m]];
-        int lo = 0, hi = n;
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if (a[mid] < vn) lo = mid + 1;
-          else hi = mid;
-        }
-        packed |= (uint32_t)lo << (8 * m);
+        packed |= (uint32_t)a.lower_bound(n, vn) << (8 * m);
       }
       celem[cbase + (int64_t)q * GL_WAVE + l] = e;
       cslots[cbase + (int64_t)q * GL_WAVE + l] = packed;
@@ -453,7 +496,7 @@ void sort_pairs(glims_ctx* h, dvec<K>& k_in, dvec<K>& k_out, dvec<V>& v_in, dvec
 
 // Device-side glims_create: fills h->pat (device arrays), h->old2new / new2old, the counters and the mesh metrics from
 // the caller's mesh already on the device (d_xyz [n_nodes][dim], d_cells [n_cells][dim + 1], caller's numbering).
-void gl_build_pattern_device(glims_ctx* h, const double* d_xyz, const int32_t* d_cells) {
+void gl_build_pattern_device(glims_ctx* h, const double* d_xyz, const int32_t* d_cells, dvec<int32_t>& cells_p) {
   const bool verbose = getenv("GLIMS_VERBOSE") != nullptr;
   double t_last = omp_get_wtime();
   auto lap = [&](const char* what) {
@@ -533,6 +576,29 @@ void gl_build_pattern_device(glims_ctx* h, const double* d_xyz, const int32_t* d
   GL_HIP(hipGetLastError());
   lap("Morton keys, sort");
 
+  // ---- 1b. cells in the order of their first owner --------------------------------------------------------------------
+  dvec<int32_t> c_old2new;
+  {
+    dvec<uint32_t> k_in, k_out;
+    dvec<int32_t> v_in;
+    k_in.alloc((size_t)n_cells);
+    k_out.alloc((size_t)n_cells);
+    v_in.alloc((size_t)n_cells);
+    h->cell_new2old.alloc((size_t)n_cells);
+    hipLaunchKernelGGL(k_cell_keys, dim3(gridn(n_cells)), dim3(256), 0, st, n_cells, nv, n_own, d_cells, o2m.p, k_in.p, v_in.p);
+    GL_HIP(hipGetLastError());
+    int cbits = 1;
+    while ((int64_t(1) << cbits) <= n_own) ++cbits;
+    sort_pairs(h, k_in, k_out, v_in, h->cell_new2old, (size_t)n_cells, cbits);   // stable: ties keep the caller's order
+    c_old2new.alloc((size_t)n_cells);
+    hipLaunchKernelGGL(k_invert, dim3(gridn(n_cells)), dim3(256), 0, st, n_cells, h->cell_new2old.p, c_old2new.p);
+    cells_p.alloc((size_t)n_cells * nv);
+    hipLaunchKernelGGL(k_permute_cells, dim3(gridn(n_cells * nv)), dim3(256), 0, st, n_cells, nv, h->cell_new2old.p, d_cells,
+                       cells_p.p);
+    GL_HIP(hipGetLastError());
+  }
+  lap("cells by first owner");
+
   // ---- 2. (row, cell) incidences sorted by row ------------------------------------------------------------------------
   const int64_t n_pairs = n_cells * nv;
   dvec<int32_t> adj;            // cells sorted by (Morton row, cell)
@@ -544,8 +610,8 @@ void gl_build_pattern_device(glims_ctx* h, const double* d_xyz, const int32_t* d
     k_out.alloc((size_t)n_pairs);
     v_in.alloc((size_t)n_pairs);
     adj.alloc((size_t)n_pairs);
-    hipLaunchKernelGGL(k_corner_pairs, dim3(gridn(n_pairs)), dim3(256), 0, st, n_pairs, nv, n_own, d_cells, o2m.p, k_in.p,
-                       v_in.p);
+    hipLaunchKernelGGL(k_corner_pairs, dim3(gridn(n_pairs)), dim3(256), 0, st, n_pairs, nv, n_own, d_cells, o2m.p,
+                       c_old2new.p, k_in.p, v_in.p);
     GL_HIP(hipGetLastError());
     int bits = 1;
     while ((int64_t(1) << bits) <= n_own) ++bits;
@@ -561,7 +627,7 @@ void gl_build_pattern_device(glims_ctx* h, const double* d_xyz, const int32_t* d
   dvec<int32_t> len, clen, row_m, d_new2old;
   len.alloc((size_t)n_own);
   clen.alloc((size_t)n_own);
-  hipLaunchKernelGGL(k_row_lengths, dim3(gridn(n_own)), dim3(256), 0, st, n_own, nv, adj_ptr.p, adj.p, d_cells, len.p,
+  hipLaunchKernelGGL(k_row_lengths, dim3((unsigned)((n_own + GL_WAVE - 1) / GL_WAVE)), dim3(GL_WAVE), 0, st, n_own, nv, adj_ptr.p, adj.p, cells_p.p, len.p,
                      clen.p, m2o.p, flags.p);
   GL_HIP(hipGetLastError());
   row_m.alloc((size_t)n_own);
@@ -634,7 +700,7 @@ void gl_build_pattern_device(glims_ctx* h, const double* d_xyz, const int32_t* d
   dvec<uint8_t> is_boundary;
   is_boundary.alloc((size_t)n_slices);
   hipLaunchKernelGGL(k_fill_pattern, dim3(n_slices), dim3(GL_WAVE), 0, st, n_own, nv, p.slice_ptr.p, p.cslice_ptr.p, row_m.p,
-                     adj_ptr.p, adj.p, d_cells, h->d_old2new.p, p.cols.p, p.diag_k.p, p.rlen.p, p.cslots.p, p.celem.p, is_boundary.p);
+                     adj_ptr.p, adj.p, cells_p.p, h->d_old2new.p, p.cols.p, p.diag_k.p, p.rlen.p, p.cslots.p, p.celem.p, is_boundary.p);
   GL_HIP(hipGetLastError());
   lap("slice offsets, columns + incidences");
 
