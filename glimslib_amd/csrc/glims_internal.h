@@ -258,6 +258,7 @@ struct MgHierarchy {
   dvec<double> x, x2, d, res;              // level-0 work vectors [n_nodes*bs] (ghost slots stay zero)
   double lam0 = 1.0;
   double cheb_ratio = 30.0;                // the smoothers' interval is [lambda_max / cheb_ratio, lambda_max]
+  double default_ratio = 30.0;             // ... its default for this mesh (mg_setup_t), used when glims_options.mg_cheb_ratio = 0
   double dropped_fraction = 0.0;           // mesh edges whose parents lie more than two grid cells apart (not in the coarse operators)
   bool half_smoother = true;               // level-0 smoother streams the half-precision copy of K_el
   bool x32 = false;                        // level-0 cycle vectors in single precision (XNode<BS, float> layout)

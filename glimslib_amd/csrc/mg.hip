@@ -1721,7 +1721,12 @@ void mg_setup_t(glims_ctx* h, MgHierarchy& mg) {
   // measured (tools/run_c5.py, degree 3): config C5 (lattice) 13.0 ms per solve with lmax / 30 against 16.6 with lmax / 10
   // and 18.7 with lmax / 4; 1 M-point Delaunay mesh 75 ms with lmax / 10 against 83 with lmax / 30
   mg.lattice = lattice;
-  mg.cheb_ratio = h->opt.mg_cheb_ratio > 1.0 ? h->opt.mg_cheb_ratio : (lattice ? 30.0 : 10.0);
+  // default interval of the smoothers [lambda_max / ratio, lambda_max]: 30 on lattice meshes AND on general meshes of bounded
+  // node spacing (no mesh edge spans more than two cells of the first grid: what a quality-controlled mesher emits -- the
+  // brain-like workload at 1 M nodes: 27 iterations, 59.9 ms per solve with 30 against 31 / 68.5 with 10), 10 on meshes with
+  // long edges / slivers (1 M random points: 75 ms per solve with 10 against 83 with 30)
+  mg.default_ratio = (lattice || mg.dropped_fraction < 1e-4) ? 30.0 : 10.0;
+  mg.cheb_ratio = h->opt.mg_cheb_ratio > 1.0 ? h->opt.mg_cheb_ratio : mg.default_ratio;
   mg.exact_level0 = framed;
   // (scalar hierarchy of a partitioned run: a float is half a double, the halo exchange moves whole doubles)
   mg.x32 = (h->opt.flags & GLIMS_FLAG_MG_FP64_VECTORS) == 0 && !(BS == 1 && framed);
@@ -2120,7 +2125,7 @@ void mg_apply_cycle(glims_ctx* h, MgHierarchy& mg, int deg, const double* r, dou
   // the smoothers' interval follows the options of the moment (no rebuild: the eigenvalue estimates do not depend on it)
   // (defaults, measured: elasticity 30 on lattice meshes / 10 on general ones with degree 3; the scalar RD hierarchy 10
   // with degree 1 -- tools/run_rd_precond.py)
-  mg.cheb_ratio = h->opt.mg_cheb_ratio > 1.0 ? h->opt.mg_cheb_ratio : (mg.bs == 1 ? 10.0 : mg.lattice ? 30.0 : 10.0);
+  mg.cheb_ratio = h->opt.mg_cheb_ratio > 1.0 ? h->opt.mg_cheb_ratio : (mg.bs == 1 ? 10.0 : mg.default_ratio);
   mg.cycles++;
   // (Replaying the cycle -- or whole Krylov iterations -- from a captured hipGraph was built and measured in round 3: no
   //  gain at any size, 1.99 vs 1.88 ms per step on config C2, 4.37 vs 4.34 at 1 M rows, C5 12.15 vs 12.07: the idle time

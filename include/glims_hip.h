@@ -93,7 +93,8 @@ typedef struct glims_options {
                              frame (glims_set_mg_frame), whose Cartesian levels are replicated on every rank, 2 / 3 / 4
                              for <= 2 / <= 6 / more ranks                                          default 0     */
   double mg_cheb_ratio;   /* the Chebyshev smoothers act on [lambda_max / ratio, lambda_max] of Dinv A;
-                             0 = by mesh class: 30 on lattice meshes, 10 on general ones (measured)  default 0     */
+                             0 = by mesh class: 30 on lattice meshes and on general meshes of bounded node spacing,
+                             10 on meshes with long edges / slivers (measured)                       default 0     */
   int    time_kernels;    /* HIP-event pairs on the handle's stream around hot kernels of glims_step: 1 = the Krylov
                              SpMV, 2 = also the assembly sweep and the PCG vector update; 3 = instead the level-0
                              multigrid pass and the block SpMV of glims_solve_mechanics; results in glims_stats.*_steps / *_mech /

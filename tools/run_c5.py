@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Config C5 (coupled model on the brain-extent box): elasticity solve after every RD step, per preconditioner.
-    python tools/run_c5.py [n] [steps]      env: PRECOND=mg|bj  SMOOTH=k  RATIO  MIXED=0|1|2  HIST=k  HFAC  COARSE  FP32SM=1  X64=1  MECH_RTOL  NU=0.49  EWM=1e4  EGM=1e4"""
+    python tools/run_c5.py [n] [steps]      env: MESH=bl|jitter PRECOND=mg|bj  SMOOTH=k  RATIO  MIXED=0|1|2  HIST=k  HFAC  COARSE  FP32SM=1  X64=1  MECH_RTOL  NU=0.49  EWM=1e4  EGM=1e4"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +9,12 @@ from glimslib_amd import _backend
 from glimslib_amd._backend import Handle
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 99
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
-w = workloads.config_c5(n) if n < 100000 else workloads.config_unstructured(n, mechanics=True)
+if os.environ.get("MESH") == "bl":      # the brain-like unstructured mesh of ~n nodes
+    w = workloads.config_brain_like(n, mechanics=True)
+elif os.environ.get("MESH") == "jitter":   # lattice nodes jittered by 0.3 h, one-piece Delaunay
+    w = workloads.config_unstructured(n, mechanics=True, jitter=0.3)
+else:
+    w = workloads.config_c5(n) if n < 100000 else workloads.config_unstructured(n, mechanics=True)
 t0 = time.perf_counter()
 h = Handle(w.mesh.points, w.mesh.cells, w.cell_label)
 t = dict(w.tables)

@@ -20,8 +20,8 @@ from glimslib_amd.mesh import RectangleMesh  # noqa: E402
 
 
 def problem(dim, n):
-    if os.environ.get("MESH") == "delaunay":     # n random points in the brain-extent box, D scaled by DSCALE
-        w = workloads.config_unstructured(n)
+    if os.environ.get("MESH") in ("delaunay", "bl"):   # n random points (or the brain-like mesh of ~n nodes) in the brain-extent box, D scaled by DSCALE
+        w = workloads.config_unstructured(n) if os.environ["MESH"] == "delaunay" else workloads.config_brain_like(n)
         f = float(os.environ.get("DSCALE", "100"))
         w.tables = dict(w.tables)
         w.tables['D'] = [f * d for d in w.tables['D']]
