@@ -646,6 +646,32 @@ def main():
             except Exception as e:   # noqa: BLE001 -- informational only
                 log("[bench] alt.%s skipped: %r" % (key, e))
 
+    # ---- partitioned runs: what every rank did (so that the first run on real hardware says where its time went) ---------
+    ranks_info = None
+    if world > 1:
+        mine = {"rank": rank, "rows": int(st['n_rows']), "nnz": int(st['nnz']),
+                "ghost_nodes": int(h.n_nodes - st['n_rows']), "peers": int(len(part.peer_rank)),
+                "halo_exchanges_per_step": st['halo_exchanges'] / max(1, steps_done),
+                "halo_bytes_per_exchange": st['halo_bytes'] / max(1, st['halo_exchanges']),
+                "halo_bytes_per_step": st['halo_bytes'] / max(1, steps_done),
+                # HIP events on the communication stream (pack -> last receive) and around the compute stream's wait for it;
+                # 0 under the host-staged rehearsal transport (GLIMS_FORCE_DEVICE), whose callback is synchronous
+                "exchange_us_per_exchange": 1e3 * st['ms_exchange'] / max(1, st['halo_exchanges']),
+                "exchange_ms_per_step": st['ms_exchange'] / max(1, steps_done),
+                "exchange_exposed_ms_per_step": st['ms_exchange_exposed'] / max(1, steps_done),
+                "exchange_hidden_share": (1.0 - st['ms_exchange_exposed'] / st['ms_exchange']) if st['ms_exchange'] > 0 else None,
+                "allreduces_per_step": st['allreduces'] / max(1, steps_done),
+                "reduce_transport": {0: "none", 1: "node mailbox (inside the reduction kernel)", 2: "ncclAllReduce",
+                                     3: "host callback"}.get(int(st['reduce_transport']), "?"),
+                "device_ms_per_step": st['ms_steps'] / max(1, steps_done),
+                "spmv_us_in_step": (1e3 * st['ms_spmv_steps'] / st['n_spmv_steps']) if st['n_spmv_steps'] > 0 else None,
+                "mg_complexity": st['mg_complexity'] if coupled else None,
+                "mg_first_grid_operator_bytes": int(st['mg_grid1_bytes']) if coupled else None,
+                "mech_ms_per_step": st['ms_mech'] / max(1, steps_done) if coupled else None}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        ranks_info = gathered
+
     if rank == 0:
         out = {
             "metric": "DoF-updates/s (implicit RD timestep) on 3D brain mesh; 1/2/4/8 GPU + %HBM roofline",
@@ -691,6 +717,8 @@ def main():
                                     if (args.workload.lower() == "c4" and not args.n and not coupled) else None)},
             "roofline": roofline,
         }
+        if ranks_info is not None:
+            out["ranks"] = ranks_info
         if alt is not None:
             out["alt"] = alt
         if world == 1 and not args.no_cpu_baseline:

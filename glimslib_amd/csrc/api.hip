@@ -304,6 +304,8 @@ int glims_destroy(glims_ctx* h) {
   if (getenv("GLIMS_VERBOSE")) fprintf(stderr, "glims: deferred linear solves that ran out of iterations: %lld\n", (long long)h->stats_defer_miss);
   mailbox_close(h);
   for (hipEvent_t e : h->tev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->cev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->wev) (void)hipEventDestroy(e);
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
   if (h->ev_a) (void)hipEventDestroy(h->ev_a);
   if (h->ev_b) (void)hipEventDestroy(h->ev_b);
@@ -363,6 +365,9 @@ int glims_set_options(glims_ctx* h, const glims_options* opt) {
     // mg_smooth and mg_cheb_ratio are read by every cycle (no rebuild); the grids depend on the other two
     if (opt->mg_coarse_nodes != h->opt.mg_coarse_nodes || opt->mg_h_factor != h->opt.mg_h_factor)
       h->mg.ready = h->mg_rd.ready = false;
+    // partitioned runs keep the first grid's operator for work boxes sized by the smoother degree: a new degree, a new set-up
+    if (h->world > 1 && opt->mg_smooth != h->opt.mg_smooth) h->mg.ready = false;
+    if (h->world > 1 && opt->rd_mg_smooth != h->opt.rd_mg_smooth) h->mg_rd.ready = false;
     if (opt->rd_precond != h->opt.rd_precond) {
       h->rd_precond_active = 0;                   // decided again by the next glims_step
       for (int& hint : h->cg_hint) hint = 0;      // iteration counts of the other preconditioner predict nothing
@@ -576,6 +581,8 @@ int glims_reset_stats(glims_ctx* h) {
   h->stats.rd_mg_levels = keep.rd_mg_levels;
   h->stats.rd_mg_complexity = keep.rd_mg_complexity;
   h->stats.ms_rd_mg_setup = keep.ms_rd_mg_setup;
+  h->stats.reduce_transport = keep.reduce_transport;
+  h->stats.mg_grid1_bytes = keep.mg_grid1_bytes;
   h->tev_used = 0;
   h->stats.steps = keep.steps;   // step counter drives the extrapolated guess; keep it
   return GLIMS_OK;

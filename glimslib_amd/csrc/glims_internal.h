@@ -198,7 +198,11 @@ struct MgLevel {                           // one Cartesian level
   int o[3] = {0, 0, 0};                    // global index of this box's node 0 (partitioned runs; 0 otherwise)
   int ng[3] = {1, 1, 1};                   // nodes per axis of the level's GLOBAL grid
   bool global = false;                     // replicated on every rank (box = whole grid), residual all-reduced per cycle
-  dvec<float> A;                           // [S][bs*bs][nn] stencil-major planes
+  // storage box of the OPERATOR planes (A / A16): lo[3], n[3]; sb_nn = 0: the whole grid.  Box-limited partitioned runs keep
+  // the first grid's operator rows for the rank's work box only (vectors, dinv and sc stay whole-grid arrays)
+  int sb[6] = {0, 0, 0, 0, 0, 0};
+  long long sb_nn = 0;
+  dvec<float> A;                           // [S][bs*bs][rows] stencil-major planes (rows = sb_nn or nn)
   bool half = false;                       // smoothed in symmetrically scaled variables with the half-precision copy A16
   dvec<uint16_t> A16;                      // [S][bs*bs][nn] _Float16 planes of S A S, S = diag(1 / sqrt(a_ii))   (half only)
   dvec<double> sc;                         // [bs][nn] the scale factors s; dinv then holds (S A S)_ii^-1       (half only)
@@ -440,6 +444,20 @@ struct glims_ctx {
   void tick(int cat) {                      // first call opens a pair of category `cat`, the second closes it
     if ((tev_used & 1) == 0) tev_cat[tev_used / 2] = (uint8_t)cat;
     (void)hipEventRecord(tev[tev_used++], st);
+  }
+  // partitioned runs with time_kernels != 0: event pairs around every halo exchange on the communication stream (cev) and
+  // around the compute stream's wait for it (wev) -> stats.ms_exchange / ms_exchange_exposed
+  std::vector<hipEvent_t> cev, wev;
+  size_t cev_used = 0, wev_used = 0;
+  hipEvent_t* comm_pair() {
+    if (!opt.time_kernels || cev_used + 2 > cev.size()) return nullptr;
+    cev_used += 2;
+    return &cev[cev_used - 2];
+  }
+  hipEvent_t* wait_pair() {
+    if (!opt.time_kernels || wev_used + 2 > wev.size()) return nullptr;
+    wev_used += 2;
+    return &wev[wev_used - 2];
   }
   hipEvent_t* pair(int cat) {               // a pair to be attached to one dispatch (hipExtLaunchKernelGGL)
     tev_cat[tev_used / 2] = (uint8_t)cat;

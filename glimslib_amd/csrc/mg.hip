@@ -78,6 +78,24 @@ __device__ __forceinline__ bool box_node(const BoxDev& b, const GridDev& g, long
   return true;
 }
 
+// Operator-sized arrays (stencil planes A / A16) of the first grid of a box-limited partitioned run are kept for the rank's
+// STORAGE box only (= its work box at the smoother degree of the set-up): row of node Iv at op_row(), plane stride
+// op_stride().  sb.nn = 0: the whole grid, global indexing.  (Vectors and the per-node arrays dinv / sc keep the level's
+// global indexing either way: they are 1-3 % of the operator's bytes.)
+__device__ __forceinline__ long long op_row(const BoxDev& sb, const int* Iv, long long I) {
+  return sb.nn ? ((long long)(Iv[2] - sb.lo2) * sb.n1 + (Iv[1] - sb.lo1)) * sb.n0 + (Iv[0] - sb.lo0) : I;
+}
+__device__ __forceinline__ long long op_stride(const BoxDev& sb, const GridDev& g) { return sb.nn ? sb.nn : g.nn; }
+// the lowest rank whose core box holds fine node iv (-1: nobody's): the owner rule of the masked restriction, also of the
+// masked Galerkin product and of the replicated per-node arrays
+__device__ __forceinline__ int core_owner(const int* __restrict__ cores, int n_ranks, const int* iv) {
+  for (int q = 0; q < n_ranks; ++q) {
+    const int* c = cores + q * 6;
+    if (iv[0] >= c[0] && iv[0] <= c[3] && iv[1] >= c[1] && iv[1] <= c[4] && iv[2] >= c[2] && iv[2] <= c[5]) return q;
+  }
+  return -1;
+}
+
 template <int D>
 __device__ __forceinline__ void off2v(int off, int R, int* o) {
   const int W = 2 * R + 1;
@@ -326,15 +344,19 @@ __global__ __launch_bounds__(256) void k_mg_kp(GridDev g1, int R, int64_t r0, in
 template <int D, int BS>
 __global__ void k_mg_ptkp(GridDev g1, int R, int S, int64_t r0, int64_t r1, const int64_t* __restrict__ pt_ptr,
                           const int32_t* __restrict__ pt_idx, const float* __restrict__ pt_w,
-                          const int32_t* __restrict__ cell0, const float* __restrict__ T, double* __restrict__ A1d) {
+                          const int32_t* __restrict__ cell0, const float* __restrict__ T, double* __restrict__ A1d,
+                          const BoxDev cb /*rows kept: this rank's core in a box-limited partitioned run, else the grid*/) {
   constexpr int B2 = BS * BS;
   const int E = 2 * R + 2, NB = D == 3 ? E * E * E : E * E;
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= g1.nn * S) return;
-  const long long I = t / S;
-  const int off = (int)(t - I * S);
+  const long long cnt = cb.nn ? cb.nn : g1.nn;
+  if (t >= cnt * S) return;
+  const long long tn = t / S;
+  const int off = (int)(t - tn * S);
   int Iv[3], o[3], Jv[3] = {0, 0, 0};
-  lin2v(I, g1, Iv);
+  long long I;
+  box_node(cb, g1, tn, Iv, &I);
+  const long long Il = op_row(cb, Iv, I), ps = op_stride(cb, g1);
   off2v<D>(off, R, o);
   bool inside = true;
 #pragma unroll
@@ -345,7 +367,7 @@ __global__ void k_mg_ptkp(GridDev g1, int R, int S, int64_t r0, int64_t r1, cons
   if (!inside) return;   // (A1d is zero-initialised)
   double acc[B2];
 #pragma unroll
-  for (int e = 0; e < B2; ++e) acc[e] = A1d[((long long)off * B2 + e) * g1.nn + I];
+  for (int e = 0; e < B2; ++e) acc[e] = A1d[((long long)off * B2 + e) * ps + Il];
   const long long sl = I >> 6;
   const int64_t base = pt_ptr[sl] + (I & 63);
   const int len = (int)((pt_ptr[sl + 1] - pt_ptr[sl]) >> 6);
@@ -362,7 +384,72 @@ __global__ void k_mg_ptkp(GridDev g1, int R, int S, int64_t r0, int64_t r1, cons
     for (int e = 0; e < B2; ++e) acc[e] += (double)w * (double)tp[e];
   }
 #pragma unroll
-  for (int e = 0; e < B2; ++e) A1d[((long long)off * B2 + e) * g1.nn + I] = acc[e];
+  for (int e = 0; e < B2; ++e) A1d[((long long)off * B2 + e) * ps + Il] = acc[e];
+}
+
+// Box-limited partitioned run: the first grid's operator rows travel by neighbour exchange instead of an all-reduce of the
+// whole operator.  Rank q's partial rows (from its own mesh nodes) are non-zero on q's core only; rank p keeps the rows of its
+// storage box, so p receives (box_p n core_q) from q -- the regions of the residual exchange (GridExchange), with S x B2
+// values per node instead of BS.  Pack: sendbuf[(reg.off + local node) * SB + e] = A1d[e][core-local row].
+__global__ void k_gx_pack_op(GridDev g, BoxDev cb, int SB, int n_reg, const GridRegion* __restrict__ reg, long long n_send,
+                             const double* __restrict__ A1d, double* __restrict__ sendbuf) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_send * SB) return;
+  const long long node = t / SB;
+  const int e = (int)(t - node * SB);
+  int k = 0;
+  while (k + 1 < n_reg && reg[k + 1].off <= node) ++k;
+  const GridRegion q = reg[k];
+  const long long l = node - q.off;
+  const int iv[3] = {q.lo[0] + (int)(l % q.n[0]), q.lo[1] + (int)((l / q.n[0]) % q.n[1]),
+                     q.lo[2] + (int)(l / ((long long)q.n[0] * q.n[1]))};
+  const long long I = v2lin(iv, g);
+  sendbuf[t] = A1d[(long long)e * op_stride(cb, g) + op_row(cb, iv, I)];
+}
+// A[e][storage row of I] = sum over the ranks, in ascending rank order (the same bits wherever two storage boxes overlap), of
+// their partial entries: this rank's own (if I lies in its core) and what the regions received hold.  Thread per (node, e).
+__global__ void k_gx_sum_op(GridDev g, BoxDev sb, BoxDev cb, int my_rank, const int* __restrict__ my_core, int SB, int n_reg,
+                            const GridRegion* __restrict__ reg, const double* __restrict__ recvbuf,
+                            const double* __restrict__ A1d, float* __restrict__ A) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long cnt = sb.nn ? sb.nn : g.nn;
+  if (t >= cnt * SB) return;
+  const long long tn = t / SB;
+  const int e = (int)(t - tn * SB);
+  int iv[3];
+  long long I;
+  box_node(sb, g, tn, iv, &I);
+  const bool mine = iv[0] >= my_core[0] && iv[0] <= my_core[3] && iv[1] >= my_core[1] && iv[1] <= my_core[4] &&
+                    iv[2] >= my_core[2] && iv[2] <= my_core[5];
+  const double own = mine ? A1d[(long long)e * op_stride(cb, g) + op_row(cb, iv, I)] : 0.0;
+  double acc = 0.0;
+  bool own_in = false;
+  for (int k = 0; k < n_reg; ++k) {
+    const GridRegion q = reg[k];
+    if (!own_in && q.rank > my_rank) {
+      acc += own;
+      own_in = true;
+    }
+    const int d0 = iv[0] - q.lo[0], d1 = iv[1] - q.lo[1], d2 = iv[2] - q.lo[2];
+    if (d0 < 0 || d0 >= q.n[0] || d1 < 0 || d1 >= q.n[1] || d2 < 0 || d2 >= q.n[2]) continue;
+    acc += recvbuf[(q.off + ((long long)d2 * q.n[1] + d1) * q.n[0] + d0) * SB + e];
+  }
+  if (!own_in) acc += own;
+  A[(long long)e * op_stride(sb, g) + op_row(sb, iv, I)] = (float)acc;
+}
+// x[.][I] = 0 unless this rank owns node I (lowest rank whose core holds it): after a sum over the ranks every node carries
+// its owner's value.  `fill`: value for nodes nobody owns (added on rank 0 only).
+template <int BS>
+__global__ void k_mg_keep_owned(GridDev g, const int* __restrict__ cores, int n_ranks, int my_rank, double* __restrict__ x,
+                                double fill) {
+  const long long I = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (I >= g.nn) return;
+  int iv[3];
+  lin2v(I, g, iv);
+  const int owner = core_owner(cores, n_ranks, iv);
+  if (owner == my_rank) return;
+#pragma unroll
+  for (int a = 0; a < BS; ++a) x[(long long)a * g.nn + I] = (owner < 0 && my_rank == 0) ? fill : 0.0;
 }
 
 // Transfer between two Cartesian levels.  Levels are boxes of ONE global index frame per level (partitioned runs:
@@ -388,7 +475,9 @@ __device__ __forceinline__ double w1d(int f, int j, int J) {
 // Galerkin product between two Cartesian levels, one thread per (coarse node, stencil offset)
 template <int D, int BS>
 __global__ void k_mg_rap(GridDev gf, GridDev gc, Fac fc, int R, int S, const float* __restrict__ Af,
-                         float* __restrict__ Ac) {
+                         float* __restrict__ Ac, const BoxDev sbf /*storage box of the fine operator*/,
+                         const int* __restrict__ cores /*with a storage box: only the fine rows this rank owns count (the
+                         partial products are all-reduced afterwards)*/, int n_ranks, int my_rank) {
   constexpr int B2 = BS * BS;
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= gc.nn * S) return;
@@ -423,8 +512,9 @@ __global__ void k_mg_rap(GridDev gf, GridDev gc, Fac fc, int R, int S, const flo
         iv[a] = child_index(fc, a, Iv[a], dv[a]);
         ok = ok && iv[a] >= 0 && iv[a] < gn(gf, a);
       }
+      if (ok && cores) ok = core_owner(cores, n_ranks, iv) == my_rank;
       if (!ok) continue;
-      const long long i = v2lin(iv, gf);
+      const long long i = op_row(sbf, iv, v2lin(iv, gf)), psf = op_stride(sbf, gf);
       // fine stencil offsets that land on a child of J: |(iv + of) - f J| <= f - 1 in global indices
       int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
 #pragma unroll
@@ -449,7 +539,7 @@ __global__ void k_mg_rap(GridDev gf, GridDev gc, Fac fc, int R, int S, const flo
             const int oi = v2off<D>(of, R);
             const double ww = wi * wj;
 #pragma unroll
-            for (int e = 0; e < B2; ++e) acc[e] += ww * (double)Af[((long long)oi * B2 + e) * gf.nn + i];
+            for (int e = 0; e < B2; ++e) acc[e] += ww * (double)Af[((long long)oi * B2 + e) * psf + i];
           }
     }
   }
@@ -493,16 +583,18 @@ __device__ __forceinline__ void inv_block(double (*A)[BS], double* o) {
 }
 
 template <int D, int BS>
-__global__ void k_mg_dinv(GridDev g, int S, const float* __restrict__ A, double* __restrict__ dinv) {
+__global__ void k_mg_dinv(GridDev g, int S, const float* __restrict__ A, double* __restrict__ dinv, const BoxDev sb) {
   constexpr int B2 = BS * BS;
-  const long long I = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (I >= g.nn) return;
+  int Iv[3];
+  long long I;
+  if (!box_node(sb, g, (long long)blockIdx.x * blockDim.x + threadIdx.x, Iv, &I)) return;
+  const long long Il = op_row(sb, Iv, I), ps = op_stride(sb, g);
   const int ctr = S / 2;
   double M[BS][BS], o[B2];
 #pragma unroll
   for (int a = 0; a < BS; ++a)
 #pragma unroll
-    for (int b = 0; b < BS; ++b) M[a][b] = (double)A[((long long)ctr * B2 + a * BS + b) * g.nn + I];
+    for (int b = 0; b < BS; ++b) M[a][b] = (double)A[((long long)ctr * B2 + a * BS + b) * ps + Il];
   // the product is symmetric up to the single-precision rounding of its entries: symmetrise the block
 #pragma unroll
   for (int a = 0; a < BS; ++a)
@@ -556,12 +648,13 @@ __global__ __launch_bounds__(256) void k_mg_cart(GridDev g, int R, const AT* __r
                                                   const double* __restrict__ r, double* __restrict__ d,
                                                   double* __restrict__ xout, double c1, double c2,
                                                   const int* __restrict__ done, const double* __restrict__ osc,
-                                                  const BoxDev box) {
+                                                  const BoxDev box, const BoxDev sb) {
   constexpr int B2 = BS * BS;
   if (done && *done) return;   // launches enqueued past the Krylov solver's convergence: nobody reads the result
   int Iv[3];
   long long I;
   if (!box_node(box, g, (long long)blockIdx.x * blockDim.x + threadIdx.x, Iv, &I)) return;
+  const long long Il = op_row(sb, Iv, I), ps = op_stride(sb, g);
   double acc[BS];
 #pragma unroll
   for (int a = 0; a < BS; ++a) acc[a] = 0.0;
@@ -575,14 +668,14 @@ __global__ __launch_bounds__(256) void k_mg_cart(GridDev g, int R, const AT* __r
       const int off0 = (D == 3 ? (oz + R) * W * W : 0) + (oy + R) * W + R;
       for (int ox = xlo; ox <= xhi; ++ox) {
         const long long nb = nb0 + ox;
-        const AT* a0 = A + (long long)(off0 + ox) * B2 * g.nn + I;
+        const AT* a0 = A + (long long)(off0 + ox) * B2 * ps + Il;
         double xb[BS];
 #pragma unroll
         for (int b = 0; b < BS; ++b) xb[b] = xin[(long long)b * g.nn + nb];
 #pragma unroll
         for (int a = 0; a < BS; ++a)
 #pragma unroll
-          for (int b = 0; b < BS; ++b) acc[a] += (double)(float)a0[(long long)(a * BS + b) * g.nn] * xb[b];
+          for (int b = 0; b < BS; ++b) acc[a] += (double)(float)a0[(long long)(a * BS + b) * ps] * xb[b];
       }
     }
   cart_epilogue<BS, MODE>(g.nn, I, acc, dinv, xin, r, d, xout, c1, c2, osc);
@@ -666,7 +759,7 @@ __global__ __launch_bounds__(256) void k_mg_cart_g(GridDev g, int R, int S, cons
                                                     const double* __restrict__ r, double* __restrict__ d,
                                                     double* __restrict__ xout, double c1, double c2,
                                                     const int* __restrict__ done, const double* __restrict__ osc,
-                                                    const BoxDev box) {
+                                                    const BoxDev box, const BoxDev sb) {
   constexpr int B2 = BS * BS, NPW = GL_WAVE / G;   // nodes per wave
   if (done && *done) return;
   const int lane = threadIdx.x & 63;
@@ -689,14 +782,15 @@ __global__ __launch_bounds__(256) void k_mg_cart_g(GridDev g, int R, int S, cons
       }
       if (!in) continue;
       const long long nb = v2lin(nv, g);
-      const AT* a0 = A + (long long)off * B2 * g.nn + I;
+      const long long ps = op_stride(sb, g);
+      const AT* a0 = A + (long long)off * B2 * ps + op_row(sb, Iv, I);
       double xb[BS];
 #pragma unroll
       for (int b = 0; b < BS; ++b) xb[b] = xin[(long long)b * g.nn + nb];
 #pragma unroll
       for (int a = 0; a < BS; ++a)
 #pragma unroll
-        for (int b = 0; b < BS; ++b) acc[a] += (double)(float)a0[(long long)(a * BS + b) * g.nn] * xb[b];
+        for (int b = 0; b < BS; ++b) acc[a] += (double)(float)a0[(long long)(a * BS + b) * ps] * xb[b];
     }
 #pragma unroll
   for (int a = 0; a < BS; ++a) {
@@ -1106,15 +1200,17 @@ __global__ void k_mg_scale(int64_t n, double* __restrict__ x, double s) {
 // operator has no stiffness), Dinv <- S^-1 Dinv S^-1 = inverse diagonal blocks of S A S ...
 template <int D, int BS>
 __global__ void k_mg_level_scale(GridDev g, int S, const float* __restrict__ A, double* __restrict__ sc,
-                                 double* __restrict__ dinv) {
+                                 double* __restrict__ dinv, const BoxDev sb) {
   constexpr int B2 = BS * BS;
-  const long long I = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (I >= g.nn) return;
+  int Iv[3];
+  long long I;
+  if (!box_node(sb, g, (long long)blockIdx.x * blockDim.x + threadIdx.x, Iv, &I)) return;
+  const long long Il = op_row(sb, Iv, I), ps = op_stride(sb, g);
   const int ctr = S / 2;
   double s[BS];
 #pragma unroll
   for (int a = 0; a < BS; ++a) {
-    const double aii = (double)A[((long long)ctr * B2 + a * BS + a) * g.nn + I];
+    const double aii = (double)A[((long long)ctr * B2 + a * BS + a) * ps + Il];
     s[a] = aii > 0.0 ? 1.0 / sqrt(aii) : 1.0;
     sc[(long long)a * g.nn + I] = s[a];
   }
@@ -1127,14 +1223,16 @@ __global__ void k_mg_level_scale(GridDev g, int S, const float* __restrict__ A, 
 // falls below the half-precision range is 1e-5 of a diagonal entry).  One thread per (node, stencil offset).
 template <int D, int BS>
 __global__ void k_mg_half_copy(GridDev g, int R, int S, const float* __restrict__ A, const double* __restrict__ sc,
-                               _Float16* __restrict__ A16) {
+                               _Float16* __restrict__ A16, const BoxDev sb) {
   constexpr int B2 = BS * BS;
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= g.nn * S) return;
-  const int off = (int)(t / g.nn);
-  const long long I = t - (long long)off * g.nn;
+  const long long cnt = sb.nn ? sb.nn : g.nn;
+  if (t >= cnt * S) return;
+  const int off = (int)(t / cnt);
   int Iv[3], o[3], Jv[3] = {0, 0, 0};
-  lin2v(I, g, Iv);
+  long long I;
+  box_node(sb, g, t - (long long)off * cnt, Iv, &I);
+  const long long Il = op_row(sb, Iv, I), ps = op_stride(sb, g);
   off2v<D>(off, R, o);
   bool in = true;
 #pragma unroll
@@ -1147,7 +1245,7 @@ __global__ void k_mg_half_copy(GridDev g, int R, int S, const float* __restrict_
   for (int a = 0; a < BS; ++a)
 #pragma unroll
     for (int b = 0; b < BS; ++b) {
-      const long long e = ((long long)off * B2 + a * BS + b) * g.nn + I;
+      const long long e = ((long long)off * B2 + a * BS + b) * ps + Il;
       A16[e] = in ? (_Float16)(float)(sc[(long long)a * g.nn + I] * (double)A[e] * sc[(long long)b * g.nn + J]) : (_Float16)0.0f;
     }
 }
@@ -1277,6 +1375,9 @@ namespace {
 // was exact on; the input outside the box is stale.  Down: deg - 1 stencil passes and the residual (exact on box - deg R,
 // needed on the core); up: the post-smoother starts from the pre-smoothed iterate (box - (deg - 1) R) and takes deg passes
 // (exact on box - (2 deg - 1) R, needed on the core).  Hence the margin (2 deg - 1) R.
+inline BoxDev sbox_of(const MgLevel& L) {
+  return BoxDev{L.sb[0], L.sb[1], L.sb[2], L.sb[3], L.sb[4], L.sb[5], L.sb_nn};
+}
 template <int D>
 BoxDev mg_work_box(const MgHierarchy& mg, const MgGrid& g, int deg) {
   const int m = (2 * deg - 1) * mg.R;
@@ -1302,12 +1403,13 @@ void mg_apply_cart(glims_ctx* h, MgHierarchy& mg, MgLevel& L, int R, int mode, c
                    const BoxDev box = BoxDev{0, 0, 0, 0, 0, 0, 0}) {
   const GridDev g = gdev(L.g);
   const int S = mg.S;
+  const BoxDev sb = sbox_of(L);                   // where the level's operator planes keep their rows
   const long long cnt = box.nn ? box.nn : g.nn;   // threads' nodes: the work box of a partitioned run, or the grid
   GL_REQUIRE(!(L.half && mode == 2), "internal: the single-precision planes of this level are gone");   // (power iteration: before)
   const bool half = L.half;
   const _Float16* A16 = (const _Float16*)L.A16.p;
   if (g.nn <= 6000) {
-    GL_REQUIRE(!half && box.nn == 0, "internal: half-precision operator / work box on a small grid");
+    GL_REQUIRE(!half && box.nn == 0 && sb.nn == 0, "internal: half-precision operator / work box on a small grid");
     const unsigned gw = gridn(g.nn, 4);
     if (mode == 0)
       hipLaunchKernelGGL((k_mg_cart_w<D, BS, 0>), dim3(gw), dim3(256), 0, h->st, g, R, S, L.A.p, L.dinv.p, xin, r, d, xout, c1, c2, done);
@@ -1324,16 +1426,16 @@ void mg_apply_cart(glims_ctx* h, MgHierarchy& mg, MgLevel& L, int R, int mode, c
   do {                                                                                                               \
     if (lanes && half)                                                                                               \
       hipLaunchKernelGGL((k_mg_cart_g<D, BS, MODE, 4, _Float16>), dim3(grid), dim3(256), 0, h->st, g, R, S, A16, L.dinv.p, \
-                         xin, r, d, xout, c1, c2, done, osc, box);                                                   \
+                         xin, r, d, xout, c1, c2, done, osc, box, sb);                                               \
     else if (lanes)                                                                                                  \
       hipLaunchKernelGGL((k_mg_cart_g<D, BS, MODE, 4, float>), dim3(grid), dim3(256), 0, h->st, g, R, S, L.A.p, L.dinv.p, \
-                         xin, r, d, xout, c1, c2, done, osc, box);                                                   \
+                         xin, r, d, xout, c1, c2, done, osc, box, sb);                                               \
     else if (half)                                                                                                   \
       hipLaunchKernelGGL((k_mg_cart<D, BS, MODE, _Float16>), dim3(grid), dim3(256), 0, h->st, g, R, A16, L.dinv.p, xin, r, \
-                         d, xout, c1, c2, done, osc, box);                                                           \
+                         d, xout, c1, c2, done, osc, box, sb);                                                       \
     else                                                                                                             \
       hipLaunchKernelGGL((k_mg_cart<D, BS, MODE, float>), dim3(grid), dim3(256), 0, h->st, g, R, L.A.p, L.dinv.p, xin, r,  \
-                         d, xout, c1, c2, done, osc, box);                                                           \
+                         d, xout, c1, c2, done, osc, box, sb);                                                       \
   } while (0)
   if (mode == 0) GL_CART(0); else if (mode == 1) GL_CART(1); else GL_CART(2);
 #undef GL_CART
@@ -1545,9 +1647,104 @@ void mg_setup_t(glims_ctx* h, MgHierarchy& mg) {
     for (size_t q = 0; q < all.size(); ++q) all_cores[q] = (int)std::lround(all[q]);
     mg.cores.upload(all_cores, h->st);
   }
-  lap("grid choice, node -> cell map, reach");
+  // ---- box-limited first grid (partitioned runs): decided BEFORE its operator is built, because the operator is then kept
+  // for the rank's work box only.  Only where the thread-per-node / lanes-per-node kernels run and a coarser level exists; a
+  // decision from replicated numbers, the same on every rank (the cycle then holds one more all-reduce).
+  // Worth it when the passes saved outweigh the one small all-reduce the masked restriction adds per cycle (taken as 40 us
+  // over RCCL): saving = (1 - largest box / grid, at the set-up's smoother degree) x (2 deg + 1) passes x the first grid's
+  // half-precision operator bytes at 4 TB/s, required to be 1.5 x the cost -- e.g. a 55^3 grid of 27-point 3 x 3 stencils
+  // (config C4's size on 8 ranks with spacing 4 h) with boxes of 22 %: 110 us saved.  GLIMS_MG_BOX_MIN_NODES (test hook)
+  // replaces the estimate by a plain size threshold so that small test meshes take the path.
+  mg.boxed = false;
+  mg.box_fraction = 1.0;
+  mg.gx.reset();
   mg.S = 1;
   for (int a = 0; a < D; ++a) mg.S *= 2 * mg.R + 1;
+  BoxDev sbox1{0, 0, 0, 0, 0, 0, 0};   // storage box of the first grid's operator planes (nn = 0: the whole grid)
+  if (framed && h->world > 1 && g1.nn > coarse_max && (h->opt.flags & GLIMS_FLAG_MG_WHOLE_GRID) == 0) {
+    const char* e = getenv("GLIMS_MG_BOX_MIN_NODES");
+    const long long min_nodes = e ? std::max(6001ll, atoll(e)) : 0;
+    const int deg0 = BS == 1 ? (h->opt.rd_mg_smooth > 0 ? h->opt.rd_mg_smooth : (lattice ? 1 : 3)) : std::max(1, h->opt.mg_smooth);
+    const MgGrid& g = g1;
+    double worst = 0.0;
+    MgHierarchy probe;   // (only core / R are read)
+    probe.R = mg.R;
+    for (int q = 0; q < h->world; ++q) {
+      for (int a = 0; a < 6; ++a) probe.core[a] = all_cores[(size_t)q * 6 + a];
+      const BoxDev b = mg_work_box<D>(probe, g, deg0);
+      const double f = b.nn ? (double)b.nn / (double)g.nn : 1.0;
+      worst = std::max(worst, f);
+      if (q == h->rank) mg.box_fraction = f;
+    }
+    const double saved_us = (1.0 - worst) * (2.0 * deg0 + 1.0) * (double)g.nn * mg.S * B2 * 2.0 / 4.0e6;
+    mg.boxed = g.nn > 6000 && (min_nodes ? g.nn >= min_nodes && worst <= 0.8 : saved_us >= 60.0);
+    if (!mg.boxed) mg.box_fraction = 1.0;
+    // the first-grid residual (every cycle) and operator rows (once, below) by neighbour exchange (GridExchange): regions
+    // from the cores every rank holds
+    if (mg.boxed) {
+      sbox1 = mg_work_box<D>(mg, g, deg0);
+      GridExchange& x = mg.gx;
+      x.deg = deg0;
+      auto box_of = [&](int q, int* lo, int* hi) {   // work box of rank q, inclusive (whole grid if mg_work_box says so)
+        for (int a = 0; a < 6; ++a) probe.core[a] = all_cores[(size_t)q * 6 + a];
+        const BoxDev b = mg_work_box<D>(probe, g, deg0);
+        const int l3[3] = {b.lo0, b.lo1, b.lo2}, n3[3] = {b.n0, b.n1, b.n2};
+        for (int a = 0; a < 3; ++a) {
+          lo[a] = b.nn ? l3[a] : 0;
+          hi[a] = b.nn ? l3[a] + n3[a] - 1 : g.n[a] - 1;
+        }
+      };
+      auto cut = [&](const int* blo, const int* bhi, int q, GridRegion* out) {   // box n core_q
+        long long vol = 1;
+        for (int a = 0; a < 3; ++a) {
+          const int lo = std::max(blo[a], all_cores[(size_t)q * 6 + a]), hi = std::min(bhi[a], all_cores[(size_t)q * 6 + 3 + a]);
+          out->lo[a] = lo;
+          out->n[a] = hi - lo + 1;
+          if (hi < lo) return 0ll;
+          vol *= out->n[a];
+        }
+        out->rank = q;
+        return vol;
+      };
+      int mylo[3], myhi[3];
+      box_of(h->rank, mylo, myhi);
+      std::vector<GridRegion> sreg, rreg;
+      x.send_ptr.assign(1, 0);
+      x.recv_ptr.assign(1, 0);
+      for (int q = 0; q < h->world; ++q) {
+        if (q == h->rank) continue;
+        GridRegion rs, rr;
+        int qlo[3], qhi[3];
+        box_of(q, qlo, qhi);
+        const long long vs = cut(qlo, qhi, h->rank, &rs);   // what q needs of my partial sums: box_q n core_me
+        const long long vr = cut(mylo, myhi, q, &rr);        // what I need of q's: box_me n core_q
+        if (vs == 0 && vr == 0) continue;
+        x.peers.push_back(q);
+        if (vs > 0) {
+          rs.rank = q;
+          rs.off = x.n_send;
+          sreg.push_back(rs);
+          x.n_send += vs;
+        }
+        if (vr > 0) {
+          rr.off = x.n_recv;
+          rreg.push_back(rr);
+          x.n_recv += vr;
+        }
+        x.send_ptr.push_back(x.n_send);
+        x.recv_ptr.push_back(x.n_recv);
+      }
+      x.n_send_reg = (int)sreg.size();
+      x.n_recv_reg = (int)rreg.size();
+      if (!sreg.empty()) x.send_reg.upload(sreg, h->st);
+      if (!rreg.empty()) x.recv_reg.upload(rreg, h->st);
+      x.sendbuf.alloc((size_t)std::max<long long>(1, x.n_send) * BS);
+      x.recvbuf.alloc((size_t)std::max<long long>(1, x.n_recv) * BS);
+      GL_HIP(hipStreamSynchronize(h->st));
+      x.ready = true;
+    }
+  }
+  lap("grid choice, node -> cell map, reach");
   {   // children lists: the OWNED mesh nodes sorted by cell (stable radix sort: ascending node index inside a cell)
     dvec<uint32_t> k_in, k_out;
     dvec<int32_t> v_in;
@@ -1612,7 +1809,7 @@ void mg_setup_t(glims_ctx* h, MgHierarchy& mg) {
   }
 
   // ---- Galerkin products ------------------------------------------------------------------------------------------
-  auto new_level = [&](const MgGrid& g, const int* off, const int* ng, bool global) {
+  auto new_level = [&](const MgGrid& g, const int* off, const int* ng, bool global, const BoxDev sb = BoxDev{0, 0, 0, 0, 0, 0, 0}) {
     MgLevel* L = new MgLevel();
     L->g = g;
     for (int a = 0; a < 3; ++a) {
@@ -1620,7 +1817,10 @@ void mg_setup_t(glims_ctx* h, MgHierarchy& mg) {
       L->ng[a] = ng[a];
     }
     L->global = global;
-    L->A.alloc((size_t)mg.S * B2 * g.nn);
+    const int sbv[6] = {sb.lo0, sb.lo1, sb.lo2, sb.n0, sb.n1, sb.n2};
+    for (int a = 0; a < 6; ++a) L->sb[a] = sbv[a];
+    L->sb_nn = sb.nn;
+    L->A.alloc((size_t)mg.S * B2 * (sb.nn ? sb.nn : g.nn));
     L->dinv.alloc((size_t)B2 * g.nn);
     for (dvec<double>* v : {&L->x, &L->x2, &L->r, &L->d, &L->res}) v->alloc_zero((size_t)BS * g.nn, h->st);
     mg.lv.push_back(L);
@@ -1647,11 +1847,20 @@ void mg_setup_t(glims_ctx* h, MgHierarchy& mg) {
     GL_HIP(hipStreamSynchronize(h->st));
   };
   const bool g1_global = framed;
-  MgLevel* L1 = new_level(g1, o1, ng1, g1_global);
+  MgLevel* L1 = new_level(g1, o1, ng1, g1_global, sbox1);
   {   // A1 = P^T K P in two gathers (k_mg_kp, k_mg_ptkp); rows in chunks so that T = K P stays below ~8 GB
     const int E = 2 * mg.R + 2;
     const int64_t NB = D == 3 ? (int64_t)E * E * E : (int64_t)E * E;
-    const size_t ne = (size_t)mg.S * B2 * g1.nn;
+    // this rank's partial operator (the rows of its own mesh nodes' parents): on its core box in a box-limited run
+    BoxDev cb{0, 0, 0, 0, 0, 0, 0};
+    if (mg.boxed) {
+      long long cn = 1;
+      for (int a = 0; a < 3; ++a) cn *= std::max(1, mg.core[3 + a] - mg.core[a] + 1);
+      cb = BoxDev{mg.core[0], mg.core[1], mg.core[2], std::max(1, mg.core[3] - mg.core[0] + 1),
+                  std::max(1, mg.core[4] - mg.core[1] + 1), std::max(1, mg.core[5] - mg.core[2] + 1), cn};
+    }
+    const long long rows = cb.nn ? cb.nn : g1.nn;
+    const size_t ne = (size_t)mg.S * B2 * rows;
     dvec<double> A1d;
     A1d.alloc_zero(ne, h->st);
     const int64_t chunk = std::max<int64_t>(GL_WAVE, std::min<int64_t>(n, ((int64_t)8 << 30) / (NB * B2 * (int64_t)sizeof(float))));
@@ -1661,16 +1870,36 @@ void mg_setup_t(glims_ctx* h, MgHierarchy& mg) {
       const int64_t r1 = std::min(n, r0 + chunk);
       hipLaunchKernelGGL((k_mg_kp<D, BS>), dim3(gridn(r1 - r0, 4)), dim3(256), 0, h->st, gdev(g1), mg.R, r0, r1, n_all,
                          mg.cell0.p, mg.wgt.p, p.slice_ptr.p, p.cols.p, mg.op_vals, fxr, T.p);
-      hipLaunchKernelGGL((k_mg_ptkp<D, BS>), dim3(gridn((long long)g1.nn * mg.S)), dim3(256), 0, h->st, gdev(g1), mg.R, mg.S,
-                         r0, r1, mg.pt_ptr.p, mg.pt_idx.p, mg.pt_w.p, mg.cell0.p, T.p, A1d.p);
+      hipLaunchKernelGGL((k_mg_ptkp<D, BS>), dim3(gridn(rows * mg.S)), dim3(256), 0, h->st, gdev(g1), mg.R, mg.S,
+                         r0, r1, mg.pt_ptr.p, mg.pt_idx.p, mg.pt_w.p, mg.cell0.p, T.p, A1d.p, cb);
       GL_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_mg_d2f, dim3(gridn((long long)ne)), dim3(256), 0, h->st, (int64_t)ne, A1d.p, L1->A.p);
-    GL_HIP(hipGetLastError());
-    GL_HIP(hipStreamSynchronize(h->st));
+    if (mg.boxed) {
+      // the rows of this rank's storage box = own partial rows + the neighbours' (box n their core), summed in rank order
+      GridExchange& x = mg.gx;
+      const int SB = mg.S * B2;
+      dvec<double> sbuf, rbuf;
+      dvec<int> my_core;
+      sbuf.alloc((size_t)std::max<long long>(1, x.n_send) * SB);
+      rbuf.alloc((size_t)std::max<long long>(1, x.n_recv) * SB);
+      my_core.upload(std::vector<int>(mg.core, mg.core + 6), h->st);
+      if (x.n_send > 0)
+        hipLaunchKernelGGL(k_gx_pack_op, dim3(gridn(x.n_send * SB)), dim3(256), 0, h->st, gdev(g1), cb, SB, x.n_send_reg,
+                           x.send_reg.p, x.n_send, A1d.p, sbuf.p);
+      GL_HIP(hipGetLastError());
+      gl_exchange(h, x.peers, x.send_ptr, x.recv_ptr, sbuf.p, rbuf.p, SB);
+      hipLaunchKernelGGL(k_gx_sum_op, dim3(gridn(sbox1.nn * SB)), dim3(256), 0, h->st, gdev(g1), sbox1, cb, h->rank, my_core.p,
+                         SB, x.n_recv_reg, x.recv_reg.p, rbuf.p, A1d.p, L1->A.p);
+      GL_HIP(hipGetLastError());
+      GL_HIP(hipStreamSynchronize(h->st));
+    } else {
+      hipLaunchKernelGGL(k_mg_d2f, dim3(gridn((long long)ne)), dim3(256), 0, h->st, (int64_t)ne, A1d.p, L1->A.p);
+      GL_HIP(hipGetLastError());
+      GL_HIP(hipStreamSynchronize(h->st));
+    }
   }
-  if (g1_global) allreduce_operator(L1);
-  mg.entries = (int64_t)mg.S * B2 * g1.nn;
+  if (g1_global && !mg.boxed) allreduce_operator(L1);
+  mg.entries = (int64_t)mg.S * B2 * (sbox1.nn ? sbox1.nn : g1.nn);   // per rank
   // coarsen until the GLOBAL grid is small enough (the level count is then the same on every rank)
   while (nn_of(mg.lv.back()->ng) > coarse_max) {
     MgLevel* Lf = mg.lv.back();
@@ -1705,14 +1934,19 @@ void mg_setup_t(glims_ctx* h, MgHierarchy& mg) {
     MgLevel* Lc = new_level(gc, oc, ngc, glob);
     Lf = mg.lv[mg.lv.size() - 2];
     Fac fc{{Lf->f[0], Lf->f[1], Lf->f[2]}, {Lf->o[0], Lf->o[1], Lf->o[2]}, {oc[0], oc[1], oc[2]}};
+    // below a box-stored level every rank forms the product of the fine rows it OWNS (lowest rank whose core holds the node;
+    // cores lie inside the storage boxes): a partition of the rows, summed over the ranks
+    const bool masked = Lf->sb_nn != 0;
     hipLaunchKernelGGL((k_mg_rap<D, BS>), dim3(gridn((long long)gc.nn * mg.S)), dim3(256), 0, h->st, gdev(Lf->g), gdev(gc),
-                       fc, mg.R, mg.S, Lf->A.p, Lc->A.p);
+                       fc, mg.R, mg.S, Lf->A.p, Lc->A.p, sbox_of(*Lf), masked ? mg.cores.p : (const int*)nullptr, h->world,
+                       h->rank);
     GL_HIP(hipGetLastError());
-    if (glob && !Lf->global) allreduce_operator(Lc);   // first replicated level: sum of the ranks' parts
+    if (glob && (!Lf->global || masked)) allreduce_operator(Lc);   // first replicated level: sum of the ranks' parts
     mg.entries += (int64_t)mg.S * B2 * gc.nn;
   }
   for (MgLevel* L : mg.lv) {
-    hipLaunchKernelGGL((k_mg_dinv<D, BS>), dim3(gridn(L->g.nn)), dim3(256), 0, h->st, gdev(L->g), mg.S, L->A.p, L->dinv.p);
+    hipLaunchKernelGGL((k_mg_dinv<D, BS>), dim3(gridn(L->sb_nn ? L->sb_nn : L->g.nn)), dim3(256), 0, h->st, gdev(L->g), mg.S,
+                       L->A.p, L->dinv.p, sbox_of(*L));
     GL_HIP(hipGetLastError());
   }
 
@@ -1758,7 +1992,17 @@ void mg_setup_t(glims_ctx* h, MgHierarchy& mg) {
     hipLaunchKernelGGL(k_mg_fill, dim3(gridn(nd)), dim3(256), 0, h->st, nd, L.x.p, (const uint8_t*)nullptr);
     double lam = 1.0;
     for (int it = 0; it < pit; ++it) {
-      mg_apply_cart<D, BS>(h, mg, L, mg.R, 2, L.x.p, nullptr, nullptr, L.x2.p, 0.0, 0.0);
+      if (L.sb_nn) {
+        // box-stored operator: every rank applies the rows of its box to the (replicated) vector, keeps the rows it owns, and
+        // the sum over the ranks is the whole product -- the single-rank iteration, evaluated in a distributed way
+        mg_apply_cart<D, BS>(h, mg, L, mg.R, 2, L.x.p, nullptr, nullptr, L.x2.p, 0.0, 0.0, nullptr, nullptr, sbox_of(L));
+        hipLaunchKernelGGL((k_mg_keep_owned<BS>), dim3(gridn(L.g.nn)), dim3(256), 0, h->st, gdev(L.g), mg.cores.p, h->world,
+                           h->rank, L.x2.p, 0.0);
+        GL_HIP(hipGetLastError());
+        gl_allreduce_bulk(h, L.x2.p, (size_t)nd);
+      } else {
+        mg_apply_cart<D, BS>(h, mg, L, mg.R, 2, L.x.p, nullptr, nullptr, L.x2.p, 0.0, 0.0);
+      }
       lam = std::sqrt(gl_dot(h, L.x2.p, L.x2.p, nd, false));
       if (!(lam > 0.0) || !std::isfinite(lam)) break;
       hipLaunchKernelGGL(k_mg_scale, dim3(gridn(nd)), dim3(256), 0, h->st, nd, L.x2.p, 1.0 / lam);
@@ -1773,11 +2017,19 @@ void mg_setup_t(glims_ctx* h, MgHierarchy& mg) {
   if (mg.lv.size() >= 2 && mg.lv[0]->g.nn > 6000 && mg.half_smoother) {
     MgLevel& L = *mg.lv[0];
     const GridDev g = gdev(L.g);
-    L.sc.alloc((size_t)BS * L.g.nn);
-    L.A16.alloc((size_t)mg.S * B2 * L.g.nn);
-    hipLaunchKernelGGL((k_mg_level_scale<D, BS>), dim3(gridn(g.nn)), dim3(256), 0, h->st, g, mg.S, L.A.p, L.sc.p, L.dinv.p);
-    hipLaunchKernelGGL((k_mg_half_copy<D, BS>), dim3(gridn((long long)g.nn * mg.S)), dim3(256), 0, h->st, g, mg.R, mg.S, L.A.p,
-                       L.sc.p, (_Float16*)L.A16.p);
+    const BoxDev sb = sbox_of(L);
+    const long long rows = sb.nn ? sb.nn : g.nn;
+    L.sc.alloc_zero((size_t)BS * L.g.nn, h->st);
+    L.A16.alloc((size_t)mg.S * B2 * rows);
+    hipLaunchKernelGGL((k_mg_level_scale<D, BS>), dim3(gridn(rows)), dim3(256), 0, h->st, g, mg.S, L.A.p, L.sc.p, L.dinv.p, sb);
+    if (sb.nn) {   // the half copy scales COLUMNS too: the factors of the nodes around the box come from their owners
+      hipLaunchKernelGGL((k_mg_keep_owned<BS>), dim3(gridn(g.nn)), dim3(256), 0, h->st, g, mg.cores.p, h->world, h->rank,
+                         L.sc.p, 1.0);
+      GL_HIP(hipGetLastError());
+      gl_allreduce_bulk(h, L.sc.p, (size_t)BS * g.nn);
+    }
+    hipLaunchKernelGGL((k_mg_half_copy<D, BS>), dim3(gridn(rows * mg.S)), dim3(256), 0, h->st, g, mg.R, mg.S, L.A.p,
+                       L.sc.p, (_Float16*)L.A16.p, sb);
     GL_HIP(hipGetLastError());
     GL_HIP(hipStreamSynchronize(h->st));
     L.A.release();
@@ -1841,99 +2093,6 @@ void mg_setup_t(glims_ctx* h, MgHierarchy& mg) {
   lap("coarsest level: dense inverse");
   mg.ready = true;
   mg.n_levels = (int)mg.lv.size() + 1;
-  // box-limited first grid (partitioned runs): only where the thread-per-node / lanes-per-node kernels run and a coarser
-  // level exists; a decision from replicated numbers, the same on every rank (the cycle then holds one more all-reduce)
-  // Worth it when the passes saved outweigh the one small all-reduce the masked restriction adds per cycle (taken as 40 us
-  // over RCCL): saving = (1 - largest box / grid, at the set-up's smoother degree) x (2 deg + 1) passes x the first grid's
-  // half-precision operator bytes at 4 TB/s, required to be 1.5 x the cost -- e.g. a 55^3 grid of 27-point 3 x 3 stencils
-  // (config C4's size on 8 ranks with spacing 4 h) with boxes of 22 %: 110 us saved.  GLIMS_MG_BOX_MIN_NODES (test hook)
-  // replaces the estimate by a plain size threshold so that small test meshes take the path.
-  mg.boxed = false;
-  mg.box_fraction = 1.0;
-  if (framed && h->world > 1 && mg.lv.size() >= 2 && (h->opt.flags & GLIMS_FLAG_MG_WHOLE_GRID) == 0) {
-    const char* e = getenv("GLIMS_MG_BOX_MIN_NODES");
-    const long long min_nodes = e ? std::max(6001ll, atoll(e)) : 0;
-    const int deg0 = BS == 1 ? (h->opt.rd_mg_smooth > 0 ? h->opt.rd_mg_smooth : (lattice ? 1 : 3)) : std::max(1, h->opt.mg_smooth);
-    const MgGrid& g = mg.lv[0]->g;
-    double worst = 0.0;
-    MgHierarchy probe;   // (only core / R are read)
-    probe.R = mg.R;
-    for (int q = 0; q < h->world; ++q) {
-      for (int a = 0; a < 6; ++a) probe.core[a] = all_cores[(size_t)q * 6 + a];
-      const BoxDev b = mg_work_box<D>(probe, g, deg0);
-      const double f = b.nn ? (double)b.nn / (double)g.nn : 1.0;
-      worst = std::max(worst, f);
-      if (q == h->rank) mg.box_fraction = f;
-    }
-    const double saved_us = (1.0 - worst) * (2.0 * deg0 + 1.0) * (double)g.nn * mg.S * B2 * 2.0 / 4.0e6;
-    mg.boxed = g.nn > 6000 && (min_nodes ? g.nn >= min_nodes && worst <= 0.8 : saved_us >= 60.0);
-    if (!mg.boxed) mg.box_fraction = 1.0;
-    // per-rank operator entries: the box's share of the first grid
-    mg.entries -= (int64_t)((1.0 - mg.box_fraction) * (double)mg.S * B2 * (double)g.nn);
-    // the first-grid residual by neighbour exchange (GridExchange): regions from the cores every rank holds
-    mg.gx.reset();
-    if (mg.boxed) {
-      GridExchange& x = mg.gx;
-      x.deg = deg0;
-      auto box_of = [&](int q, int* lo, int* hi) {   // work box of rank q, inclusive (whole grid if mg_work_box says so)
-        for (int a = 0; a < 6; ++a) probe.core[a] = all_cores[(size_t)q * 6 + a];
-        const BoxDev b = mg_work_box<D>(probe, g, deg0);
-        const int l3[3] = {b.lo0, b.lo1, b.lo2}, n3[3] = {b.n0, b.n1, b.n2};
-        for (int a = 0; a < 3; ++a) {
-          lo[a] = b.nn ? l3[a] : 0;
-          hi[a] = b.nn ? l3[a] + n3[a] - 1 : g.n[a] - 1;
-        }
-      };
-      auto cut = [&](const int* blo, const int* bhi, int q, GridRegion* out) {   // box n core_q
-        long long vol = 1;
-        for (int a = 0; a < 3; ++a) {
-          const int lo = std::max(blo[a], all_cores[(size_t)q * 6 + a]), hi = std::min(bhi[a], all_cores[(size_t)q * 6 + 3 + a]);
-          out->lo[a] = lo;
-          out->n[a] = hi - lo + 1;
-          if (hi < lo) return 0ll;
-          vol *= out->n[a];
-        }
-        out->rank = q;
-        return vol;
-      };
-      int mylo[3], myhi[3];
-      box_of(h->rank, mylo, myhi);
-      std::vector<GridRegion> sreg, rreg;
-      x.send_ptr.assign(1, 0);
-      x.recv_ptr.assign(1, 0);
-      for (int q = 0; q < h->world; ++q) {
-        if (q == h->rank) continue;
-        GridRegion rs, rr;
-        int qlo[3], qhi[3];
-        box_of(q, qlo, qhi);
-        const long long vs = cut(qlo, qhi, h->rank, &rs);   // what q needs of my partial sums: box_q n core_me
-        const long long vr = cut(mylo, myhi, q, &rr);        // what I need of q's: box_me n core_q
-        if (vs == 0 && vr == 0) continue;
-        x.peers.push_back(q);
-        if (vs > 0) {
-          rs.rank = q;
-          rs.off = x.n_send;
-          sreg.push_back(rs);
-          x.n_send += vs;
-        }
-        if (vr > 0) {
-          rr.off = x.n_recv;
-          rreg.push_back(rr);
-          x.n_recv += vr;
-        }
-        x.send_ptr.push_back(x.n_send);
-        x.recv_ptr.push_back(x.n_recv);
-      }
-      x.n_send_reg = (int)sreg.size();
-      x.n_recv_reg = (int)rreg.size();
-      if (!sreg.empty()) x.send_reg.upload(sreg, h->st);
-      if (!rreg.empty()) x.recv_reg.upload(rreg, h->st);
-      x.sendbuf.alloc((size_t)std::max<long long>(1, x.n_send) * BS);
-      x.recvbuf.alloc((size_t)std::max<long long>(1, x.n_recv) * BS);
-      GL_HIP(hipStreamSynchronize(h->st));
-      x.ready = true;
-    }
-  }
   mg.complexity = 1.0 + (double)mg.entries / ((double)p.total_entries * B2);
   mg.ms_setup = 1e3 * (omp_get_wtime() - t_start);
   if (getenv("GLIMS_VERBOSE")) {
@@ -2032,6 +2191,8 @@ void mg_apply_t(glims_ctx* h, MgHierarchy& mg, int deg, const double* r, double*
   const int64_t n = h->n_own;
   const uint8_t* fx = mg.op_fixed;
   const double* r_full = r;
+  GL_REQUIRE(!(mg.lv[0]->sb_nn && deg > mg.gx.deg),
+             "multigrid: the first grid's operator is stored for the work boxes of a lower smoother degree (rebuild the hierarchy)");
   Cheb ch(mg.lam0, mg.cheb_ratio);
   double c1, c2;
   ch.next(0, &c1, &c2);

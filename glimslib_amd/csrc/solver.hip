@@ -625,6 +625,8 @@ inline unsigned grid_exact(int64_t n, int bs = 256) { return (unsigned)((n + bs 
 // `prepacked`: the kernel that produced `vec` has written the send buffer already (PackMap)
 static void halo_start(glims_ctx* h, double* vec, int bs, bool prepacked = false) {
   if (h->world <= 1 || h->n_peers == 0) return;
+  h->stats.halo_exchanges++;
+  h->stats.halo_bytes += h->n_send * bs * (int64_t)sizeof(double);
   if (h->n_send > 0 && !prepacked) {
     hipLaunchKernelGGL(k_pack, dim3(grid_exact(h->n_send * bs)), dim3(256), 0, h->st, h->n_send, bs,
                        h->send_idx.p, vec, h->sendbuf.p);
@@ -639,6 +641,8 @@ static void halo_start(glims_ctx* h, double* vec, int bs, bool prepacked = false
   GL_HIP(hipEventRecord(h->ev_pack, h->st));
   GL_HIP(hipStreamWaitEvent(h->st_comm, h->ev_pack, 0));
   GL_REQUIRE(h->comm_halo, "world > 1 but no communicator: call glims_comm_init or glims_set_transport");
+  hipEvent_t* ce = h->comm_pair();   // glims_options.time_kernels: the exchange's duration on the communication stream
+  if (ce) GL_HIP(hipEventRecord(ce[0], h->st_comm));
   GL_NCCL(ncclGroupStart());
   for (int p = 0; p < h->n_peers; ++p) {
     const int64_t ns = h->send_ptr[p + 1] - h->send_ptr[p], nr = h->recv_ptr[p + 1] - h->recv_ptr[p];
@@ -650,11 +654,17 @@ static void halo_start(glims_ctx* h, double* vec, int bs, bool prepacked = false
                        h->comm_halo, h->st_comm));
   }
   GL_NCCL(ncclGroupEnd());
+  if (ce) GL_HIP(hipEventRecord(ce[1], h->st_comm));
   GL_HIP(hipEventRecord(h->ev_halo, h->st_comm));
 }
 static void halo_finish(glims_ctx* h) {
   if (h->world <= 1 || h->n_peers == 0 || h->tr_halo) return;
+  // ... and how long the compute stream really waits for it (what the interior slices did not hide): an event before the
+  // wait and one after it
+  hipEvent_t* we = h->wait_pair();
+  if (we) GL_HIP(hipEventRecord(we[0], h->st));
   GL_HIP(hipStreamWaitEvent(h->st, h->ev_halo, 0));
+  if (we) GL_HIP(hipEventRecord(we[1], h->st));
 }
 void gl_halo_exchange(glims_ctx* h, double* vec, int bs) {
   halo_start(h, vec, bs);
@@ -664,6 +674,8 @@ void gl_exchange(glims_ctx* h, const std::vector<int32_t>& peers, const std::vec
                  const std::vector<int64_t>& recv_ptr, const double* sendbuf, double* recvbuf, int bs) {
   const int np = (int)peers.size();
   if (h->world <= 1 || np == 0) return;
+  h->stats.halo_exchanges++;
+  h->stats.halo_bytes += send_ptr[np] * bs * (int64_t)sizeof(double);
   if (h->tr_halo) {
     const int rc = h->tr_halo(h->tr_user, sendbuf, send_ptr.data(), recvbuf, recv_ptr.data(), np, peers.data(), bs, (void*)h->st);
     if (rc != 0) throw glims_error(GLIMS_E_RCCL, "transport halo callback failed (" + std::to_string(rc) + ")");
@@ -689,7 +701,10 @@ void gl_halo_finish(glims_ctx* h) { halo_finish(h); }
 // Sum over ranks of the values reduce_partials / k_reduce_cg just left in `dev` (= h->red).  With the node mailbox
 // the final reduction block has already done it.
 static void allreduce_sum(glims_ctx* h, double* dev, int n) {
-  if (h->world <= 1 || h->nm.slots) return;
+  if (h->world <= 1) return;
+  h->stats.allreduces++;
+  h->stats.reduce_transport = h->nm.slots ? 1 : h->tr_allreduce ? 3 : 2;
+  if (h->nm.slots) return;
   if (h->tr_allreduce) {
     const int rc = h->tr_allreduce(h->tr_user, dev, n, (void*)h->st);
     if (rc != 0) throw glims_error(GLIMS_E_RCCL, "transport allreduce callback failed (" + std::to_string(rc) + ")");
@@ -820,6 +835,10 @@ void gl_mg_setup_mech(glims_ctx* h) {
   h->stats.mg_levels = mg.n_levels;
   h->stats.mg_complexity = mg.complexity;
   h->stats.ms_mg_setup = mg.ms_setup;
+  if (!mg.lv.empty()) {
+    const MgLevel& L = *mg.lv[0];
+    h->stats.mg_grid1_bytes = (int64_t)(L.half ? L.A16.n * sizeof(uint16_t) : L.A.n * sizeof(float));
+  }
 }
 
 // RD block: the hierarchy is built ONCE per glims_setup on the static part S = (1 - dt rho) M + dt K_D of the Newton
@@ -1184,10 +1203,30 @@ void glims_ctx::timing_begin() {
     tev_cat.assign(tev.size() / 2, 0);
     for (hipEvent_t& e : tev) GL_HIP(hipEventCreate(&e));
   }
+  if (opt.time_kernels && world > 1 && cev.empty()) {
+    cev.resize(8192);
+    wev.resize(8192);
+    for (hipEvent_t& e : cev) GL_HIP(hipEventCreate(&e));
+    for (hipEvent_t& e : wev) GL_HIP(hipEventCreate(&e));
+  }
   tev_used = 0;
+  cev_used = wev_used = 0;
 }
 
 void glims_ctx::timing_collect() {
+  if (cev_used >= 2 || wev_used >= 2) {   // partitioned run: exchange durations (communication stream) and exposed waits
+    if (wev_used >= 2) GL_HIP(hipEventSynchronize(wev[wev_used - 1]));
+    if (cev_used >= 2) GL_HIP(hipEventSynchronize(cev[cev_used - 1]));
+    for (size_t q = 0; q + 1 < cev_used; q += 2) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, cev[q], cev[q + 1]) == hipSuccess) stats.ms_exchange += t;
+    }
+    for (size_t q = 0; q + 1 < wev_used; q += 2) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, wev[q], wev[q + 1]) == hipSuccess) stats.ms_exchange_exposed += t;
+    }
+    cev_used = wev_used = 0;
+  }
   if (tev_used < 2) return;
   // launches that the decision word turned into no-ops last a few microseconds: leave them out of sums and medians
   std::vector<float> d[TK_COUNT];
@@ -1530,7 +1569,7 @@ int gl_solve_mechanics(glims_ctx* h, const double* c_dev) {
   const int mh_depth = std::max(0, std::min((int)glims_ctx::MHIST, h->opt.mech_history));
   if (h->mh_next >= std::max(1, mh_depth)) h->mh_count = h->mh_next = 0;   // the depth option shrank
   const double t_wall0 = omp_get_wtime();
-  if (h->opt.time_kernels == 3) h->timing_begin();
+  if (h->opt.time_kernels) h->timing_begin();   // (kernel pairs: time_kernels = 3 only; exchange pairs of a partitioned run: any)
   // preconditioner of the constrained operator: one multigrid V-cycle (built on first use, K_el does not change in
   // time) or block-Jacobi
   const bool use_mg = h->opt.mech_precond == GLIMS_PRECOND_MULTIGRID;
@@ -1758,7 +1797,7 @@ int gl_solve_mechanics(glims_ctx* h, const double* c_dev) {
   gl_halo_exchange(h, h->U.p, bs);
   GL_HIP(hipStreamSynchronize(h->st));
   h->stats.ms_mech += 1e3 * (omp_get_wtime() - t_wall0);
-  if (h->opt.time_kernels == 3) h->timing_collect();
+  if (h->opt.time_kernels) h->timing_collect();
   return cs;
 }
 
