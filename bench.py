@@ -265,11 +265,11 @@ def alt_unstructured(Handle, device, steps=10, warmup=2, n_points=1000000):
           s['ms_spmv_steps'], s['n_spmv_steps'], s['us_spmv_median'], steps, 1e3 * el / steps,
           "HIP events inside the %d timed steps" % steps)
     where = "HIP events in a separate pass of %d steps right after the timed ones" % k_steps
-    entry("k_rd_assemble<4, ...>", "Jacobian + Newton residual(s) in one sweep over the (row, cell) incidences "
+    entry("k_rd_assemble_s<4, CAP, RB, 1, double> (one launch per slice class)", "Jacobian + Newton residual(s) in one sweep over the (row, cell) incidences "
           "(algorithmic bytes: 12 per incidence + 20 per stored entry + 32 per row; unpadded counts)",
           12 * s['n_corners'] + 20 * s['nnz'] + 32 * s['n_rows'],
           k['ms_sweep_steps'], k['n_sweep_steps'], k['us_sweep_median'], k_steps, kms, where)
-    entry("k_rd_quad<4, ...>", "Newton residual from the quadratic structure (algorithmic bytes: 8 per incidence + 4 per "
+    entry("k_rd_quad_s<4, CAP, RB, 1> (one launch per slice class)", "Newton residual from the quadratic structure (algorithmic bytes: 8 per incidence + 4 per "
           "stored entry + 24 per row)", 8 * s['n_corners'] + 4 * s['nnz'] + 24 * s['n_rows'],
           k['ms_quad_steps'], k['n_quad_steps'], k['us_quad_median'], k_steps, kms, where)
     entry("k_cg_update<1>", "PCG recurrence + vector update (96 B per row)", 96 * s['n_rows'],
@@ -490,7 +490,7 @@ def main():
     # a measurement of this run: only reported when this run's operator is the one the passes measured, and
     # `traffic_source` names the file.
     pmc, pmc_file = None, None
-    for cand in ("r03_f_pmc_c4.json", "r03_e_pmc_c4.json", "r03_d_pmc_c4.json", "r03_c_pmc_c4.json", "r03_b_pmc_c4.json", "r02_pmc_c4.json", "r01_pmc_c4.json"):
+    for cand in ("r04_a_pmc_c4.json", "r03_f_pmc_c4.json", "r03_e_pmc_c4.json", "r03_d_pmc_c4.json", "r03_c_pmc_c4.json", "r03_b_pmc_c4.json", "r02_pmc_c4.json", "r01_pmc_c4.json"):
         try:
             q = json.load(open(os.path.join(HERE, "profiles", cand)))
             if world == 1 and q["n_rows"] == st['n_rows'] and q["nnz"] == st['nnz']:
@@ -503,7 +503,11 @@ def main():
         if pmc is None:
             return None
         keys = [k for k in pmc["kernels"] if k.startswith(prefix)]
-        return pmc["kernels"][keys[0]]["hbm_bytes_per_launch"] if keys else None
+        if not keys:
+            return None
+        if prefix in ("k_rd_assemble", "k_rd_quad"):      # one launch per slice class: a sweep is the sum of them
+            return sum(pmc["kernels"][k]["hbm_bytes_per_launch"] for k in keys)
+        return pmc["kernels"][keys[0]]["hbm_bytes_per_launch"]
 
     traffic = pmc_bytes("k_spmv<1" if (in_step or post_pass) else "k_spmv<0")
     steps_n = max(1, steps_done)

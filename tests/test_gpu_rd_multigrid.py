@@ -206,6 +206,47 @@ def test_delaunay_mesh_with_a_stiff_step(backend):
         assert st['rd_precond_used'] == backend.RD_PRECOND_JACOBI
 
 
+def test_brain_like_mesh_with_stiff_steps(backend):
+    """The quality-controlled unstructured mesh (workloads.config_brain_like: jittered-lattice Delaunay tetrahedra, the
+    stand-in for the CGAL atlas meshes): off-lattice, 125-point coarse stencils, but bounded node spacing and cell quality --
+    there the auxiliary-grid hierarchy keeps the lattice's iteration count (4-5 per Newton solve; a Delaunay mesh of random
+    points, slivers included, needs ~40).  Reduced size against the oracle's Newton + sparse LU, then at 200 k nodes against
+    the Jacobi path with the iteration counts asserted."""
+    w = workloads.config_brain_like(12000, workers=2)
+    t = dict(w.tables)
+    t['D'] = [3000.0 * d for d in w.tables['D']]                          # dt D / h^2 of 50-300 at a node spacing of ~9 mm
+    c0 = np.exp(-0.002 * ((w.mesh.points - np.array([118.0, -109.0, 72.0])) ** 2).sum(axis=1))
+    per = {k: np.asarray(v)[w.cell_label] for k, v in t.items()}
+    o = OracleTumorGrowth(w.mesh.points, w.mesh.cells, per['D'], per['rho'], per['gamma'], per['E'], per['nu'], 1.0)
+    co = c0.copy()
+    for _ in range(2):
+        co, _ = o.rd_step(co)
+    for pre in (backend.RD_PRECOND_MULTIGRID, backend.RD_PRECOND_JACOBI):
+        h = _handle(backend, w.mesh, w.cell_label, t, rd_precond=pre)
+        h.setup(False)
+        h.set_state(c0)
+        assert h.step(2) == 0
+        assert rel_l2(h.get_state(want_u=False)[0], co) < 1e-9
+        h.close()
+    # 200 k nodes, diffusivities x 300 (the stiff case of tools/run_rd_precond.py)
+    w = workloads.config_brain_like(200000)
+    t = dict(w.tables)
+    t['D'] = [300.0 * d for d in w.tables['D']]
+    res = {}
+    for pre in (backend.RD_PRECOND_MULTIGRID, backend.RD_PRECOND_JACOBI):
+        h = _handle(backend, w.mesh, w.cell_label, t, rd_precond=pre)
+        h.setup(False)
+        h.set_state(w.c0)
+        assert h.step(3) == 0
+        st = h.stats()
+        res[pre] = (h.get_state(want_u=False)[0], st['cg_its'] / st['newton_its'], st['rd_mg_levels'])
+        h.close()
+    mg_its, j_its = res[backend.RD_PRECOND_MULTIGRID][1], res[backend.RD_PRECOND_JACOBI][1]
+    print("brain-like mesh, 200 k nodes, D x 300: PCG its per Newton solve multigrid %.1f, Jacobi %.1f" % (mg_its, j_its))
+    assert rel_l2(res[backend.RD_PRECOND_MULTIGRID][0], res[backend.RD_PRECOND_JACOBI][0]) < 1e-9
+    assert mg_its <= 8.0 and mg_its < 0.4 * j_its
+
+
 # ---- partitioned: the RD hierarchy on the global frame (replicated coarse levels) through the transport hook -------------
 def _free_port():
     s = socket.socket()
