@@ -337,8 +337,16 @@ def config_brain_like(n_points=1000000, mechanics=False, jitter=0.3, seed=0, wor
     already initialised the GPU runtime, e.g. bench.py after its timed region.
     """
     from .mesh import Mesh
-    if isolate:
-        import os
+    import os
+    # GLIMS_MESH_CACHE=<dir>: the mesh is read from / written to <dir>/brain_like_<args>.npz.  Needed under a profiler, whose
+    # preloaded library has initialised the GPU before this program starts: neither a child interpreter nor forked workers
+    # may be started from such a process (tools/collect_profiles.sh fills the cache in an un-profiled step first).
+    cache = os.environ.get("GLIMS_MESH_CACHE")
+    cfile = os.path.join(cache, "brain_like_%d_%g_%d.npz" % (int(n_points), float(jitter), int(seed))) if cache else None
+    if cfile and os.path.exists(cfile):
+        z = np.load(cfile)
+        pts, cells = z["points"], z["cells"]
+    elif isolate:
         import subprocess
         import sys
         import tempfile
@@ -351,6 +359,9 @@ def config_brain_like(n_points=1000000, mechanics=False, jitter=0.3, seed=0, wor
             pts, cells = np.load(os.path.join(d, "p.npy")), np.load(os.path.join(d, "c.npy"))
     else:
         pts, cells = brain_like_mesh(n_points, jitter, seed, workers)
+    if cfile and not os.path.exists(cfile):
+        os.makedirs(cache, exist_ok=True)
+        np.savez(cfile, points=pts, cells=cells)
     mesh = Mesh(pts, cells)
     label = _brain_like_labels(mesh.cell_midpoints())
     tables = dict(D=[0.0, 0.0, 0.01, 0.05, 0.0], rho=[0.0, 0.0, 0.05, 0.05, 0.0],
