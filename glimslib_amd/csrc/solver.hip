@@ -981,10 +981,13 @@ static void apply_with_halo(glims_ctx* h, const CgVecs& v) {
   // interior slices overlap with the xGMI transfer; boundary slices run once the ghosts have landed
   halo_start(h, v.u, v.bs, /*prepacked=*/v.mg == nullptr);
   const int nbi = p.n_interior > 0 ? gl_spmv_grid(p.n_interior) : 0;   // partial-sum slots of the interior launch
-  if (v.vals)
+  if (v.vals) {
+    // (glims_options.time_kernels: the interior launch carries the event pair -- the part of the operator pass that hides
+    //  the exchange)
+    hipEvent_t* ev = h->timing(glims_ctx::TK_SPMV) ? h->pair(glims_ctx::TK_SPMV) : nullptr;
     gl_launch_spmv(h, h->st, p.n_interior, p.interior_slices.p, v.vals, v.u, v.w, v.fixed, nullptr, v.r,
-                   h->partials.p, 0, h->done.p, v.vals32);
-  else
+                   h->partials.p, 0, h->done.p, v.vals32, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr);
+  } else
     gl_launch_spmv_block(h, h->st, p.n_interior, p.interior_slices.p, v.u, v.w, v.fixed, v.r, h->partials.p, 0,
                          h->done.p, v.k32);
   halo_finish(h);
