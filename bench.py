@@ -298,6 +298,9 @@ def main():
     ap.add_argument("--fp32-jacobian", type=int, default=0,
                     help="1: GLIMS_FLAG_FP32_JACOBIAN (study runs only; the line then says dtype f64/f32-jacobian)")
     ap.add_argument("--warm-start", type=int, default=None, help="override GLIMS_FLAG_WARM_START (tuning runs only)")
+    ap.add_argument("--fixed-forcing", type=int, default=0,
+                    help="1: GLIMS_FLAG_FIXED_FORCING, cg_rtol for every linear solve (A/B against the default forcing that "
+                         "follows the quadratic remainder from a step's second solve on)")
     ap.add_argument("--full-newton", type=int, default=0,
                     help="1: GLIMS_FLAG_FULL_NEWTON, a sweep after every linear solve (A/B against the default, which takes "
                          "the residual after a solve from the quadratic structure)")
@@ -394,6 +397,8 @@ def main():
         flags |= 4
     if args.full_newton:
         flags |= 128
+    if args.fixed_forcing:
+        flags |= 256
     # HIP events around the Krylov SpMV launches of the timed steps (the dominant kernel's in-step roofline figure)
     h.set_options(dt=w.dt, flags=flags, time_kernels=1, **extra)
     # coupled configs (C5): the displacement is solved after EVERY step, as the reference's monolithic solve does; the

@@ -25,6 +25,7 @@ FLAG_INT32_COLUMNS = 16
 FLAG_MG_FP64_VECTORS = 32
 FLAG_MG_WHOLE_GRID = 64
 FLAG_FULL_NEWTON = 128
+FLAG_FIXED_FORCING = 256
 PRECOND_BLOCK_JACOBI, PRECOND_MULTIGRID = 0, 1
 RD_PRECOND_AUTO, RD_PRECOND_JACOBI, RD_PRECOND_MULTIGRID = 0, 1, 2
 ABI_VERSION = 5

@@ -37,8 +37,11 @@ def test_no_more_newton_iterations_and_fewer_sweeps_same_fields(backend):
     than the full-Newton path, mid-step sweeps replaced by cheap passes, fields equal to solver tolerance, and equal to the
     oracle's Newton + LU."""
     w = _c3_reduced(24)
-    s1, c1, st1 = _run(backend, w, w.tables, 12, backend.FLAG_WARM_START)
-    s2, c2, st2 = _run(backend, w, w.tables, 12, backend.FLAG_WARM_START | backend.FLAG_FULL_NEWTON)
+    # (fixed forcing term: every solve to cg_rtol, i.e. steps of three to four Newton iterations with evaluations in the
+    #  middle of a step -- the regime the cheap residuals were built for; the default forcing is compared at the end)
+    ff = backend.FLAG_FIXED_FORCING
+    s1, c1, st1 = _run(backend, w, w.tables, 12, backend.FLAG_WARM_START | ff)
+    s2, c2, st2 = _run(backend, w, w.tables, 12, backend.FLAG_WARM_START | backend.FLAG_FULL_NEWTON | ff)
     assert s1 == 0 and s2 == 0
     print("quadratic updates: Newton %d, PCG %d, sweeps %d, cheap passes %d | full Newton: %d, %d, %d, %d" %
           (st1['newton_its'], st1['cg_its'], st1['rd_assemblies'], st1['rd_quad_updates'],
@@ -55,6 +58,15 @@ def test_no_more_newton_iterations_and_fewer_sweeps_same_fields(backend):
     for _ in range(12):
         co, _ = o.rd_step(co)
     assert rel_l2(c1, co) < 1e-8
+    # default options: from a step's second solve on the linear tolerance follows the quadratic remainder -- fewer Newton
+    # iterations (a step is first solve, sweep, second solve, confirming sweep), the same fields
+    s3, c3, st3 = _run(backend, w, w.tables, 12, backend.FLAG_WARM_START)
+    print("default forcing: Newton %d, PCG %d, sweeps %d, cheap passes %d" %
+          (st3['newton_its'], st3['cg_its'], st3['rd_assemblies'], st3['rd_quad_updates']))
+    assert s3 == 0 and rel_l2(c3, co) < 1e-8 and rel_l2(c3, c1) < 1e-9
+    # (on this small, coarse problem the tighter second solves cost Krylov iterations -- 242 against 208 -- for one Newton
+    #  iteration less; at the sizes bench.py times, both counts drop: brain-like mesh 4.0 -> 2.25 / 39 -> 30 per step)
+    assert st3['newton_its'] <= st1['newton_its'] and st3['cg_its'] <= 1.25 * st1['cg_its']
 
 
 @pytest.mark.parametrize("dim", [2, 3])

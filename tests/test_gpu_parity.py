@@ -437,22 +437,32 @@ def test_baseline_configs_complete_runs_match_the_c_oracle(backend, name):
     w = workloads.by_name(name)
     co = COracle(w.mesh.points, w.mesh.cells, w.per_cell('D'), w.per_cell('rho'), w.dt)
     ref = co.step(w.c0, w.n_steps, rtol=1e-11, cg_rtol=1e-4)
+    # Default options, then GLIMS_FLAG_FIXED_FORCING (every linear solve to cg_rtol: steps of three to four Newton iterations,
+    # which is where the midpoint correction of a step's first right-hand side switches on).  Between them the two runs
+    # exercise every path the Newton iteration can take -- residuals from the quadratic structure, adaptive forcing, the
+    # midpoint correction -- and both must land on the oracle's field.
     h = _handle(backend, w.mesh, w.cell_label, w.dt, w.tables, mechanics=False)
-    h.set_state(w.c0)
-    assert h.step(w.n_steps) == 0
-    c = h.get_state(want_u=False)[0]
-    err = rel_l2(c, ref)
-    st = h.stats()
-    print("%s: %d steps, rel-L2 vs C oracle %.2e; Newton %d, sweeps %d, cheap residuals %d, midpoint-corrected steps %d, "
-          "rebase events %d" % (name, w.n_steps, err, st['newton_its'], st['rd_assemblies'], st['rd_quad_updates'],
-                                st['midpoint_steps'], st['rebase_events']))
-    assert err < 1e-8
-    assert st['steps'] == w.n_steps
+    counts = {}
+    for fixed in (False, True):
+        h.set_options(dt=w.dt, flags=backend.FLAG_WARM_START | (backend.FLAG_FIXED_FORCING if fixed else 0))
+        h.set_state(w.c0)
+        h.reset_stats()
+        assert h.step(w.n_steps) == 0
+        c = h.get_state(want_u=False)[0]
+        err = rel_l2(c, ref)
+        st = h.stats()
+        counts[fixed] = st
+        print("%s%s: %d steps, rel-L2 vs C oracle %.2e; Newton %d, PCG %d, sweeps %d, cheap residuals %d, midpoint-corrected "
+              "steps %d, rebase events %d" % (name, " (fixed forcing)" if fixed else "", w.n_steps, err, st['newton_its'],
+                                              st['cg_its'], st['rd_assemblies'], st['rd_quad_updates'], st['midpoint_steps'],
+                                              st['rebase_events']))
+        assert err < 1e-8
+        assert st['steps'] == w.n_steps
     if name == "c3":
-        # the full-length run exercises every path of the Newton iteration the default options can take: residuals from
-        # the quadratic structure AND the midpoint correction of a step's first right-hand side (it switches on after a
-        # step that needed four iterations) -- the comparison above holds with both engaged
-        assert st['rd_quad_updates'] > 0 and st['midpoint_steps'] > 0
+        assert counts[False]['rd_quad_updates'] > 0
+        assert counts[True]['rd_quad_updates'] > 0 and counts[True]['midpoint_steps'] > 0
+        # the forcing that follows the quadratic remainder saves Newton iterations, not accuracy
+        assert counts[False]['newton_its'] < 0.8 * counts[True]['newton_its']
     h.close()
     co.close()
 
