@@ -490,6 +490,8 @@ struct glims_ctx {
   dvec<double> mh_rhs[MHIST], mh_x[MHIST], mh_w[MHIST];   // solve history: right-hand sides, solutions, K_el x (= rhs - final residual)
   int mh_count = 0, mh_next = 0;           // depth: glims_options.mech_history
   double mh_G[MHIST][MHIST] = {{0.0}};     // Gram matrix (rhs_k, rhs_l) of the stored right-hand sides (host copy)
+  dvec<double> ws_du;                                         // the increment of the step before the last (warm start, k_ws_delta)
+  int ws_depth = 0;                                           // ... 1 once it holds a real increment
   bool have_c_old = false;                                    // c_old holds the state at the start of the previous step
   bool pending = false;                                      // cg_r / b / vA already hold the first assembly of the next step
   double pending_r0 = 0.0;

@@ -494,11 +494,19 @@ __global__ void k_extrapolate(int64_t n, double* __restrict__ c, double* __restr
 }
 
 // warm start of a step's first Newton solve: u = c - c_old (the previous step's increment), c_old = c
-__global__ void k_ws_delta(int64_t n, const double* __restrict__ c, double* __restrict__ c_old, double* __restrict__ u) {
+// The step's predicted increment, extrapolated linearly in time from the last two: d1 = c - c_old is the increment of the step
+// just finished, du holds the one before it (second_order = 0 while only one is known): u = 2 d1 - du.  Measured against
+// u = d1 (interleaved runs, profiles/r04_warm_start_order_ab.txt): C4 12.7 -> 11.8 PCG iterations per step, 10.2-10.7 -> 9.9
+// ms; C3 17.95 -> 16.55, 1.60 -> 1.53 ms; brain-like mesh 29.65 -> 28.65.  A quadratic extrapolation (three increments) buys
+// C3 another 1.6 iterations and costs C4 0.1 ms: not taken.
+__global__ void k_ws_delta(int64_t n, const double* __restrict__ c, double* __restrict__ c_old, double* __restrict__ u,
+                           double* __restrict__ du, int second_order) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double ci = c[i];
-  u[i] = ci - c_old[i];
+  const double d1 = ci - c_old[i];
+  u[i] = second_order ? 2.0 * d1 - du[i] : d1;
+  du[i] = d1;
   c_old[i] = ci;
 }
 // r -= A u (w = A u), c += u
@@ -1390,10 +1398,12 @@ int gl_step(glims_ctx* h, int n_steps) {
                               hipMemcpyDeviceToDevice, h->st));
       }
       if (it == 0 && (o.flags & GLIMS_FLAG_WARM_START) && !extrapolate) {   // both options own the c_old buffer
-        // initial guess of the first linear solve = the previous step's total increment: same linear system, same
-        // solution, the Krylov iteration just starts closer.  One SpMV with the already assembled A(c^n).
+        // initial guess of the first linear solve = the increment predicted from the previous steps' (k_ws_delta): same linear
+        // system, same solution, the Krylov iteration just starts closer.  One SpMV with the already assembled A(c^n).
+        h->ws_du.alloc((size_t)h->n_nodes);
         hipLaunchKernelGGL(k_ws_delta, dim3(grid_exact(h->n_nodes)), dim3(256), 0, h->st, h->n_nodes, h->c.p,
-                           h->c_old.p, h->cg_u.p);
+                           h->c_old.p, h->cg_u.p, h->ws_du.p, (h->have_c_old && h->ws_depth >= 1) ? 1 : 0);
+        h->ws_depth = h->have_c_old ? 1 : 0;   // (ws_du holds a real increment from the second warm-started step on)
         if (h->have_c_old) {
           gl_launch_spmv(h, h->st, p.n_slices, nullptr, h->vA.p, h->cg_u.p, h->cg_w.p,
                          h->have_fixed_c ? h->fixed_c.p : nullptr, nullptr, nullptr, nullptr, 0, nullptr,

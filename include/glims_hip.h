@@ -156,7 +156,7 @@ typedef struct glims_options {
                                            the quadratic remainder the iteration is about to leave (q |R_k|^2 / |R_0|, q observed
                                            in the step's first iteration), so that a step of four iterations at three decades
                                            each becomes one of three (general meshes; lattice configs are unchanged) */
-#define GLIMS_FLAG_WARM_START 2         /* first linear solve of a step starts from the previous step's increment
+#define GLIMS_FLAG_WARM_START 2         /* first linear solve of a step starts from the increment extrapolated from the previous two steps'
                                            (ignored when GLIMS_FLAG_EXTRAPOLATE_GUESS is set) */
 
 typedef struct glims_stats {
