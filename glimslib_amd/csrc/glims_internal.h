@@ -26,7 +26,9 @@
 // Blocks are dealt to the 8 XCDs in chunks of this many consecutive logical blocks: neighbouring slices (overlapping x
 // gathers) share one L2 while the XCDs together still walk the matrix front to back (measured: time of the plain
 // mapping, fabric reads 2.21 -> 1.97 GB per SpMV at 10 M rows; contiguous eighths are 1-5 % slower).
-#define GL_XCD_CHUNK 64
+#define GL_XCD_CHUNK_DEFAULT 64
+int gl_xcd_chunk();   // GL_XCD_CHUNK_DEFAULT, or GLIMS_XCD_CHUNK from the environment (tuning runs)
+#define GL_XCD_CHUNK gl_xcd_chunk()
 
 struct glims_error : std::runtime_error {
   int code;
@@ -209,6 +211,11 @@ struct MgLevel {                           // one Cartesian level
   dvec<double> dinv;                       // [bs*bs][nn] inverse diagonal blocks
   dvec<double> x, x2, r, d, res;           // [bs][nn] (component-major)
   double lam = 1.0;                        // estimate of lambda_max(Dinv A)
+  // polynomial acceleration (mg_poly_setup): the system of this level is solved by poly_m steps of the Chebyshev iteration
+  // preconditioned with the V-cycle B from here down, for a spectrum of B A in [poly_a, poly_b]; 0: the plain V-cycle
+  int poly_m = 0;
+  double poly_a = 1.0, poly_b = 1.0;       // the interval: 0.7 x measured lambda_min(B A), 1.05 x max(1, measured lambda_max)
+  dvec<double> pd, pacc, pres;             // [bs][nn] direction, accumulated solution, spare residual buffer
 };
 // Neighbour exchange that replaces the all-reduce of the first grid's restricted residual in a box-limited partitioned
 // cycle: rank p needs the sum on its work box only, and rank q's partial sums are nonzero only on q's core, so p receives
@@ -344,11 +351,17 @@ static __device__ __forceinline__ int xcd_chunk_remap(int b, int nb, int G) {
   // Hardware deals block b to XCD b % 8.  Give every XCD chunks of G consecutive logical blocks, chunk after chunk
   // round-robin over the XCDs: neighbouring slices (overlapping x gathers) share one L2, while the eight XCDs
   // together still walk the matrix front to back (one shared, moving x window in the Infinity Cache; DRAM pages are
-  // visited nearly sequentially).  Blocks beyond the last full group of 8*G keep their index -> bijective.
+  // visited nearly sequentially).  The blocks beyond the last full group of 8*G form one more group with chunks of
+  // (what is left) / 8; the last < 8 blocks keep their index -> bijective.
   const int full = (nb / (8 * G)) * (8 * G);
-  if (b >= full) return b;
-  const int q = b >> 3, xcd = b & 7;
-  return ((q / G) * 8 + xcd) * G + (q % G);
+  if (b < full) {
+    const int q = b >> 3, xcd = b & 7;
+    return ((q / G) * 8 + xcd) * G + (q % G);
+  }
+  const int g2 = (nb - full) >> 3;
+  const int t = b - full;
+  if (t >= 8 * g2) return b;
+  return full + (t & 7) * g2 + (t >> 3);
 }
 
 // Level-0 cycle vectors of the elasticity multigrid.  XT = double: [node][BS] doubles.  XT = float (default): the

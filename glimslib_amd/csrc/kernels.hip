@@ -12,6 +12,15 @@
 #include <algorithm>
 #include <cmath>
 
+int gl_xcd_chunk() {
+  static const int g = [] {
+    const char* e = getenv("GLIMS_XCD_CHUNK");
+    const int v = e ? atoi(e) : 0;
+    return v >= 1 ? v : GL_XCD_CHUNK_DEFAULT;
+  }();
+  return g;
+}
+
 namespace {
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -757,7 +766,7 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_matfree(
   double* cn = lds + (size_t)max_len * GL_WAVE;
   double* xn = lds + (size_t)2 * max_len * GL_WAVE;
   const int lane = threadIdx.x;
-  const int s = slice_list[xcd_chunk_remap(blockIdx.x, gridDim.x, 4 * GL_XCD_CHUNK)];
+  const int s = slice_list[xcd_chunk_remap(blockIdx.x, gridDim.x, 4 * GL_XCD_CHUNK_DEFAULT)];
   const int64_t row = (int64_t)s * GL_WAVE + lane;
   const int64_t base = slice_ptr[s], cbase = cslice_ptr[s];
   const int len = (int)((slice_ptr[s + 1] - base) >> 6), clen = (int)((cslice_ptr[s + 1] - cbase) >> 6);
