@@ -36,7 +36,7 @@ export GLIMS_MESH_CACHE=/tmp/glims_mesh_cache
 python3 -c "import sys; sys.path.insert(0, '.'); from glimslib_amd import workloads; workloads.config_brain_like(1000000)"
 if [ $part = bench ] || [ $part = all ]; then
 # bench lines (un-profiled)
-python3 bench.py > $out/${tag}_c4_bench.json 2> $out/${tag}_c4_bench.log; echo "[collect] bench c4 done"
+python3 bench.py --steps 20 --warmup 5 > $out/${tag}_c4_bench.json 2> $out/${tag}_c4_bench.log; echo "[collect] bench c4 done (the driver's flags: --steps 20 --warmup 5)"
 python3 bench.py --workload c3 --steps 40 --warmup 5 --no-cpu-baseline --no-alt > $out/${tag}_c3_bench.json 2>/dev/null
 python3 bench.py --workload c5 --steps 20 --warmup 10 --no-cpu-baseline --no-alt > $out/${tag}_c5_bench.json 2>/dev/null
 python3 bench.py --workload c5 --size 215 --steps 10 --warmup 10 --no-cpu-baseline --no-alt > $out/${tag}_c5_10m_bench.json 2>/dev/null
@@ -48,7 +48,7 @@ echo "[collect] bench lines done"
 fi
 if [ $part = trace ] || [ $part = all ]; then
 
-trace c4 python3 bench.py --workload c4 --steps 10 --warmup 2 --no-cpu-baseline --no-alt
+trace c4 python3 bench.py --workload c4 --steps 20 --warmup 5 --no-cpu-baseline --no-alt
 trace bl python3 bench.py --workload bl --steps 10 --warmup 2 --no-cpu-baseline --no-alt
 trace c5 python3 bench.py --workload c5 --steps 20 --warmup 10 --no-cpu-baseline --no-alt
 ONLY=multigrid trace rdmg_c2 python3 tools/run_rd_precond.py 46
