@@ -722,9 +722,9 @@ def main():
                                               "oracle breaks at the same step (tests/test_gpu_parity.py::test_long_run_"
                                               "breakdown_...); handled as the reference does (warn, stop, return the last "
                                               "solution, simulation_base.py:301-305)",
-                                     "ms_per_step_mean_over_the_run": 10.4,
-                                     "ms_per_step_range_over_the_run": [8.5, 13.6],
-                                     "source": "profiles/r04_b_long_c4_run.txt (20-step windows of the 482 steps)"}
+                                     "ms_per_step_mean_over_the_run": 8.6,
+                                     "ms_per_step_range_over_the_run": [7.5, 12.3],
+                                     "source": "profiles/r04_c_long_c4_run.txt (20-step windows of the 482 steps)"}
                                     if (args.workload.lower() == "c4" and not args.n and not coupled) else None)},
             "roofline": roofline,
         }

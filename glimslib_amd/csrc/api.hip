@@ -517,6 +517,7 @@ int glims_set_state(glims_ctx* h, const double* c, const double* u) {
     // hierarchies and the preconditioner `auto` has settled on; they depend on the mesh and the parameters, not on the run.)
     h->mid_on = false;
     h->mid_cooldown = h->mid_streak = 0;
+    h->nw_mode = h->nw_hold = h->nw_since = h->nw_steps = 0;
     h->nq_first_ratio = 1e-3;
     h->nq_skip_steps = 0;
     for (int& hint : h->cg_hint) hint = 0;

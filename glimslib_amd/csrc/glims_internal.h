@@ -494,6 +494,9 @@ struct glims_ctx {
   double nq_first_ratio = 1e-3;                               // residual contraction of the last step's first Newton iteration
   bool mid_on = false;                                        // midpoint correction of the first right-hand side (gl_step)
   int mid_cooldown = 0, mid_streak = 0;
+  // default forcing: how a step's FIRST solve is run (gl_step).  0: tolerance 0.3 cg_rtol; 1: the same + midpoint correction;
+  // 2: cg_rtol, no correction (for nw_hold steps after a step that took three iterations even with the correction)
+  int nw_mode = 0, nw_hold = 0, nw_since = 0, nw_steps = 0;   // nw_steps: steps since glims_set_state
   int nq_skip_steps = 0;                                      // steps left without cheap evaluations (after a poor contraction)
   int cg_hint[8] = {0, 0, 0, 0, 0, 0, 0, 0};                  // PCG iterations of the k-th Newton solve of the previous step
   int mech_hint = 0;

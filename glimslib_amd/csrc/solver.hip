@@ -1338,8 +1338,24 @@ int gl_step(glims_ctx* h, int n_steps) {
     // it saves the step's fourth Newton iteration (config C4: steps 50-200 of the 500, 3.9 -> 3.3 iterations per step;
     // nothing in the first 50).  So it is switched on after a step that took four, off again (for 16 steps) after a step
     // that took four WITH it, and every 16th step runs without it to see whether three are reached anyway.
-    const bool mid_probe = h->mid_on && (++h->mid_streak % 16) == 0;
-    const bool midpoint = quad && h->mid_on && !mid_probe;
+    // Default forcing (round 4): the FIRST solve of a step decides whether two Newton iterations can be enough.  With the
+    // second solve's Jacobian at c_1, two iterations leave q_2 (r_1 / r_0)^2 r_0, q_2 = what the quadratic term alone leaves of
+    // a whole step (5e-4 late in config C4's run) -- below the Newton target 1e-10 r_0 only if r_1 <= 4e-4 r_0, i.e. with the
+    // first solve at 0.3 cg_rtol instead of cg_rtol (+0-1 PCG iterations) AND a first residual not dominated by the quadratic
+    // term.  Early in a run (small increments) the tolerance alone does it (mode 0: C4 steps 5-25 2.4 -> 2.1 iterations per
+    // step, 9.50 -> 9.37 ms; brain-like mesh 2.74 -> 2.65; C3 1.50 -> 1.46); later the quadratic term has to go too, which is
+    // what the midpoint correction of the first right-hand side does with the extrapolated increment (mode 1, one cheap pass:
+    // C4 steps 120-160 three solves -> two, 8.89 -> 8.19 ms; steps 300-340 9.38 -> 8.71; C3 1.51 -> 1.29; brain-like mesh
+    // 3.00 -> 2.70; profiles/r04_ab_midpoint.txt).  Either one alone is a loss there (tolerance alone: a third sweep, 9.67 ms;
+    // correction alone: 9.39).  The mode follows the outcome: 0 until a step takes three iterations, then 1; a step that
+    // takes three WITH the correction sends the next 16 back to cg_rtol without it (mode 2: strong nonlinearity, where the
+    // extra effort buys nothing); every 64th step in mode 1 tries mode 0 again.  GLIMS_FLAG_FIXED_FORCING keeps round 3's rules:
+    // cg_rtol, and the correction switched on by steps of four iterations.
+    const bool fixed_forcing = (o.flags & GLIMS_FLAG_FIXED_FORCING) != 0;
+    const int nw_mode = (quad && !fixed_forcing) ? h->nw_mode : 2;
+    const bool mid_probe = fixed_forcing && h->mid_on && (++h->mid_streak % 16) == 0;
+    const bool midpoint = quad && (fixed_forcing ? (h->mid_on && !mid_probe) : nw_mode == 1);
+    const double first_rtol = (quad && !fixed_forcing && nw_mode != 2) ? 0.3 * o.cg_rtol : o.cg_rtol;
     bool base_is_current = true, ck_is_c0 = false;
     // (margin 3: with 1 the cheap pass reported convergence unpredicted -- pass + confirming sweep -- in 14-28 % of the steps
     //  of C4 / C3, with 3 in 2 %; with 10 the failed confirmations are back)
@@ -1374,7 +1390,8 @@ int gl_step(glims_ctx* h, int n_steps) {
       const bool adaptive_forcing = (o.flags & GLIMS_FLAG_FIXED_FORCING) == 0 && it >= 1;
       const double floor_pred = std::min(0.5, std::max(1e-6, h->nq_first_ratio)) * nr * (nr / std::max(r0, 1e-300));
       const double tol_lin = std::max(std::max(o.cg_atol, 0.5 * target),
-                                      adaptive_forcing ? std::min(o.cg_rtol * nr, 0.3 * floor_pred) : o.cg_rtol * nr);
+                                      adaptive_forcing ? std::min(o.cg_rtol * nr, 0.3 * floor_pred)
+                                                       : (it == 0 ? first_rtol : o.cg_rtol) * nr);
       // what this iteration is expected to leave: the linear residual plus the quadratic remainder
       const double pred_next = adaptive_forcing ? tol_lin + floor_pred : nr * std::min(0.5, std::max(1e-6, ratio_est));
       // Newton converges quadratically here (the nonlinearity is exactly quadratic): once the residual before the
@@ -1508,7 +1525,31 @@ int gl_step(glims_ctx* h, int n_steps) {
         break;
       }
     }
-    if (quad && status == GLIMS_OK) {
+    ++h->nw_steps;
+    // (the first steps of a run have no increments to extrapolate from and take three iterations whatever the mode: they do
+    //  not speak for it)
+    if (quad && status == GLIMS_OK && !fixed_forcing && h->nw_steps > 8) {
+      const int64_t count = h->stats.newton_its - newton0;
+      if (h->nw_mode == 0) {
+        // (one step in ten taking a third iteration is cheaper than the correction's pass on every step: two within a few)
+        h->nw_hold = count >= 3 ? h->nw_hold + 4 : std::max(0, h->nw_hold - 1);
+        if (h->nw_hold >= 6) {
+          h->nw_mode = 1;
+          h->nw_since = h->nw_hold = 0;
+        }
+      } else if (h->nw_mode == 1) {
+        if (count >= 3) {
+          h->nw_mode = 2;
+          h->nw_hold = 16;
+        } else if (++h->nw_since % 64 == 0) {
+          h->nw_mode = 0;
+          h->nw_hold = 0;
+        }
+      } else if (--h->nw_hold <= 0) {
+        h->nw_mode = 1;
+        h->nw_since = 0;
+      }
+    } else if (quad && status == GLIMS_OK && fixed_forcing) {
       const int64_t count = h->stats.newton_its - newton0;
       if (midpoint) {
         if (count >= 4) {

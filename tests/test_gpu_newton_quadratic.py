@@ -145,3 +145,25 @@ def test_a_second_run_on_the_same_handle_is_bitwise_the_run_of_a_fresh_handle(ba
     assert np.array_equal(c1, c3) and np.array_equal(u1, u3)      # run-to-run reproducibility of a fresh handle
     assert np.array_equal(c2, c3) and np.array_equal(u2, u3)      # the re-run
     assert s1["rd_quad_updates"] > 0
+
+
+def test_first_solve_controller_two_newton_iterations_per_step_through_a_long_run(backend):
+    """Default forcing: the first solve of a step runs at 0.3 cg_rtol, and once steps start taking a third iteration (the
+    quadratic term of a whole step no longer small: later in a run) its right-hand side gets the midpoint correction from
+    the extrapolated increment -- two Newton iterations per step where GLIMS_FLAG_FIXED_FORCING (round 3's rules) takes
+    three, the same fields.  BASELINE config C3 at full size, 170 steps (the config itself runs 50)."""
+    w = workloads.config_c3()
+    steps = 170
+    s1, c1, st1 = _run(backend, w, w.tables, steps, backend.FLAG_WARM_START)
+    s2, c2, st2 = _run(backend, w, w.tables, steps, backend.FLAG_WARM_START | backend.FLAG_FIXED_FORCING)
+    print("default: Newton %.2f, PCG %.2f per step, %d sweeps, %d cheap passes, %d steps with the midpoint correction | "
+          "fixed forcing: Newton %.2f, PCG %.2f, %d sweeps, %d cheap passes, %d" %
+          (st1['newton_its'] / steps, st1['cg_its'] / steps, st1['rd_assemblies'], st1['rd_quad_updates'], st1['midpoint_steps'],
+           st2['newton_its'] / steps, st2['cg_its'] / steps, st2['rd_assemblies'], st2['rd_quad_updates'], st2['midpoint_steps']))
+    assert s1 == 0 and s2 == 0
+    assert rel_l2(c1, c2) < 1e-9
+    assert st1['newton_its'] <= 2.15 * steps            # (the first steps of a run take three)
+    assert st2['newton_its'] >= 2.6 * steps
+    assert st1['cg_its'] <= 1.05 * st2['cg_its']        # (2.06 against 3.61 Newton iterations per step, 14.2 against 13.9 PCG)
+    assert st1['midpoint_steps'] >= 20                  # the late regime was reached and answered with the correction
+    assert st1['rd_assemblies'] <= 2.1 * steps
