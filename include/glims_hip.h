@@ -152,10 +152,12 @@ typedef struct glims_options {
 #define GLIMS_FLAG_INT32_COLUMNS 16       /* OFF by default.  Stream the 4-byte column indices everywhere instead of the 16-bit
                                            (window, offset) codes (same bits in every result; takes effect at glims_setup) */
 #define GLIMS_FLAG_FIXED_FORCING 256      /* OFF by default.  Every linear solve of the RD Newton iteration is asked for cg_rtol x
-                                           its right-hand side.  Default: from a step's second solve on the tolerance follows
-                                           the quadratic remainder the iteration is about to leave (q |R_k|^2 / |R_0|, q observed
-                                           in the step's first iteration), so that a step of four iterations at three decades
-                                           each becomes one of three (general meshes; lattice configs are unchanged) */
+                                           its right-hand side (and the midpoint correction of a step's first right-hand side is
+                                           switched on by steps of four iterations): round 3's rules.  Default: a step's FIRST
+                                           solve runs at 0.3 cg_rtol, with that correction once steps start taking a third
+                                           iteration; from the second solve on the tolerance follows the quadratic remainder the
+                                           iteration is about to leave (q |R_k|^2 / |R_0|, q observed in the step's first
+                                           iteration) -- two Newton iterations per step where the fixed rules take three to four */
 #define GLIMS_FLAG_WARM_START 2         /* first linear solve of a step starts from the increment extrapolated from the previous two steps'
                                            (ignored when GLIMS_FLAG_EXTRAPOLATE_GUESS is set) */
 
