@@ -283,8 +283,8 @@ def alt_unstructured(Handle, device, steps=10, warmup=2, n_points=1000000):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=os.environ.get("GLIMS_BENCH_WORKLOAD", "c4"))
     ap.add_argument("--size", "--n", dest="n", type=int, default=0,
                     help="cells per edge (overrides the workload's size); use --size under torchrun, which claims --n*")
