@@ -212,7 +212,7 @@ def alt_c5(Handle, device, steps=10, warmup=10):
     return out
 
 
-def alt_unstructured(Handle, device, steps=10, warmup=2, n_points=1000000):
+def alt_unstructured(Handle, device, steps=20, warmup=5, n_points=1000000):
     """The brain-like unstructured mesh (workloads.config_brain_like: ~1 M nodes, quality-controlled Delaunay tetrahedra,
     curved two-tissue interface, config C3's parameters) under the driver's clock -- the stand-in for the CGAL atlas
     meshes the reference's 3-D cases load (test_case_comparison_3D_atlas.py:84-121): ms per step, iterations, and the
