@@ -1347,9 +1347,11 @@ int gl_step(glims_ctx* h, int n_steps) {
     // what the midpoint correction of the first right-hand side does with the extrapolated increment (mode 1, one cheap pass:
     // C4 steps 120-160 three solves -> two, 8.89 -> 8.19 ms; steps 300-340 9.38 -> 8.71; C3 1.51 -> 1.29; brain-like mesh
     // 3.00 -> 2.70; profiles/r04_ab_midpoint.txt).  Either one alone is a loss there (tolerance alone: a third sweep, 9.67 ms;
-    // correction alone: 9.39).  The mode follows the outcome: 0 until a step takes three iterations, then 1; a step that
+    // correction alone: 9.39).  The mode follows the outcome: 0 until two steps within a few take three iterations (one step in ten
+    // doing so is cheaper than a pass on every step), then 1; a step that
     // takes three WITH the correction sends the next 16 back to cg_rtol without it (mode 2: strong nonlinearity, where the
-    // extra effort buys nothing); every 64th step in mode 1 tries mode 0 again.  GLIMS_FLAG_FIXED_FORCING keeps round 3's rules:
+    // extra effort buys nothing); every 64th step in mode 1 tries mode 0 again; the first 8 steps of a run do not count (no
+    // increments to extrapolate from yet).  GLIMS_FLAG_FIXED_FORCING keeps round 3's rules:
     // cg_rtol, and the correction switched on by steps of four iterations.
     const bool fixed_forcing = (o.flags & GLIMS_FLAG_FIXED_FORCING) != 0;
     const int nw_mode = (quad && !fixed_forcing) ? h->nw_mode : 2;
