@@ -26,9 +26,12 @@ FLAG_MG_FP64_VECTORS = 32
 FLAG_MG_WHOLE_GRID = 64
 FLAG_FULL_NEWTON = 128
 FLAG_FIXED_FORCING = 256
+FLAG_MG_NO_LUMPING = 512
 PRECOND_BLOCK_JACOBI, PRECOND_MULTIGRID = 0, 1
 RD_PRECOND_AUTO, RD_PRECOND_JACOBI, RD_PRECOND_MULTIGRID = 0, 1, 2
-ABI_VERSION = 5
+RD_LINEAR_AUTO, RD_LINEAR_PCG, RD_LINEAR_CHEBYSHEV = 0, 1, 2
+STREAM_AUTO, STREAM_NONTEMPORAL, STREAM_CACHED = 0, 1, 2
+ABI_VERSION = 6
 
 
 class BackendError(RuntimeError):
@@ -45,7 +48,8 @@ class Options(C.Structure):
                 ("mech_precond", C.c_int), ("mech_mixed", C.c_int), ("mech_history", C.c_int),
                 ("mg_smooth", C.c_int), ("mg_coarse_nodes", C.c_int), ("mg_h_factor", C.c_double),
                 ("mg_cheb_ratio", C.c_double), ("time_kernels", C.c_int),
-                ("rd_precond", C.c_int), ("rd_mg_smooth", C.c_int)]
+                ("rd_precond", C.c_int), ("rd_mg_smooth", C.c_int),
+                ("rd_linear", C.c_int), ("stream_policy", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -69,7 +73,11 @@ class Stats(C.Structure):
                 ("midpoint_steps", C.c_int64), ("rebase_events", C.c_int64),
                 ("halo_exchanges", C.c_int64), ("halo_bytes", C.c_int64), ("ms_exchange", C.c_double),
                 ("ms_exchange_exposed", C.c_double), ("allreduces", C.c_int64), ("reduce_transport", C.c_int64),
-                ("mg_grid1_bytes", C.c_int64)]
+                ("mg_grid1_bytes", C.c_int64),
+                ("halo_exchanges_timed", C.c_int64), ("cheb_solves", C.c_int64), ("cheb_its", C.c_int64),
+                ("cheb_fallbacks", C.c_int64), ("cheb_learn_solves", C.c_int64), ("cheb_lmin", C.c_double),
+                ("cheb_lmax", C.c_double), ("ms_cheb_steps", C.c_double), ("n_cheb_steps", C.c_int64),
+                ("us_cheb_median", C.c_double), ("stream_nontemporal", C.c_int64), ("krylov_working_set", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -114,6 +114,8 @@ int glims_options_default(glims_options* o) {
   o->time_kernels = 0;
   o->rd_precond = GLIMS_RD_PRECOND_AUTO;
   o->rd_mg_smooth = 0;
+  o->rd_linear = GLIMS_RD_LINEAR_AUTO;
+  o->stream_policy = GLIMS_STREAM_AUTO;
   return GLIMS_OK;
 }
 
@@ -147,6 +149,7 @@ int glims_create(glims_ctx** out, int dim, int64_t n_nodes, int64_t n_own, int64
     h->n_cells = n_cells;
     glims_options_default(&h->opt);
     std::memset(&h->stats, 0, sizeof(h->stats));
+    if (const char* e = getenv("GLIMS_CHEB_TEST_SCALE_HI")) h->cheb_test_hi = std::max(0.05, atof(e));   // test hook, per handle
     GL_HIP(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
     GL_HIP(hipStreamCreateWithFlags(&h->st_comm, hipStreamNonBlocking));
     GL_HIP(hipEventCreate(&h->ev_a));
@@ -362,6 +365,9 @@ int glims_set_options(glims_ctx* h, const glims_options* opt) {
     GL_REQUIRE(opt->rd_precond >= GLIMS_RD_PRECOND_AUTO && opt->rd_precond <= GLIMS_RD_PRECOND_MULTIGRID &&
                    opt->rd_mg_smooth >= 0 && opt->rd_mg_smooth <= 8,
                "bad RD preconditioner options");
+    GL_REQUIRE(opt->rd_linear >= GLIMS_RD_LINEAR_AUTO && opt->rd_linear <= GLIMS_RD_LINEAR_CHEBYSHEV &&
+                   opt->stream_policy >= GLIMS_STREAM_AUTO && opt->stream_policy <= GLIMS_STREAM_CACHED,
+               "bad rd_linear / stream_policy");
     // mg_smooth and mg_cheb_ratio are read by every cycle (no rebuild); the grids depend on the other two
     if (opt->mg_coarse_nodes != h->opt.mg_coarse_nodes || opt->mg_h_factor != h->opt.mg_h_factor)
       h->mg.ready = h->mg_rd.ready = false;
@@ -377,7 +383,8 @@ int glims_set_options(glims_ctx* h, const glims_options* opt) {
     if (opt->mech_history != h->opt.mech_history) h->mh_count = h->mh_next = 0;
     if (opt->dt != h->opt.dt) h->is_setup = false;
     if ((opt->flags ^ h->opt.flags) & (GLIMS_FLAG_FP32_JACOBIAN | GLIMS_FLAG_INT32_COLUMNS)) h->is_setup = false;
-    if ((opt->flags ^ h->opt.flags) & (GLIMS_FLAG_MG_FP32_SMOOTHER | GLIMS_FLAG_MG_FP64_VECTORS | GLIMS_FLAG_MG_WHOLE_GRID))
+    if (opt->stream_policy != h->opt.stream_policy) h->is_setup = false;
+    if ((opt->flags ^ h->opt.flags) & (GLIMS_FLAG_MG_FP32_SMOOTHER | GLIMS_FLAG_MG_FP64_VECTORS | GLIMS_FLAG_MG_WHOLE_GRID | GLIMS_FLAG_MG_NO_LUMPING))
       h->mg.ready = h->mg_rd.ready = false;
     h->opt = *opt;
     h->pending = false;
@@ -498,6 +505,20 @@ int glims_setup(glims_ctx* h, int with_mechanics) {
     h->jac32 = (h->opt.flags & GLIMS_FLAG_FP32_JACOBIAN) != 0;
     h->use_idx16 = (h->opt.flags & GLIMS_FLAG_INT32_COLUMNS) == 0;
     h->stats.nnz_idx16 = h->use_idx16 ? h->nnz_idx16_avail : 0;
+    h->cheb = glims_ctx::ChebState();   // the interval belongs to one operator
+    {
+      // Cache policy of the operator streams in the Krylov pass.  What one Krylov iteration touches: the stored entries
+      // (values + column codes) and the iteration's vector traffic.  While that fits the 256 MiB Infinity Cache with room to
+      // spare, default-policy loads keep the operator resident from pass to pass; beyond it non-temporal streams stop the
+      // operator from displacing the gathered vector (measured on a 1/8 share of config C4 and on C4).
+      const int64_t ent = h->pat.total_entries;
+      const int64_t ws = ent * ((h->jac32 ? 4 : 8) + (h->use_idx16 ? 2 : 4)) + h->n_own * 64;
+      h->stats.krylov_working_set = ws;
+      h->stream_nt = h->opt.stream_policy == GLIMS_STREAM_NONTEMPORAL ? 1
+                     : h->opt.stream_policy == GLIMS_STREAM_CACHED    ? 0
+                                                                      : (ws > GL_STREAM_CACHED_LIMIT ? 1 : 0);
+      h->stats.stream_nontemporal = h->stream_nt;
+    }
     gl_assemble_static(h, with_mechanics);
     GL_HIP(hipStreamSynchronize(h->st));
     h->is_setup = true;
@@ -515,9 +536,8 @@ int glims_set_state(glims_ctx* h, const double* c, const double* u) {
     // run_for_adjoint does): what the Newton iteration has learnt from the previous run's steps is forgotten, so that the run
     // takes the iteration path -- and produces the bits -- of a fresh handle.  (What stays: the operators, both multigrid
     // hierarchies and the preconditioner `auto` has settled on; they depend on the mesh and the parameters, not on the run.)
-    h->mid_on = false;
-    h->mid_cooldown = h->mid_streak = 0;
     h->nw_mode = h->nw_hold = h->nw_since = h->nw_steps = 0;
+    h->cheb = glims_ctx::ChebState();   // ... and the spectral interval of the dot-free solves (measured again by the first step)
     h->nq_first_ratio = 1e-3;
     h->nq_skip_steps = 0;
     for (int& hint : h->cg_hint) hint = 0;
@@ -584,6 +604,10 @@ int glims_reset_stats(glims_ctx* h) {
   h->stats.ms_rd_mg_setup = keep.ms_rd_mg_setup;
   h->stats.reduce_transport = keep.reduce_transport;
   h->stats.mg_grid1_bytes = keep.mg_grid1_bytes;
+  h->stats.cheb_lmin = keep.cheb_lmin;
+  h->stats.cheb_lmax = keep.cheb_lmax;
+  h->stats.stream_nontemporal = keep.stream_nontemporal;
+  h->stats.krylov_working_set = keep.krylov_working_set;
   h->tev_used = 0;
   h->stats.steps = keep.steps;   // step counter drives the extrapolated guess; keep it
   return GLIMS_OK;

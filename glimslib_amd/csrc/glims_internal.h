@@ -26,9 +26,10 @@
 // Blocks are dealt to the 8 XCDs in chunks of this many consecutive logical blocks: neighbouring slices (overlapping x
 // gathers) share one L2 while the XCDs together still walk the matrix front to back (measured: time of the plain
 // mapping, fabric reads 2.21 -> 1.97 GB per SpMV at 10 M rows; contiguous eighths are 1-5 % slower).
-#define GL_XCD_CHUNK_DEFAULT 64
-int gl_xcd_chunk();   // GL_XCD_CHUNK_DEFAULT, or GLIMS_XCD_CHUNK from the environment (tuning runs)
-#define GL_XCD_CHUNK gl_xcd_chunk()
+// glims_options.stream_policy = AUTO: Krylov working sets up to this many bytes stream the operator with the default cache policy
+#define GL_STREAM_CACHED_LIMIT (192ll << 20)
+// (chunks of 128-512 blocks change the in-step kernel times by <= 2 %: profiles/r04_ab_xcd_chunk.txt)
+#define GL_XCD_CHUNK 64
 
 struct glims_error : std::runtime_error {
   int code;
@@ -211,11 +212,6 @@ struct MgLevel {                           // one Cartesian level
   dvec<double> dinv;                       // [bs*bs][nn] inverse diagonal blocks
   dvec<double> x, x2, r, d, res;           // [bs][nn] (component-major)
   double lam = 1.0;                        // estimate of lambda_max(Dinv A)
-  // polynomial acceleration (mg_poly_setup): the system of this level is solved by poly_m steps of the Chebyshev iteration
-  // preconditioned with the V-cycle B from here down, for a spectrum of B A in [poly_a, poly_b]; 0: the plain V-cycle
-  int poly_m = 0;
-  double poly_a = 1.0, poly_b = 1.0;       // the interval: 0.7 x measured lambda_min(B A), 1.05 x max(1, measured lambda_max)
-  dvec<double> pd, pacc, pres;             // [bs][nn] direction, accumulated solution, spare residual buffer
 };
 // Neighbour exchange that replaces the all-reduce of the first grid's restricted residual in a box-limited partitioned
 // cycle: rank p needs the sum on its work box only, and rank q's partial sums are nonzero only on q's core, so p receives
@@ -302,6 +298,14 @@ struct MeshMetrics {
   double mean_edge = 0.0;
 };
 
+// halo payload of one owned row, written by the kernel that has just produced the row's value(s)
+struct PackMap {
+  const int32_t* ref = nullptr;    // [n_own]: -1 or index into ptr; nullptr = no fused packing
+  const int32_t* ptr = nullptr;
+  const int32_t* slot = nullptr;
+  double* sendbuf = nullptr;
+};
+
 #ifdef __HIPCC__
 // Node-local all-reduce of red[0..nq) (see NodeMail): called by every thread of the (single) final reduction block.
 // Sums in rank order on every rank -> the same bits everywhere, hence identical decisions.
@@ -345,6 +349,17 @@ static __device__ __forceinline__ void node_allreduce(double* __restrict__ red, 
     red[lane] = t;
   }
   if (!ok && lane == 0) *nm.err = 1;
+}
+
+template <int BS>
+static __device__ __forceinline__ void pack_row(const PackMap& pm, int64_t row, const double* vals /*[BS]*/) {
+  const int32_t r = pm.ref[row];
+  if (r < 0) return;
+  for (int32_t q = pm.ptr[r]; q < pm.ptr[r + 1]; ++q) {
+    const int64_t k = pm.slot[q];
+#pragma unroll
+    for (int a = 0; a < BS; ++a) pm.sendbuf[k * BS + a] = vals[a];
+  }
 }
 
 static __device__ __forceinline__ int xcd_chunk_remap(int b, int nb, int G) {
@@ -413,6 +428,7 @@ inline int gl_xrec_doubles(int bs, bool x32) { return x32 ? (bs == 3 ? 2 : 1) : 
 
 // scalar slots of the Krylov recurrence (device array `scal`)
 enum { SC_ALPHA = 0, SC_BETA, SC_GAMMA, SC_IT, SC_COUNT = 8 };
+#define GL_CG_HIST 64   // PCG iterations whose recurrence coefficients are recorded (Ritz values: spectral interval of the dot-free solves)
 
 struct glims_ctx {
   int dim = 0, nv = 0, device = 0;
@@ -439,7 +455,7 @@ struct glims_ctx {
   int64_t stats_defer_miss = 0;
   int64_t nnz_idx16_avail = 0;             // stored entries of slices that have 16-bit codes
   // glims_options.time_kernels: event pairs around the hot kernels of glims_step (bench.py's in-step roofline figures)
-  enum { TK_SPMV = 0, TK_SWEEP = 1, TK_UPDATE = 2, TK_MGFINE = 3, TK_SPMVB = 4, TK_QUAD = 5, TK_COUNT = 6 };
+  enum { TK_SPMV = 0, TK_SWEEP = 1, TK_UPDATE = 2, TK_MGFINE = 3, TK_SPMVB = 4, TK_QUAD = 5, TK_CHEB = 6, TK_COUNT = 7 };
   std::vector<hipEvent_t> tev;
   std::vector<uint8_t> tev_cat;             // category of pair q = events 2q, 2q+1
   size_t tev_used = 0;
@@ -449,7 +465,7 @@ struct glims_ctx {
   bool timing(int cat) const {
     const bool on = (cat == TK_MGFINE || cat == TK_SPMVB)
                         ? opt.time_kernels == 3
-                        : (opt.time_kernels == 2 || (opt.time_kernels == 1 && cat == TK_SPMV));
+                        : (opt.time_kernels == 2 || (opt.time_kernels == 1 && (cat == TK_SPMV || cat == TK_CHEB)));
     return on && tev_used + 2 <= tev.size();
   }
   void timing_begin();                      // allocates the event pool on first use
@@ -483,6 +499,21 @@ struct glims_ctx {
   dvec<float> vA32;                        // Newton Jacobian in single precision (GLIMS_FLAG_FP32_JACOBIAN only)
   bool jac32 = false;
   int spmv_unroll = 8;                     // entries in flight per lane of the scalar SpMV: 8 on lattice meshes, 16 on general ones
+  int stream_nt = 1;                       // value / column-code streams of the Krylov operator pass non-temporal (1) or with the
+                                           // default cache policy (0): glims_options.stream_policy, resolved at glims_setup
+  // Dot-free RD linear solves (Chebyshev semi-iteration, solver.hip): interval of the spectrum of Dinv A(c) the right-hand sides
+  // of this run excite, from the Lanczos coefficients of recorded PCG solves
+  struct ChebState {
+    bool valid = false;                    // [lmin, lmax] usable
+    double lmin = 0.0, lmax = 0.0;         // union of the Ritz intervals of the last learning step's PCG solves
+    double acc_lmin = 0.0, acc_lmax = 0.0; // ... being accumulated by the current learning step
+    int learned = 0;                       // PCG solves that contributed to acc_*
+    int age = 0;                           // steps since the interval was measured
+  } cheb;
+  double cheb_test_hi = 1.0;               // TEST HOOK GLIMS_CHEB_TEST_SCALE_HI (read by glims_create): factor on the measured upper end
+  dvec<double> cg_hist;                    // [2 * GL_CG_HIST] (alpha_k, beta_k) of the running PCG solve
+  dvec<double> cheb_delta;                 // accumulated correction of the running Chebyshev solve [n_nodes]
+  dvec<int> cheb_plan;                     // [1] iteration count computed on the device (a step's first, warm-started solve)
   dvec<float> vKel32;                      // single-precision copy of K_el (inner solves of the elasticity solver)
   // vectors (internal numbering; length n_nodes unless noted)
   dvec<double> c, c_old, b, load_rd, dinv;
@@ -492,8 +523,6 @@ struct glims_ctx {
   dvec<double> nq_c0, nq_ck;
   dvec<float> nq_ad;                                          // (a, delta) pairs, single precision (see k_rd_quad)
   double nq_first_ratio = 1e-3;                               // residual contraction of the last step's first Newton iteration
-  bool mid_on = false;                                        // midpoint correction of the first right-hand side (gl_step)
-  int mid_cooldown = 0, mid_streak = 0;
   // default forcing: how a step's FIRST solve is run (gl_step).  0: tolerance 0.3 cg_rtol; 1: the same + midpoint correction;
   // 2: cg_rtol, no correction (for nw_hold steps after a step that took three iterations even with the correction)
   int nw_mode = 0, nw_hold = 0, nw_since = 0, nw_steps = 0;   // nw_steps: steps since glims_set_state
@@ -582,6 +611,10 @@ void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* s
                     const double* x, double* y, const uint8_t* fixed, const double* addv, const double* r,
                     double* partials, int partial_off, const int* done, const float* vals32 = nullptr,
                     hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+void gl_launch_cheb(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* slice_list, const double* vals,
+                    const float* vals32, const double* d_in, double* d_out, double* r, const double* dinv, double* delta,
+                    double* x, const uint8_t* fixed, double c1, double c2, int k, int m_host, const int* plan, int want_res,
+                    const PackMap& pm, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 void gl_launch_spmv_block(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* slice_list, const double* x,
                           double* y, const uint8_t* fixed, const double* r, double* partials, int partial_off,
                           const int* done, bool single_precision_operator = false);

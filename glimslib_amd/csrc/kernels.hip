@@ -12,15 +12,6 @@
 #include <algorithm>
 #include <cmath>
 
-int gl_xcd_chunk() {
-  static const int g = [] {
-    const char* e = getenv("GLIMS_XCD_CHUNK");
-    const int v = e ? atoi(e) : 0;
-    return v >= 1 ? v : GL_XCD_CHUNK_DEFAULT;
-  }();
-  return g;
-}
-
 namespace {
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -766,7 +757,7 @@ __global__ __launch_bounds__(GL_WAVE) void k_rd_matfree(
   double* cn = lds + (size_t)max_len * GL_WAVE;
   double* xn = lds + (size_t)2 * max_len * GL_WAVE;
   const int lane = threadIdx.x;
-  const int s = slice_list[xcd_chunk_remap(blockIdx.x, gridDim.x, 4 * GL_XCD_CHUNK_DEFAULT)];
+  const int s = slice_list[xcd_chunk_remap(blockIdx.x, gridDim.x, 4 * GL_XCD_CHUNK)];
   const int64_t row = (int64_t)s * GL_WAVE + lane;
   const int64_t base = slice_ptr[s], cbase = cslice_ptr[s];
   const int len = (int)((slice_ptr[s + 1] - base) >> 6), clen = (int)((cslice_ptr[s + 1] - cbase) >> 6);
@@ -962,6 +953,73 @@ __global__ __launch_bounds__(256) void k_spmv(int n_launch, int chunk, const int
     }
   }
   if (DOTS) spmv_dot_partial(pd, b, partials, partial_off);
+}
+
+// Dot-free Krylov iteration (round 5): ONE launch per iteration.  Step k of the Chebyshev semi-iteration for A x = b on the
+// spectrum [lmin, lmax] of Dinv A, in residual form, with the vector work in the operator pass's epilogue -- the row owner has
+// (A d)_row in registers, and d_in[row] arrives with the gather of the diagonal entry:
+//     r <- r - A d_in;   d_out = c1 d_in + c2 Dinv r;   delta += d_out                      (launches 1 .. last)
+// No dot product, no reduction kernel, no all-reduce: the iteration count m follows from the interval and the wanted
+// reduction (solver.hip, cheb_solve), either known to the host (m_host) or, for a step's first solve, computed on the device
+// from the norm of the warm-started residual (*plan).  The accumulated correction delta = d_0 + .. + d_(m-1) is added to
+// the Newton iterate x by the LAST launch, so that a solve whose interval turns out wrong can be taken back (x -= delta).
+//   want_res = 1: m operator passes, the last one (k = m) only updates r -- r is then the residual of the final iterate, which
+//                 the quadratic-structure evaluation of the Newton residual builds on;
+//   want_res = 0: m - 1 passes (a sweep re-evaluates the residual anyway), the last one (k = m - 1) computes d_(m-1).
+// d_in is gathered (ghosts included), d_out written by the row owner: two buffers that change roles every launch.
+template <int UNR, int NT, int CIDX, class VT>
+__global__ __launch_bounds__(256) void k_cheb(int n_launch, int chunk, const int32_t* __restrict__ slice_list,
+                                               int64_t n_own, const int64_t* __restrict__ slice_ptr,
+                                               const int32_t* __restrict__ cols, const uint16_t* __restrict__ cols16,
+                                               const int32_t* __restrict__ win_base, const uint8_t* __restrict__ win_ok,
+                                               const uint8_t* __restrict__ diag_k, const uint8_t* __restrict__ rlen,
+                                               const VT* __restrict__ vals, const double* __restrict__ d_in,
+                                               double* __restrict__ d_out, double* __restrict__ r,
+                                               const double* __restrict__ dinv, double* __restrict__ delta,
+                                               double* __restrict__ x, const uint8_t* __restrict__ fixed, double c1,
+                                               double c2, int k, int m_host, const int* __restrict__ plan, int want_res,
+                                               const PackMap pm, int remap) {
+  const int m = plan ? *plan : m_host;
+  const int last = want_res ? m : m - 1;
+  if (k > last) return;
+  const bool direction = !want_res || k < m, fin = k == last;
+  const int b = remap > 1 ? xcd_chunk_remap(blockIdx.x, gridDim.x, remap) : blockIdx.x;
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int s_end = min(n_launch, (b + 1) * chunk);
+  for (int si = b * chunk + wid; si < s_end; si += 4) {
+    const int s = slice_list ? slice_list[si] : si;
+    const int64_t row = (int64_t)s * GL_WAVE + lane;
+    const int64_t base = slice_ptr[s];
+    const int len = (int)((slice_ptr[s + 1] - base) >> 6);
+    const VT* v = vals + base + lane;
+    double acc, dd = 0.0;
+    const int dk = (int)diag_k[row];
+    const int rl = (int)rlen[row];
+    if (CIDX && win_ok[s]) {   // wave-uniform
+      const int32_t wb = win_base[(int64_t)s * GL_N_WIN + (lane & (GL_N_WIN - 1))];
+      acc = spmv_row<1, UNR, NT, 1, VT>(nullptr, cols16 + base + lane, wb, v, d_in, len, rl, dk, dd);
+    } else {
+      acc = spmv_row<0, UNR, NT, 1, VT>(cols + base + lane, nullptr, 0, v, d_in, len, rl, dk, dd);
+    }
+    if (row >= n_own) continue;
+    if (fixed && fixed[row]) acc = 0.0;   // constrained rows: r = 0 there, so every direction stays 0
+    const double rn = r[row] - acc;
+    r[row] = rn;
+    double dl = delta[row];
+    if (direction) {
+      const double dn = c1 * dd + c2 * dinv[row] * rn;
+      dl += dn;
+      if (!fin) {
+        d_out[row] = dn;
+        delta[row] = dl;
+        if (pm.ref) pack_row<1>(pm, row, &dn);
+      }
+    }
+    if (fin) {
+      delta[row] = dl;
+      x[row] += dl;
+    }
+  }
 }
 
 // Pipelined block SpMV: KB block entries per batch -- all column loads, then all KB*BS*BS value loads (non-temporal:
@@ -1553,17 +1611,22 @@ void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* s
   // the x gather misses the caches far more often (1 M-point Delaunay mesh: 58.5 / 52.5 / 48.7 us with 4 / 8 / 16; the
   // brain-extent box at 10 M rows: 332 / 323 / 323 us isolated, 366 / 356 / 379 inside the time steps).
   const int unr = h->spmv_unroll;
-#define GL_SPMV4(DOTS, UNR, CIDX, VT, VPTR)                                                                          \
+#define GL_SPMV5(DOTS, UNR, NT, CIDX, VT, VPTR)                                                                      \
   do {                                                                                                               \
     if (ev0 || ev1)                                                                                                  \
-      hipExtLaunchKernelGGL((k_spmv<DOTS, UNR, 1, CIDX, VT>), dim3(grid), dim3(256), 0, st, ev0, ev1, 0, n_launch,    \
+      hipExtLaunchKernelGGL((k_spmv<DOTS, UNR, NT, CIDX, VT>), dim3(grid), dim3(256), 0, st, ev0, ev1, 0, n_launch,   \
                             chunk, slice_list, h->n_own, p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p,          \
                             p.win_ok.p, p.diag_k.p, p.rlen.p, VPTR, x, y, fixed, addv, r, partials, partial_off,     \
                             done, remap);                                                                            \
     else                                                                                                             \
-      hipLaunchKernelGGL((k_spmv<DOTS, UNR, 1, CIDX, VT>), dim3(grid), dim3(256), 0, st, n_launch, chunk, slice_list, \
+      hipLaunchKernelGGL((k_spmv<DOTS, UNR, NT, CIDX, VT>), dim3(grid), dim3(256), 0, st, n_launch, chunk, slice_list, \
                          h->n_own, p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, p.win_ok.p, p.diag_k.p,        \
                          p.rlen.p, VPTR, x, y, fixed, addv, r, partials, partial_off, done, remap);                  \
+  } while (0)
+#define GL_SPMV4(DOTS, UNR, CIDX, VT, VPTR)                                                                          \
+  do {                                                                                                               \
+    if (h->stream_nt) GL_SPMV5(DOTS, UNR, 1, CIDX, VT, VPTR);                                                        \
+    else GL_SPMV5(DOTS, UNR, 0, CIDX, VT, VPTR);                                                                     \
   } while (0)
 #define GL_SPMV3(DOTS, CIDX)                                                                                         \
   do {                                                                                                               \
@@ -1578,6 +1641,50 @@ void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* s
   }
 #undef GL_SPMV3
 #undef GL_SPMV4
+#undef GL_SPMV5
+  GL_HIP(hipGetLastError());
+}
+
+// One launch of the dot-free Krylov iteration (k_cheb) over a slice subset; same launch shape, stream policy and column-code
+// choice as the SpMV it replaces.
+void gl_launch_cheb(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* slice_list, const double* vals,
+                    const float* vals32, const double* d_in, double* d_out, double* r, const double* dinv, double* delta,
+                    double* x, const uint8_t* fixed, double c1, double c2, int k, int m_host, const int* plan, int want_res,
+                    const PackMap& pm, hipEvent_t ev0, hipEvent_t ev1) {
+  if (n_launch <= 0) return;
+  const DevPattern& p = h->pat;
+  const int grid = gl_spmv_grid(n_launch);
+  const int chunk = (n_launch + grid - 1) / grid;
+  const int remap = slice_list ? 0 : GL_XCD_CHUNK;
+  const int unr = h->spmv_unroll;
+#define GL_CH4(UNR, NT, CIDX, VT, VPTR)                                                                              \
+  do {                                                                                                               \
+    if (ev0 || ev1)                                                                                                  \
+      hipExtLaunchKernelGGL((k_cheb<UNR, NT, CIDX, VT>), dim3(grid), dim3(256), 0, st, ev0, ev1, 0, n_launch, chunk,  \
+                            slice_list, h->n_own, p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, p.win_ok.p,     \
+                            p.diag_k.p, p.rlen.p, VPTR, d_in, d_out, r, dinv, delta, x, fixed, c1, c2, k, m_host,    \
+                            plan, want_res, pm, remap);                                                              \
+    else                                                                                                             \
+      hipLaunchKernelGGL((k_cheb<UNR, NT, CIDX, VT>), dim3(grid), dim3(256), 0, st, n_launch, chunk, slice_list,      \
+                         h->n_own, p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, p.win_ok.p, p.diag_k.p,        \
+                         p.rlen.p, VPTR, d_in, d_out, r, dinv, delta, x, fixed, c1, c2, k, m_host, plan, want_res,   \
+                         pm, remap);                                                                                 \
+  } while (0)
+#define GL_CH3(UNR, CIDX, VT, VPTR)                                                                                  \
+  do {                                                                                                               \
+    if (h->stream_nt) GL_CH4(UNR, 1, CIDX, VT, VPTR);                                                                \
+    else GL_CH4(UNR, 0, CIDX, VT, VPTR);                                                                             \
+  } while (0)
+#define GL_CH2(CIDX)                                                                                                 \
+  do {                                                                                                               \
+    if (vals32) GL_CH3(8, CIDX, float, vals32);                                                                      \
+    else if (unr >= 16) GL_CH3(16, CIDX, double, vals);                                                              \
+    else GL_CH3(8, CIDX, double, vals);                                                                              \
+  } while (0)
+  if (h->use_idx16) GL_CH2(1); else GL_CH2(0);
+#undef GL_CH2
+#undef GL_CH3
+#undef GL_CH4
   GL_HIP(hipGetLastError());
 }
 

@@ -1898,7 +1898,7 @@ void mg_setup_t(glims_ctx* h, MgHierarchy& mg) {
     dvec<float> T;
     T.alloc((size_t)(std::min(chunk, n) * NB * B2));
     // (nothing is dropped on lattice meshes and on quality-controlled ones: no far couplings, the test costs nothing)
-    const int lump_far = getenv("GLIMS_MG_NO_LUMPING") ? 0 : 1;
+    const int lump_far = (h->opt.flags & GLIMS_FLAG_MG_NO_LUMPING) ? 0 : 1;
     for (int64_t r0 = 0; r0 < n; r0 += chunk) {
       const int64_t r1 = std::min(n, r0 + chunk);
       hipLaunchKernelGGL((k_mg_kp<D, BS>), dim3(gridn(r1 - r0, 4)), dim3(256), 0, h->st, gdev(g1), mg.R, r0, r1, n_all,
@@ -2149,19 +2149,16 @@ void mg_setup_t(glims_ctx* h, MgHierarchy& mg) {
 // c2 of the first Chebyshev step of level l, if the restriction INTO level l may do that step itself (a smoothed
 // level, and no all-reduce between the restriction and the step); 0 otherwise
 inline double mg_fused_first_c2(const MgHierarchy& mg, size_t l, bool allreduce_before) {
-  if (allreduce_before || l + 1 == mg.lv.size() || mg.lv[l]->poly_m > 1) return 0.0;
+  if (allreduce_before || l + 1 == mg.lv.size()) return 0.0;
   Cheb ch(mg.lv[l]->lam, mg.cheb_ratio);
   double c1, c2;
   ch.next(0, &c1, &c2);
   return c2;
 }
 
-template <int D, int BS>
-void mg_cycle_cart(glims_ctx* h, MgHierarchy& mg, int deg, size_t l, const int* done, bool first_done);
-
 // `first_done`: the restriction that produced L.r has taken the first smoothing step as well (L.d, L.x are set)
 template <int D, int BS>
-void mg_cycle_cart_v(glims_ctx* h, MgHierarchy& mg, int deg, size_t l, const int* done, bool first_done) {
+void mg_cycle_cart(glims_ctx* h, MgHierarchy& mg, int deg, size_t l, const int* done, bool first_done) {
   MgLevel& L = *mg.lv[l];
   const GridDev g = gdev(L.g);
   if (l + 1 == mg.lv.size()) {
@@ -2214,238 +2211,6 @@ void mg_cycle_cart_v(glims_ctx* h, MgHierarchy& mg, int deg, size_t l, const int
     std::swap(xa, xb);
   }
   if (xa != L.x.p) std::swap(L.x.p, L.x2.p);   // the result is always handed up in L.x
-}
-
-// d = cz z (+ cd d), acc (+)= d: the vector work of one step of the Chebyshev iteration below
-__global__ void k_mg_poly_step(long long n, const double* __restrict__ z, double* __restrict__ d, double* __restrict__ acc,
-                               double cd, double cz, int first, const int* __restrict__ done) {
-  if (done && *done) return;
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const double dn = first ? cz * z[i] : cd * d[i] + cz * z[i];
-  d[i] = dn;
-  acc[i] = first ? dn : acc[i] + dn;
-}
-
-// Level l of a cycle.  Plain: one V-cycle from here down.  Levels with MgLevel::poly_m > 1 (opt-in, see mg_poly_setup):
-// x = p(B A) B r, the degree-poly_m Chebyshev iteration for A_l x = r preconditioned with that V-cycle B, spectrum of B A in
-// [poly_a, poly_b] -- a FIXED polynomial, so the cycle stays a linear symmetric operator and the outer Krylov iteration
-// needs no flexible variant (an AMLI-type cycle).  poly_m V-cycles from level l and poly_m - 1 operator passes on it per
-// outer iteration.
-template <int D, int BS>
-void mg_cycle_cart(glims_ctx* h, MgHierarchy& mg, int deg, size_t l, const int* done, bool first_done) {
-  MgLevel& L = *mg.lv[l];
-  if (L.poly_m <= 1 || l + 1 == mg.lv.size()) {
-    mg_cycle_cart_v<D, BS>(h, mg, deg, l, done, first_done);
-    return;
-  }
-  GL_REQUIRE(!first_done && !L.half && !(l == 0 && mg.boxed), "internal: polynomial cycle on a level it was not set up for");
-  const long long nv = (long long)BS * L.g.nn;
-  const double a = L.poly_a, b = L.poly_b;
-  const double theta = 0.5 * (a + b), delta = 0.5 * (b - a), sigma = theta / delta;
-  double rho = 1.0 / sigma;
-  for (int k = 0; k < L.poly_m; ++k) {
-    if (k > 0) {   // residual of the accumulated solution: r <- r - A d (into the spare buffer, then the two change roles)
-      mg_apply_cart<D, BS>(h, mg, L, mg.R, 0, L.pd.p, L.r.p, nullptr, L.pres.p, 0.0, 0.0, done);
-      std::swap(L.r.p, L.pres.p);
-    }
-    mg_cycle_cart_v<D, BS>(h, mg, deg, l, done, false);   // z = B r, in L.x
-    double cd = 0.0, cz = 1.0 / theta;
-    if (k > 0) {
-      const double rho2 = 1.0 / (2.0 * sigma - rho);
-      cd = rho2 * rho;
-      cz = 2.0 * rho2 / delta;
-      rho = rho2;
-    }
-    hipLaunchKernelGGL(k_mg_poly_step, dim3(gridn(nv)), dim3(256), 0, h->st, nv, L.x.p, L.pd.p, L.pacc.p, cd, cz, k == 0 ? 1 : 0,
-                       done);
-    GL_HIP(hipGetLastError());
-  }
-  std::swap(L.x.p, L.pacc.p);   // the result is handed up in L.x
-}
-
-// Set-up of the polynomial on the second grid: both ends of the spectrum of B A by power iteration.
-template <int D, int BS>
-void mg_poly_setup(glims_ctx* h, MgHierarchy& mg, int deg) {
-  for (MgLevel* L : mg.lv) {
-    L->poly_m = 0;
-    L->poly_a = L->poly_b = 1.0;
-  }
-  // OFF by default (GLIMS_MG_POLY=k >= 2 switches it on with degree k; GLIMS_MG_POLY_CHECK=1 prints the measurements only).
-  // In the scipy prototype, whose Galerkin operators are exact, the polynomial halves the iteration count (58-68 -> 27-29 on
-  // 30-100 k random points).  On the device it does not: the first grid's operator is truncated to the stencil radius, and on
-  // sliver meshes -- the only ones where the V-cycle below the first grid is weak -- the truncation leaves the coarse
-  // operators INDEFINITE (cancelling couplings of both signs around a sliver, some kept, some dropped): lambda_min of
-  // Dinv A on the second grid -0.19 (scalar RD operator, 200 k random points), of B A -0.17 ... -0.88.  PCG copes with a few
-  // negative eigenvalues of the preconditioner; a polynomial in B A amplifies them: elasticity on 300 k random points
-  // 48 / 39 / 32 iterations (first three solves) with the plain cycle, 55 / 45 / 36 with degree 4.
-  // profiles/r04_mg_poly_*.txt; quality meshes and lattices: spectrum of B A in [0.46, 1.00], nothing to accelerate.
-  const char* e = getenv("GLIMS_MG_POLY");
-  const int forced = e ? atoi(e) : 0;
-  const bool check = getenv("GLIMS_MG_POLY_CHECK") != nullptr;
-  if ((forced < 2 && !check) || mg.lv.size() < 3) return;
-  const double t0 = omp_get_wtime();
-  mg.cheb_ratio = h->opt.mg_cheb_ratio > 1.0 ? h->opt.mg_cheb_ratio : (mg.bs == 1 ? 10.0 : mg.default_ratio);
-  // the second grid only: polynomials on two or three levels, one inside the other, gain less than one of degree 3-4 there
-  // (100 k random points: V-cycle 68, second grid 34 / 29 with degree 3 / 4, second + third grid 56 / 39 with degree 2 / 3)
-  const size_t l_top = 1, l_bottom = 1;
-  for (size_t l = l_bottom; l >= l_top; --l) {
-    MgLevel& L = *mg.lv[l];
-    if (L.half || L.g.nn * BS < 200) continue;
-    const long long nv = (long long)BS * L.g.nn;
-    std::vector<double> x((size_t)nv), y((size_t)nv);
-    uint64_t s = 0x9E3779B97F4A7C15ull;
-    double nx = 0.0;
-    for (double& v : x) {   // the same start vector everywhere (replicated levels of a partitioned run stay replicated)
-      s = s * 6364136223846793005ull + 1442695040888963407ull;
-      v = (double)(s >> 11) / 9007199254740992.0 - 0.5;
-      nx += v * v;
-    }
-    for (double& v : x) v /= std::sqrt(nx);
-    L.pd.alloc((size_t)nv);
-    L.pacc.alloc((size_t)nv);
-    L.pres.alloc((size_t)nv);
-    GL_HIP(hipMemsetAsync(L.pres.p, 0, (size_t)nv * sizeof(double), h->st));
-    auto apply_BA = [&](const std::vector<double>& in, std::vector<double>& out) {
-      GL_HIP(hipMemcpyAsync(L.pd.p, in.data(), (size_t)nv * sizeof(double), hipMemcpyHostToDevice, h->st));
-      mg_apply_cart<D, BS>(h, mg, L, mg.R, 0, L.pd.p, L.pres.p, nullptr, L.r.p, 0.0, 0.0);   // r = -A x
-      mg_cycle_cart_v<D, BS>(h, mg, deg, l, nullptr, false);                                   // L.x = -B A x
-      GL_HIP(hipMemcpyAsync(out.data(), L.x.p, (size_t)nv * sizeof(double), hipMemcpyDeviceToHost, h->st));
-      GL_HIP(hipStreamSynchronize(h->st));
-      for (double& v : out) v = -v;
-    };
-    auto normalise = [&](std::vector<double>& v) {
-      double s2 = 0.0;
-      for (double q : v) s2 += q * q;
-      if (!(s2 > 0.0)) return false;
-      const double inv = 1.0 / std::sqrt(s2);
-      for (double& q : v) q *= inv;
-      return true;
-    };
-    // grid nodes without mesh support have empty rows: B A = 0 there.  One application of B A takes them out of the start vector
-    apply_BA(x, y);
-    x.swap(y);
-    bool ok = normalise(x);
-    double lmax = 1.0;
-    const int n_its = getenv("GLIMS_MG_POLY_ITS") ? atoi(getenv("GLIMS_MG_POLY_ITS")) : 12;
-    const double margin = getenv("GLIMS_MG_POLY_MARGIN") ? atof(getenv("GLIMS_MG_POLY_MARGIN")) : 1.05;
-    for (int it = 0; ok && it < n_its; ++it) {   // lambda_max(B A): 1 for exact smoother bounds, above where they are under-estimated
-      apply_BA(x, y);
-      double xy = 0.0;
-      for (long long i = 0; i < nv; ++i) xy += x[(size_t)i] * y[(size_t)i];
-      lmax = xy;
-      x.swap(y);
-      ok = normalise(x);
-    }
-    const double top = margin * std::max(1.0, lmax);
-    double mu = 0.0;
-    {   // fresh start vector for the other end of the spectrum (the last one is the top eigenvector)
-      for (double& v : x) {
-        s = s * 6364136223846793005ull + 1442695040888963407ull;
-        v = (double)(s >> 11) / 9007199254740992.0 - 0.5;
-      }
-      apply_BA(x, y);
-      x.swap(y);
-      ok = normalise(x);
-    }
-    for (int it = 0; ok && it < n_its; ++it) {   // power iteration on top I - B A
-      apply_BA(x, y);
-      double xy = 0.0;
-      for (long long i = 0; i < nv; ++i) {
-        y[(size_t)i] = top * x[(size_t)i] - y[(size_t)i];
-        xy += x[(size_t)i] * y[(size_t)i];
-      }
-      mu = xy;
-      x.swap(y);
-      ok = normalise(x);
-    }
-    const double lmin = std::min(1.0, std::max(1e-3, top - mu));
-    L.poly_b = top;
-    L.poly_a = lmin;
-    int m = 0;
-    if (forced >= 2 && lmin < 0.3 * top) {   // (where the plain cycle's bound 1 - lambda_min is good already, it stays)
-      m = std::min(forced, 8);
-      L.poly_m = m;
-      L.poly_a = 0.7 * lmin;   // (a too-small bound costs little: 28 -> 28-31 iterations at half the measured value)
-    }
-    if (getenv("GLIMS_VERBOSE"))
-      fprintf(stderr, "glims multigrid (%d dof / node): grid %zu (%dx%dx%d), spectrum of B A in [%.4f, %.4f] (raw lower end %.5f) -> %s\n", BS, l + 1,
-              L.g.n[0], L.g.n[1], L.g.n[2], lmin, lmax, top - mu, m > 1 ? ("Chebyshev polynomial of degree " + std::to_string(m)).c_str() : "plain V-cycle");
-    if (getenv("GLIMS_MG_POLY_CHECK")) {   // diagnostics: lower end of the spectrum of Dinv A on the levels from here down
-      for (size_t q = l; q + 1 < mg.lv.size(); ++q) {
-        MgLevel& Q = *mg.lv[q];
-        if (Q.half) continue;
-        const long long nq = (long long)BS * Q.g.nn;
-        std::vector<double> xq((size_t)nq), yq((size_t)nq);
-        for (double& v : xq) { s = s * 6364136223846793005ull + 1442695040888963407ull; v = (double)(s >> 11) / 9007199254740992.0 - 0.5; }
-        const double topq = 1.2 * Q.lam;
-        double muq = 0.0;
-        for (int it = 0; it < 300; ++it) {
-          GL_HIP(hipMemcpyAsync(Q.x.p, xq.data(), (size_t)nq * sizeof(double), hipMemcpyHostToDevice, h->st));
-          mg_apply_cart<D, BS>(h, mg, Q, mg.R, 2, Q.x.p, nullptr, nullptr, Q.x2.p, 0.0, 0.0);
-          GL_HIP(hipMemcpyAsync(yq.data(), Q.x2.p, (size_t)nq * sizeof(double), hipMemcpyDeviceToHost, h->st));
-          GL_HIP(hipStreamSynchronize(h->st));
-          double xy = 0.0, xx = 0.0, yy = 0.0;
-          for (long long i = 0; i < nq; ++i) {
-            if (it == 0 && yq[(size_t)i] == 0.0) xq[(size_t)i] = 0.0;   // nodes without stiffness
-            yq[(size_t)i] = topq * xq[(size_t)i] - yq[(size_t)i];
-            xy += xq[(size_t)i] * yq[(size_t)i];
-            xx += xq[(size_t)i] * xq[(size_t)i];
-            yy += yq[(size_t)i] * yq[(size_t)i];
-          }
-          muq = xy / xx;
-          for (long long i = 0; i < nq; ++i) xq[(size_t)i] = yq[(size_t)i] / std::sqrt(yy);
-        }
-        fprintf(stderr, "  check: grid %zu, lambda_min(Dinv A) = %.3e (lambda_max estimate %.2f)\n", q + 1, topq - muq, Q.lam);
-      }
-      GL_HIP(hipMemsetAsync(L.x.p, 0, (size_t)nv * sizeof(double), h->st));
-      GL_HIP(hipMemsetAsync(L.x2.p, 0, (size_t)nv * sizeof(double), h->st));
-    }
-    if (getenv("GLIMS_MG_POLY_CHECK")) {   // diagnostics: symmetry of B, and what the polynomial does to a random right-hand side
-      std::vector<double> u((size_t)nv), v((size_t)nv), Bu((size_t)nv), Bv((size_t)nv), w((size_t)nv);
-      for (double& q : u) { s = s * 6364136223846793005ull + 1442695040888963407ull; q = (double)(s >> 11) / 9007199254740992.0 - 0.5; }
-      for (double& q : v) { s = s * 6364136223846793005ull + 1442695040888963407ull; q = (double)(s >> 11) / 9007199254740992.0 - 0.5; }
-      apply_BA(u, w); u = w; apply_BA(v, w); v = w;   // live subspace
-      auto apply_B = [&](const std::vector<double>& in, std::vector<double>& out, bool poly) {
-        GL_HIP(hipMemcpyAsync(L.r.p, in.data(), (size_t)nv * sizeof(double), hipMemcpyHostToDevice, h->st));
-        if (poly) mg_cycle_cart<D, BS>(h, mg, deg, l, nullptr, false);
-        else mg_cycle_cart_v<D, BS>(h, mg, deg, l, nullptr, false);
-        GL_HIP(hipMemcpyAsync(out.data(), L.x.p, (size_t)nv * sizeof(double), hipMemcpyDeviceToHost, h->st));
-        GL_HIP(hipStreamSynchronize(h->st));
-      };
-      auto apply_A = [&](const std::vector<double>& in, std::vector<double>& out) {
-        GL_HIP(hipMemcpyAsync(L.pd.p, in.data(), (size_t)nv * sizeof(double), hipMemcpyHostToDevice, h->st));
-        GL_HIP(hipMemsetAsync(L.pacc.p, 0, (size_t)nv * sizeof(double), h->st));
-        mg_apply_cart<D, BS>(h, mg, L, mg.R, 0, L.pd.p, L.pacc.p, nullptr, L.x2.p, 0.0, 0.0);
-        GL_HIP(hipMemcpyAsync(out.data(), L.x2.p, (size_t)nv * sizeof(double), hipMemcpyDeviceToHost, h->st));
-        GL_HIP(hipStreamSynchronize(h->st));
-        for (double& q : out) q = -q;
-      };
-      auto dot = [&](const std::vector<double>& a, const std::vector<double>& b) { double t = 0; for (long long i = 0; i < nv; ++i) t += a[(size_t)i] * b[(size_t)i]; return t; };
-      for (int poly = 0; poly <= (L.poly_m > 1 ? 1 : 0); ++poly) {
-        apply_B(u, Bu, poly); apply_B(v, Bv, poly);
-        std::vector<double> Au((size_t)nv), ABu((size_t)nv);
-        apply_A(Bu, ABu);
-        double rr = 0, r0 = 0;
-        for (long long i = 0; i < nv; ++i) { const double d = u[(size_t)i] - ABu[(size_t)i]; rr += d * d; r0 += u[(size_t)i] * u[(size_t)i]; }
-        apply_A(u, Au); apply_A(v, w);
-        std::vector<double> rp((size_t)nv), Brp((size_t)nv), Bu0((size_t)nv);
-        for (long long i = 0; i < nv; ++i) rp[(size_t)i] = u[(size_t)i] - ABu[(size_t)i];
-        apply_B(rp, Brp, false);
-        apply_B(u, Bu0, false);
-        fprintf(stderr, "  check (%s): (v, B u) = %.10e, (u, B v) = %.10e; (v, A u) = %.10e, (u, A v) = %.10e; |u - A B u| / |u| = %.4f; in the norm of the plain cycle: %.4f\n",
-                poly ? "polynomial" : "V-cycle", dot(v, Bu), dot(u, Bv), dot(v, Au), dot(u, w), std::sqrt(rr / r0),
-                std::sqrt(dot(rp, Brp) / dot(u, Bu0)));
-      }
-    }
-    if (L.poly_m <= 1) {
-      L.pd.release();
-      L.pacc.release();
-      L.pres.release();
-    }
-    if (l == 0) break;
-  }
-  mg.ms_setup += 1e3 * (omp_get_wtime() - t0);
 }
 
 }  // namespace
@@ -2566,17 +2331,12 @@ void mg_apply_cycle(glims_ctx* h, MgHierarchy& mg, int deg, const double* r, dou
 
 void gl_mg_setup(glims_ctx* h, MgHierarchy& mg) {
   GL_REQUIRE(mg.bs == 1 || mg.bs == h->dim, "multigrid: block size must be 1 or the dimension");
-  // (the polynomial's spectral bound is measured with the smoother degree the cycles will run with)
-  auto deg = [&] {
-    return std::max(1, std::min(8, mg.bs == 1 ? (h->opt.rd_mg_smooth > 0 ? h->opt.rd_mg_smooth : (mg.lattice ? 1 : 3))
-                                              : h->opt.mg_smooth));
-  };
   if (h->dim == 2) {
-    if (mg.bs == 1) mg_setup_t<2, 1>(h, mg), mg_poly_setup<2, 1>(h, mg, deg());
-    else mg_setup_t<2, 2>(h, mg), mg_poly_setup<2, 2>(h, mg, deg());
+    if (mg.bs == 1) mg_setup_t<2, 1>(h, mg);
+    else mg_setup_t<2, 2>(h, mg);
   } else {
-    if (mg.bs == 1) mg_setup_t<3, 1>(h, mg), mg_poly_setup<3, 1>(h, mg, deg());
-    else mg_setup_t<3, 3>(h, mg), mg_poly_setup<3, 3>(h, mg, deg());
+    if (mg.bs == 1) mg_setup_t<3, 1>(h, mg);
+    else mg_setup_t<3, 3>(h, mg);
   }
 }
 

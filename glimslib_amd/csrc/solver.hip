@@ -44,24 +44,6 @@ __device__ __forceinline__ void block_sum2(double a, double b, double* __restric
   if (threadIdx.x < 2) pv[(size_t)blockIdx.x * 2 + threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
 }
 
-// halo payload of one owned row, written by the kernel that has just produced the row's value(s)
-struct PackMap {
-  const int32_t* ref = nullptr;    // [n_own]: -1 or index into ptr; nullptr = no fused packing
-  const int32_t* ptr = nullptr;
-  const int32_t* slot = nullptr;
-  double* sendbuf = nullptr;
-};
-template <int BS>
-__device__ __forceinline__ void pack_row(const PackMap& pm, int64_t row, const double* vals /*[BS]*/) {
-  const int32_t r = pm.ref[row];
-  if (r < 0) return;
-  for (int32_t q = pm.ptr[r]; q < pm.ptr[r + 1]; ++q) {
-    const int64_t k = pm.slot[q];
-#pragma unroll
-    for (int a = 0; a < BS; ++a) pm.sendbuf[k * BS + a] = vals[a];
-  }
-}
-
 // u = Dinv r and the first (r.u, r.r) partials (p, s start undefined: the first update has beta = 0 and skips them); also clears the recurrence scalars and the decision word
 // of the previous solve (two memset nodes on the stream cost ~20 us of idle device per solve)
 template <int BS>
@@ -127,7 +109,7 @@ __global__ __launch_bounds__(256) void k_cg_update(int64_t n_own, const double* 
                                                     double* __restrict__ x, double* __restrict__ r,
                                                     double* __restrict__ u, const double* __restrict__ w,
                                                     const double* __restrict__ dinv, double* __restrict__ pv, int nt,
-                                                    const PackMap pm, int ext) {
+                                                    const PackMap pm, int ext, double* __restrict__ hist) {
   if (*done) return;
   const double gamma = red[0], delta = red[1], rr = red[2];
   const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
@@ -158,6 +140,10 @@ __global__ __launch_bounds__(256) void k_cg_update(int64_t n_own, const double* 
     cur[SC_GAMMA] = gamma;
     cur[SC_IT] = it + 1.0;
     info[0] = it + 1.0;
+    if (hist && it < (double)GL_CG_HIST) {   // Lanczos coefficients of this solve (Ritz values -> interval of the dot-free solves)
+      hist[2 * (int)it] = alpha;
+      hist[2 * (int)it + 1] = beta;
+    }
   }
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   double pg = 0.0, pr = 0.0;   // partials of the NEXT iteration's gamma = r.u and rr = r.r
@@ -954,6 +940,60 @@ void gl_apply_dirichlet_c(glims_ctx* h) {
 }
 
 // ===================================================================================================
+// Dot-free RD linear solves: Chebyshev semi-iteration on the interval the run's right-hand sides excite
+// ===================================================================================================
+// Start of a solve: [warm start: r -= w (= A u), c += u;]  d_0 = Dinv r / theta,  delta = d_0, halo payload of d_0, and -- for
+// the device-side choice of the iteration count -- the partial sums of |r|^2.
+__global__ __launch_bounds__(256) void k_cheb_start(int64_t n_own, double* __restrict__ r, const double* __restrict__ w,
+                                                     double* __restrict__ c, const double* __restrict__ u,
+                                                     const double* __restrict__ dinv, double inv_theta,
+                                                     double* __restrict__ d, double* __restrict__ delta,
+                                                     double* __restrict__ pv, const PackMap pm) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double pr = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_own; i += stride) {
+    double ri = r[i];
+    if (w) {
+      ri -= w[i];
+      r[i] = ri;
+      c[i] += u[i];
+    }
+    const double d0 = inv_theta * dinv[i] * ri;
+    d[i] = d0;
+    delta[i] = d0;
+    if (pm.ref) pack_row<1>(pm, i, &d0);
+    pr += ri * ri;
+  }
+  if (pv) block_sum2(pr, 0.0, pv);
+}
+// Iteration count of a warm-started solve, on the device: the smallest m with 1 / T_m(sigma) <= tol / |r|, i.e.
+// m = ceil(acosh(|r| / tol) / acosh(sigma)), at least m_min (2 when no residual pass follows: the correction is added to the
+// iterate by pass m - 1), at most m_max; 0 = the warm start alone meets the tolerance.  Left in plan[0] for the launches and
+// in the Krylov info slot for the host's statistics (travels with the next decision mail).
+__global__ void k_cheb_plan(const double* __restrict__ red, double tol2, double inv_acosh_sigma, int m_min, int m_max,
+                            int* __restrict__ plan, double* __restrict__ info) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double rr = red[0];
+  int m = m_max;
+  if (isfinite(rr)) {
+    if (rr <= tol2) m = 0;
+    else {
+      const double q = sqrt(rr / tol2);
+      m = (int)ceil(log(q + sqrt(q * q - 1.0)) * inv_acosh_sigma);
+      m = max(m_min, min(m_max, m));
+    }
+  }
+  plan[0] = m;
+  info[0] = (double)m;
+  info[1] = rr;
+}
+// x -= delta (a Chebyshev solve taken back)
+__global__ void k_sub_inplace(int64_t n, double* __restrict__ x, const double* __restrict__ d) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] -= d[i];
+}
+
+// ===================================================================================================
 // single-reduction PCG.  On entry: r = residual of the current x (owned rows), x = current iterate.
 // ===================================================================================================
 struct CgVecs {
@@ -966,6 +1006,7 @@ struct CgVecs {
   const float* vals32 = nullptr;   // scalar operator in single precision (optional; streamed instead of vals)
   MgHierarchy* mg = nullptr;   // u = V-cycle(r) of this hierarchy instead of the (block-)Jacobi scaling
   int mg_degree = 3;           // Chebyshev degree of its smoothers
+  double* hist = nullptr;      // (alpha_k, beta_k) of the first GL_CG_HIST iterations are recorded here (device)
 };
 
 // w = A u with the fused dot product: one delta partial per SpMV block, interior launch first (slots [0, nbi)), then the
@@ -1068,7 +1109,7 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
     // (with an external preconditioner the update's |r|^2 pairs go to a buffer of their own: partials_v is rewritten by
     //  the cycle's last kernel)
     GL_VEC(k_cg_update, n, h->red.p, prev, cur, info_dev, h->done.p, tol2, v.p, v.s, v.x, v.r, v.u, v.w, v.dinv,
-           ext ? h->partials_rr.p : h->partials_v.p, /*nt=*/0, pm, ext);
+           ext ? h->partials_rr.p : h->partials_v.p, /*nt=*/0, pm, ext, v.hist);
     if (timed_upd) h->tick(glims_ctx::TK_UPDATE);
     if (early) {
       const bool decide = h->world <= 1 || h->nm.slots != nullptr;
@@ -1109,6 +1150,162 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
   if (done == 1) return GLIMS_OK;
   if (done == 2) return GLIMS_NAN;
   return GLIMS_NOT_CONVERGED;
+}
+
+// ---- the dot-free solve -------------------------------------------------------------------------------------------------
+// Chebyshev recurrence on [a, b]: d_0 = z_0 / theta;  d_k = rho_k rho_(k-1) d_(k-1) + (2 rho_k / delta) z_k,  z = Dinv r
+struct ChebRec {
+  double theta, delta, sigma, rho;
+  ChebRec(double a, double b) : theta(0.5 * (a + b)), delta(0.5 * (b - a)), sigma(theta / delta), rho(delta / theta) {}
+  void next(double* c1, double* c2) {
+    const double rn = 1.0 / (2.0 * sigma - rho);
+    *c1 = rn * rho;
+    *c2 = 2.0 * rn / delta;
+    rho = rn;
+  }
+  double inv_acosh_sigma() const { return 1.0 / std::log(sigma + std::sqrt(sigma * sigma - 1.0)); }
+  // operator-pass count for a residual reduction by `red` (< 1): smallest m with 1 / T_m(sigma) <= red
+  int iterations(double red) const {
+    if (!(red < 1.0)) return 0;
+    const double q = 1.0 / std::max(red, 1e-300);
+    return (int)std::ceil(std::log(q + std::sqrt(q * q - 1.0)) * inv_acosh_sigma());
+  }
+};
+
+// Extreme eigenvalues of the Lanczos matrix of a PCG solve (recorded alpha_k, beta_k; beta_0 = 0): the Ritz interval of
+// Dinv A on the Krylov space of THIS right-hand side.  Bisection on the Sturm sequence (m <= GL_CG_HIST).
+static bool ritz_interval(const double* hist, int m, double* lo, double* hi) {
+  if (m < 2) return false;
+  std::vector<double> a((size_t)m), b2((size_t)m, 0.0);   // diagonal, squared off-diagonal (b2[k] couples k-1 and k)
+  for (int k = 0; k < m; ++k) {
+    const double al = hist[2 * k], be = hist[2 * k + 1];
+    if (!(al > 0.0) || !std::isfinite(al) || !(be >= 0.0) || !std::isfinite(be)) return false;
+    a[(size_t)k] = 1.0 / al + (k > 0 ? be / hist[2 * (k - 1)] : 0.0);
+    if (k > 0) b2[(size_t)k] = be / (hist[2 * (k - 1)] * hist[2 * (k - 1)]);
+  }
+  double glo = 1e300, ghi = -1e300;
+  for (int k = 0; k < m; ++k) {
+    const double rad = (k > 0 ? std::sqrt(b2[(size_t)k]) : 0.0) + (k + 1 < m ? std::sqrt(b2[(size_t)k + 1]) : 0.0);
+    glo = std::min(glo, a[(size_t)k] - rad);
+    ghi = std::max(ghi, a[(size_t)k] + rad);
+  }
+  auto below = [&](double x) {   // eigenvalues < x
+    int cnt = 0;
+    double q = 1.0;
+    for (int k = 0; k < m; ++k) {
+      q = a[(size_t)k] - x - (k > 0 ? b2[(size_t)k] / q : 0.0);
+      if (q == 0.0) q = 1e-300;
+      if (q < 0.0) ++cnt;
+    }
+    return cnt;
+  };
+  double l0 = glo, l1 = ghi;   // smallest: the x where below(x) turns >= 1
+  for (int i = 0; i < 80; ++i) {
+    const double mid = 0.5 * (l0 + l1);
+    if (below(mid) >= 1) l1 = mid; else l0 = mid;
+  }
+  double h0 = glo, h1 = ghi;   // largest: the x where below(x) turns == m
+  for (int i = 0; i < 80; ++i) {
+    const double mid = 0.5 * (h0 + h1);
+    if (below(mid) >= m) h1 = mid; else h0 = mid;
+  }
+  *lo = 0.5 * (l0 + l1);
+  *hi = 0.5 * (h0 + h1);
+  return *lo > 0.0 && *hi > *lo && std::isfinite(*hi);
+}
+
+// A finished PCG solve of `its` iterations contributes its Ritz interval to the one being learnt
+static void cheb_learn(glims_ctx* h, int64_t its) {
+  const int m = (int)std::min<int64_t>(its, GL_CG_HIST);
+  if (m < 2 || !h->cg_hist.p) return;
+  double hist[2 * GL_CG_HIST];
+  GL_HIP(hipMemcpyAsync(hist, h->cg_hist.p, (size_t)2 * m * sizeof(double), hipMemcpyDeviceToHost, h->st));
+  GL_HIP(hipStreamSynchronize(h->st));
+  double lo, hi;
+  if (!ritz_interval(hist, m, &lo, &hi)) return;
+  glims_ctx::ChebState& cs = h->cheb;
+  if (getenv("GLIMS_VERBOSE"))
+    fprintf(stderr, "glims dot-free solves: PCG solve of %lld iterations, Ritz interval [%.4f, %.4f]\n", (long long)its, lo, hi);
+  cs.acc_lmin = cs.learned ? std::min(cs.acc_lmin, lo) : lo;
+  cs.acc_lmax = cs.learned ? std::max(cs.acc_lmax, hi) : hi;
+  cs.learned++;
+  h->stats.cheb_learn_solves++;
+}
+
+// Safety factors on the measured interval.  A lower end set too low only costs iterations (prototype: 0.5 x -> +50 %); an upper
+// end set too low makes the iteration diverge on what lies above it, so the Ritz value -- an estimate from inside -- gets more room.
+static const double GL_CHEB_LO = 0.85, GL_CHEB_HI = 1.08;
+static const int GL_CHEB_MAX = 96;
+
+struct ChebRun {
+  int passes = 0;        // operator passes enqueued that can run (host-known count), or the upper bound when planned
+  bool planned = false;  // the count is computed on the device; it arrives in the Krylov info of the next decision mail
+};
+
+// Solves A x = r for the correction of v.x (accumulated in cheb_delta, added to v.x by the last pass).  On entry v.r is the
+// residual at v.x -- or, with ws_w / ws_u, the residual BEFORE the warm start u is applied (r -= ws_w, x += ws_u happen in the
+// start kernel).  r_norm: |r| on entry if the host knows it (then the count is fixed here); <= 0: unknown (warm start,
+// midpoint correction) -- `norm_in_partials` says where the start of the solve finds it: 0 = the start kernel computes it,
+// n > 0 = the caller has left n pairs (|r|^2, .) in h->partials.
+static ChebRun cheb_solve(glims_ctx* h, const CgVecs& v, double tol_abs, double r_norm, double r_bound, bool want_res,
+                          const double* ws_w, const double* ws_u, int norm_in_partials) {
+  const DevPattern& p = h->pat;
+  const bool split = h->world > 1 && h->n_peers > 0;
+  const int64_t n = h->n_own;
+  h->cheb_delta.alloc((size_t)h->n_nodes);
+  h->cheb_plan.alloc(1);
+  ChebRec rec(GL_CHEB_LO * h->cheb.lmin, GL_CHEB_HI * h->cheb.lmax * h->cheb_test_hi);
+  PackMap pm;
+  if (split && h->n_send > 0) {
+    pm.ref = h->send_ref.p;
+    pm.ptr = h->send_slot_ptr.p;
+    pm.slot = h->send_slot.p;
+    pm.sendbuf = h->sendbuf.p;
+  }
+  ChebRun run;
+  run.planned = !(r_norm > 0.0);
+  const int m_min = want_res ? 1 : 2;
+  int m = 0;
+  if (run.planned) m = std::min(GL_CHEB_MAX, std::max(m_min, rec.iterations(tol_abs / std::max(r_bound, tol_abs)) + 3));
+  else if (r_norm > tol_abs) m = std::min(GL_CHEB_MAX, std::max(m_min, rec.iterations(tol_abs / r_norm)));
+  const unsigned g = grid_for(n);
+  double* info_dev = h->scal.p + 2 * SC_COUNT;
+  const bool start_norm = run.planned && norm_in_partials == 0;
+  hipLaunchKernelGGL(k_cheb_start, dim3(g), dim3(256), 0, h->st, n, v.r, ws_w, v.x, ws_u, v.dinv, 1.0 / rec.theta, v.p,
+                     h->cheb_delta.p, start_norm ? h->partials.p : (double*)nullptr, pm);
+  GL_HIP(hipGetLastError());
+  if (run.planned) {
+    reduce_partials(h, start_norm ? (int)g : norm_in_partials, 2, nullptr);
+    allreduce_sum(h, h->red.p, 2);
+    hipLaunchKernelGGL(k_cheb_plan, dim3(1), dim3(1), 0, h->st, (const double*)h->red.p, tol_abs * tol_abs,
+                       rec.inv_acosh_sigma(), m_min, m, h->cheb_plan.p, info_dev);
+    GL_HIP(hipGetLastError());
+  }
+  const int last = want_res ? m : m - 1;
+  run.passes = std::max(0, last);
+  double *d_in = v.p, *d_out = v.s;
+  for (int k = 1; k <= last; ++k) {
+    double c1 = 0.0, c2 = 0.0;
+    if (!want_res || k < m) rec.next(&c1, &c2);
+    const int* plan = run.planned ? h->cheb_plan.p : nullptr;
+    hipEvent_t* ev = h->timing(glims_ctx::TK_CHEB) ? h->pair(glims_ctx::TK_CHEB) : nullptr;
+    if (!split) {
+      gl_launch_cheb(h, h->st, p.n_slices, nullptr, v.vals, v.vals32, d_in, d_out, v.r, v.dinv, h->cheb_delta.p, v.x,
+                     v.fixed, c1, c2, k, m, plan, want_res ? 1 : 0, pm, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr);
+    } else {
+      // the ghosts of d_in travel (payload packed by the kernel that produced it) while the slices without ghost columns run
+      halo_start(h, d_in, 1, /*prepacked=*/true);
+      gl_launch_cheb(h, h->st, p.n_interior, p.interior_slices.p, v.vals, v.vals32, d_in, d_out, v.r, v.dinv,
+                     h->cheb_delta.p, v.x, v.fixed, c1, c2, k, m, plan, want_res ? 1 : 0, pm, ev ? ev[0] : nullptr,
+                     ev ? ev[1] : nullptr);
+      halo_finish(h);
+      gl_launch_cheb(h, h->st, p.n_boundary, p.boundary_slices.p, v.vals, v.vals32, d_in, d_out, v.r, v.dinv,
+                     h->cheb_delta.p, v.x, v.fixed, c1, c2, k, m, plan, want_res ? 1 : 0, pm);
+    }
+    std::swap(d_in, d_out);
+  }
+  h->stats.cheb_solves++;
+  return run;
 }
 
 // ===================================================================================================
@@ -1230,7 +1427,10 @@ void glims_ctx::timing_collect() {
     if (cev_used >= 2) GL_HIP(hipEventSynchronize(cev[cev_used - 1]));
     for (size_t q = 0; q + 1 < cev_used; q += 2) {
       float t = 0.f;
-      if (hipEventElapsedTime(&t, cev[q], cev[q + 1]) == hipSuccess) stats.ms_exchange += t;
+      if (hipEventElapsedTime(&t, cev[q], cev[q + 1]) == hipSuccess) {
+        stats.ms_exchange += t;
+        stats.halo_exchanges_timed++;   // (the pool holds 4096 pairs per call; exchanges beyond it are counted, not timed)
+      }
     }
     for (size_t q = 0; q + 1 < wev_used; q += 2) {
       float t = 0.f;
@@ -1247,11 +1447,11 @@ void glims_ctx::timing_collect() {
     d[std::min<int>(TK_COUNT - 1, tev_cat[q])].push_back(t);
   }
   double* sums[TK_COUNT] = {&stats.ms_spmv_steps, &stats.ms_sweep_steps, &stats.ms_update_steps, &stats.ms_mgfine_mech,
-                            &stats.ms_spmvb_mech, &stats.ms_quad_steps};
+                            &stats.ms_spmvb_mech, &stats.ms_quad_steps, &stats.ms_cheb_steps};
   int64_t* cnts[TK_COUNT] = {&stats.n_spmv_steps, &stats.n_sweep_steps, &stats.n_update_steps, &stats.n_mgfine_mech,
-                             &stats.n_spmvb_mech, &stats.n_quad_steps};
+                             &stats.n_spmvb_mech, &stats.n_quad_steps, &stats.n_cheb_steps};
   double* meds[TK_COUNT] = {&stats.us_spmv_median, &stats.us_sweep_median, &stats.us_update_median,
-                            &stats.us_mgfine_median, &stats.us_spmvb_median, &stats.us_quad_median};
+                            &stats.us_mgfine_median, &stats.us_spmvb_median, &stats.us_quad_median, &stats.us_cheb_median};
   for (int c = 0; c < TK_COUNT; ++c) {
     if (d[c].empty()) continue;
     // reference duration = the 90th percentile (no-op launches are the SHORT ones; a single pair that straddles a
@@ -1293,6 +1493,17 @@ int gl_step(glims_ctx* h, int n_steps) {
     const int64_t newton0 = h->stats.newton_its, cg0 = h->stats.cg_its;
     double norms[2] = {0.0, 0.0};
     double nr;
+    // Dot-free linear solves (glims_options.rd_linear): Jacobi-preconditioned RD solves run the Chebyshev iteration on the
+    // interval measured by the PCG solves of a LEARNING step -- the first step of a run, every 32nd one after it, and the
+    // step after a solve had to be taken back.
+    glims_ctx::ChebState& cb = h->cheb;
+    const bool cheb_allowed = o.rd_linear != GLIMS_RD_LINEAR_PCG && !rd_mg;
+    if (cheb_allowed && cb.valid && ++cb.age >= 32) cb.valid = false;
+    const bool cheb_learning = cheb_allowed && !cb.valid;
+    if (cheb_learning) {
+      cb.learned = 0;
+      h->cg_hist.alloc((size_t)2 * GL_CG_HIST);
+    }
     if (h->pending) {
       // the sweep that verified the previous step already assembled A(c^n) and -R(c^n; c^n) for this one
       nr = h->pending_r0;
@@ -1334,10 +1545,6 @@ int gl_step(glims_ctx* h, int n_steps) {
     // Copies of iterates are made only where a cheap evaluation follows (known before the solve): after a sweep the base
     // point c_0 IS the current iterate (`base_is_current`), so the first such copy serves as c_0 and as c_k (`ck_is_c0`);
     // a second cheap evaluation in a row copies c_k into a buffer of its own.  One 8 B / node copy per cheap evaluation.
-    // The midpoint correction of the first right-hand side (see the warm start below) costs a cheap pass and pays where
-    // it saves the step's fourth Newton iteration (config C4: steps 50-200 of the 500, 3.9 -> 3.3 iterations per step;
-    // nothing in the first 50).  So it is switched on after a step that took four, off again (for 16 steps) after a step
-    // that took four WITH it, and every 16th step runs without it to see whether three are reached anyway.
     // Default forcing (round 4): the FIRST solve of a step decides whether two Newton iterations can be enough.  With the
     // second solve's Jacobian at c_1, two iterations leave q_2 (r_1 / r_0)^2 r_0, q_2 = what the quadratic term alone leaves of
     // a whole step (5e-4 late in config C4's run) -- below the Newton target 1e-10 r_0 only if r_1 <= 4e-4 r_0, i.e. with the
@@ -1351,13 +1558,11 @@ int gl_step(glims_ctx* h, int n_steps) {
     // doing so is cheaper than a pass on every step), then 1; a step that
     // takes three WITH the correction sends the next 16 back to cg_rtol without it (mode 2: strong nonlinearity, where the
     // extra effort buys nothing); every 64th step in mode 1 tries mode 0 again; the first 8 steps of a run do not count (no
-    // increments to extrapolate from yet).  GLIMS_FLAG_FIXED_FORCING keeps round 3's rules:
-    // cg_rtol, and the correction switched on by steps of four iterations.
+    // increments to extrapolate from yet).  GLIMS_FLAG_FIXED_FORCING: cg_rtol for every solve, no correction (mode 2 throughout).
     const bool fixed_forcing = (o.flags & GLIMS_FLAG_FIXED_FORCING) != 0;
     const int nw_mode = (quad && !fixed_forcing) ? h->nw_mode : 2;
-    const bool mid_probe = fixed_forcing && h->mid_on && (++h->mid_streak % 16) == 0;
-    const bool midpoint = quad && (fixed_forcing ? (h->mid_on && !mid_probe) : nw_mode == 1);
-    const double first_rtol = (quad && !fixed_forcing && nw_mode != 2) ? 0.3 * o.cg_rtol : o.cg_rtol;
+    const bool midpoint = quad && nw_mode == 1;
+    const double first_rtol = (quad && nw_mode != 2) ? 0.3 * o.cg_rtol : o.cg_rtol;
     bool base_is_current = true, ck_is_c0 = false;
     // (margin 3: with 1 the cheap pass reported convergence unpredicted -- pass + confirming sweep -- in 14-28 % of the steps
     //  of C4 / C3, with 3 in 2 %; with 10 the failed confirmations are back)
@@ -1416,6 +1621,8 @@ int gl_step(glims_ctx* h, int n_steps) {
         GL_HIP(hipMemcpyAsync(ck_is_c0 ? h->nq_c0.p : h->nq_ck.p, h->c.p, (size_t)h->n_nodes * sizeof(double),
                               hipMemcpyDeviceToDevice, h->st));
       }
+      const bool use_cheb = cheb_allowed && cb.valid;
+      bool warm = false, ws_fused = false;
       if (it == 0 && (o.flags & GLIMS_FLAG_WARM_START) && !extrapolate) {   // both options own the c_old buffer
         // initial guess of the first linear solve = the increment predicted from the previous steps' (k_ws_delta): same linear
         // system, same solution, the Krylov iteration just starts closer.  One SpMV with the already assembled A(c^n).
@@ -1427,6 +1634,10 @@ int gl_step(glims_ctx* h, int n_steps) {
           gl_launch_spmv(h, h->st, p.n_slices, nullptr, h->vA.p, h->cg_u.p, h->cg_w.p,
                          h->have_fixed_c ? h->fixed_c.p : nullptr, nullptr, nullptr, nullptr, 0, nullptr,
                          h->jac32 ? h->vA32.p : nullptr);
+          warm = true;
+          // (dot-free solve without the midpoint correction: its start kernel applies the warm start and measures |r|)
+          ws_fused = use_cheb && !midpoint;
+          if (!ws_fused)
           hipLaunchKernelGGL(k_ws_apply, dim3(grid_exact(n)), dim3(256), 0, h->st, n, h->cg_r.p, h->cg_w.p, h->c.p,
                              h->cg_u.p);
           // Midpoint correction of the step's first right-hand side.  For the exactly quadratic residual the whole step
@@ -1456,12 +1667,31 @@ int gl_step(glims_ctx* h, int n_steps) {
       int64_t its = 0;
       double res = 0.0;
       const int slot = std::min(it, 7);
-      const int cs = cg_solve(h, v, tol_lin, o.cg_maxit, h->cg_hint[slot], &its, &res, /*defer=*/true);
-      const bool deferred = its < 0;
-      if (!deferred) {
-        h->cg_hint[slot] = (int)its;
-        h->stats.cg_its += its;
-        h->stats.last_cg_res = res;
+      int cs = GLIMS_OK;
+      bool deferred = false;
+      ChebRun crun;
+      if (use_cheb) {
+        // |r| on entry: known to the host unless a warm start (and the midpoint correction) has just changed r -- then the
+        // count is chosen on the device from the norm the start of the solve measures (midpoint: the correction's pass has
+        // left the partial sums of |r|^2 already)
+        crun = cheb_solve(h, v, tol_lin, warm ? 0.0 : nr, nr, cheap_next, ws_fused ? h->cg_w.p : nullptr,
+                          ws_fused ? h->cg_u.p : nullptr, (warm && midpoint) ? gl_rd_grid(h) : 0);
+        deferred = crun.planned;
+        if (!deferred) {
+          h->stats.cg_its += crun.passes;
+          h->stats.cheb_its += crun.passes;
+          h->stats.last_cg_res = tol_lin;
+        }
+      } else {
+        if (cheb_learning) v.hist = h->cg_hist.p;
+        cs = cg_solve(h, v, tol_lin, o.cg_maxit, h->cg_hint[slot], &its, &res, /*defer=*/!cheb_learning);
+        deferred = its < 0;
+        if (!deferred) {
+          h->cg_hint[slot] = (int)its;
+          h->stats.cg_its += its;
+          h->stats.last_cg_res = res;
+          if (cheb_learning && cs == GLIMS_OK) cheb_learn(h, its);
+        }
       }
       h->stats.newton_its++;
       if (cs != GLIMS_OK) {
@@ -1480,7 +1710,13 @@ int gl_step(glims_ctx* h, int n_steps) {
         base_is_current = true;   // a fresh Jacobian: A_0 = A(c) from here on
         rebase = false;
       }
-      if (deferred) {
+      if (deferred && use_cheb) {   // the count the device chose for the warm-started solve
+        const int64_t m_dev = (int64_t)km.info[0];
+        const int64_t passes = std::max<int64_t>(0, std::min<int64_t>(crun.passes, cheap ? m_dev : m_dev - 1));
+        h->stats.cg_its += passes;
+        h->stats.cheb_its += passes;
+        h->stats.last_cg_res = tol_lin;
+      } else if (deferred) {
         // the linear solve's outcome arrives with the sweep: a solve that used up its hint + 2 iterations simply
         // was a slightly weaker Newton step (the residual below decides); give it more room next time
         h->cg_hint[slot] = km.done == 1 ? (int)km.info[0] : (int)km.info[0] + 2;
@@ -1494,6 +1730,29 @@ int gl_step(glims_ctx* h, int n_steps) {
         if (km.done == 3) h->cg_hint[slot] = 0;   // breakdown: next time take the polled path
       }
       nr = norms[0];
+      if (use_cheb && getenv("GLIMS_VERBOSE_CHEB"))
+        fprintf(stderr, "  cheb: step %lld it %d  %.3e -> %.3e  tol_lin %.3e target %.3e  %s passes %d (m_dev %g) %s\n",
+                (long long)h->stats.steps, it, nr_before, nr, tol_lin, target, crun.planned ? "planned" : "host", crun.passes,
+                crun.planned ? km.info[0] : -1.0, cheap ? "cheap" : (speculate ? "sweep+spec" : "sweep"));
+      if (use_cheb && !(std::isfinite(nr) && (nr <= 0.5 * nr_before || nr <= target))) {
+        // The Newton residual did not contract: part of the right-hand side lies outside the interval (the Chebyshev polynomial
+        // grows there).  Take the correction back (it is still in cheb_delta), drop the interval -- this step's remaining
+        // solves and the next step's run PCG and measure it again -- and repeat the iteration from a fresh sweep.
+        if (getenv("GLIMS_VERBOSE"))
+          fprintf(stderr, "glims dot-free solves: step %lld, Newton iteration %d: residual %.3e -> %.3e (target %.3e, linear tolerance "
+                  "%.3e, %s count, %d passes enqueued) -- taken back, PCG from here\n", (long long)h->stats.steps, it, nr_before, nr,
+                  target, tol_lin, crun.planned ? "device-side" : "host-side", crun.passes);
+        hipLaunchKernelGGL(k_sub_inplace, dim3(grid_exact(n)), dim3(256), 0, h->st, n, h->c.p, h->cheb_delta.p);
+        GL_HIP(hipGetLastError());
+        cb.valid = false;
+        h->stats.cheb_fallbacks++;
+        h->pending = false;
+        rd_sweep(h, nullptr, norms, nullptr, /*exchange_c=*/true);
+        nr = norms[0];
+        base_is_current = true;
+        rebase = false;
+        continue;
+      }
       if (std::isfinite(nr) && nr_before > 0.0) {
         ratio_est = nr / nr_before;
         if (it == 0) h->nq_first_ratio = ratio_est;
@@ -1528,6 +1787,14 @@ int gl_step(glims_ctx* h, int n_steps) {
       }
     }
     ++h->nw_steps;
+    if (cheb_learning && status == GLIMS_OK && cb.learned > 0) {
+      cb.lmin = cb.acc_lmin;
+      cb.lmax = cb.acc_lmax;
+      cb.valid = true;
+      cb.age = 0;
+      h->stats.cheb_lmin = cb.lmin;
+      h->stats.cheb_lmax = cb.lmax;
+    }
     // (the first steps of a run have no increments to extrapolate from and take three iterations whatever the mode: they do
     //  not speak for it)
     if (quad && status == GLIMS_OK && !fixed_forcing && h->nw_steps > 8) {
@@ -1550,21 +1817,6 @@ int gl_step(glims_ctx* h, int n_steps) {
       } else if (--h->nw_hold <= 0) {
         h->nw_mode = 1;
         h->nw_since = 0;
-      }
-    } else if (quad && status == GLIMS_OK && fixed_forcing) {
-      const int64_t count = h->stats.newton_its - newton0;
-      if (midpoint) {
-        if (count >= 4) {
-          h->mid_on = false;
-          h->mid_cooldown = 16;
-        }
-      } else if (mid_probe) {
-        if (count <= 3) h->mid_on = false;
-      } else if (h->mid_cooldown > 0) {
-        --h->mid_cooldown;
-      } else if (count >= 4) {
-        h->mid_on = true;
-        h->mid_streak = 0;
       }
     }
     h->stats.last_newton_res = nr;

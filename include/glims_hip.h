@@ -29,6 +29,9 @@
  *   GLIMS_WIN_LIMIT      TEST HOOK: at most this many (<= 32) column windows per 64-row slice before a slice falls back
  *                        to 4-byte column indices -- lets tests/ exercise the mixed 16-bit / 32-bit index path on
  *                        meshes whose slices would all be compressible
+ *   GLIMS_CHEB_TEST_SCALE_HI  TEST HOOK (read once by glims_create, per handle): factor on the measured upper end of the
+ *                        spectral interval of the dot-free RD solves -- 0.5 makes their polynomial diverge on part of the
+ *                        right-hand side, so that tests/ can exercise the take-back / PCG fallback path
  *   GLIMS_MG_BOX_MIN_NODES  TEST HOOK: smallest replicated first grid (nodes, at least 6 001) on which a partitioned run
  *                        limits each rank's smoothing to its work box (see GLIMS_FLAG_MG_WHOLE_GRID), instead of the
  *                        library's estimate of what that saves -- lets tests/ exercise the path on small meshes
@@ -42,7 +45,7 @@
 extern "C" {
 #endif
 
-#define GLIMS_ABI_VERSION 5
+#define GLIMS_ABI_VERSION 6
 
 enum {
   GLIMS_OK = 0,
@@ -119,6 +122,24 @@ typedef struct glims_options {
                              [lambda/30, lambda] 2.9 / 7.4 / 46.2 (Jacobi-PCG: 4.4 / 26.5 / 486); on a Delaunay mesh of
                              200 k random points degree 1 / 3: 77 / 40 iterations per solve.  mg_cheb_ratio = 0 means 10
                              for this hierarchy                                                           default 0     */
+  /* ---- ABI 6: the Krylov iteration of the Jacobi-preconditioned RD solves, and how its operator streams are cached.  PETSc's
+   * counterpart is the KSP type (-ksp_type cg | chebyshev) behind solver.parameters (simulation_tumor_growth.py:126-130). */
+  int    rd_linear;       /* GLIMS_RD_LINEAR_AUTO | _PCG | _CHEBYSHEV.  CHEBYSHEV: the dot-free iteration -- ONE kernel per
+                             iteration (operator pass with the Chebyshev recurrence in its epilogue), no dot product, no
+                             reduction kernel, no all-reduce in partitioned runs; the iteration count follows from the wanted
+                             reduction and the interval [lmin, lmax] of Dinv A(c) that the run's right-hand sides excite, taken
+                             from the Lanczos coefficients of PCG solves: all solves of the first step after glims_set_state
+                             and of every 32nd step run PCG and (re)measure it.  Every solve is followed by a Newton residual
+                             evaluation anyway; one that did not contract (interval too narrow) is taken back, the interval
+                             dropped and the iteration repeated with PCG (glims_stats.cheb_fallbacks).  Same iteration counts
+                             as PCG +-1 on the BASELINE configs (tools/proto_chebyshev.py).  AUTO = CHEBYSHEV wherever the RD
+                             solves are Jacobi-preconditioned; solves with the multigrid preconditioner always use PCG
+                                                                                                          default AUTO  */
+  int    stream_policy;   /* GLIMS_STREAM_AUTO | _NONTEMPORAL | _CACHED: cache policy of the operator's value / column-code
+                             streams in the Krylov operator pass.  Non-temporal keeps the gathered vector in L2 when the
+                             operator is far larger than the 256 MiB Infinity Cache (config C4: +3 %); default-policy loads
+                             let a small operator (a 1/8 share of C4 per GPU) stay resident between the passes of a solve.
+                             AUTO picks by the working set at glims_setup              default AUTO  */
 } glims_options;
 
 #define GLIMS_PRECOND_BLOCK_JACOBI 0
@@ -126,6 +147,12 @@ typedef struct glims_options {
 #define GLIMS_RD_PRECOND_AUTO 0
 #define GLIMS_RD_PRECOND_JACOBI 1
 #define GLIMS_RD_PRECOND_MULTIGRID 2
+#define GLIMS_RD_LINEAR_AUTO 0
+#define GLIMS_RD_LINEAR_PCG 1
+#define GLIMS_RD_LINEAR_CHEBYSHEV 2
+#define GLIMS_STREAM_AUTO 0
+#define GLIMS_STREAM_NONTEMPORAL 1
+#define GLIMS_STREAM_CACHED 2
 
 #define GLIMS_FLAG_EXTRAPOLATE_GUESS 1  /* Newton guess c^n + (c^n - c^{n-1}) instead of c^n (reference: c^n) */
 #define GLIMS_FLAG_FP32_JACOBIAN 4       /* OFF by default.  The Newton Jacobian A(c) is stored and streamed in single
@@ -152,12 +179,18 @@ typedef struct glims_options {
 #define GLIMS_FLAG_INT32_COLUMNS 16       /* OFF by default.  Stream the 4-byte column indices everywhere instead of the 16-bit
                                            (window, offset) codes (same bits in every result; takes effect at glims_setup) */
 #define GLIMS_FLAG_FIXED_FORCING 256      /* OFF by default.  Every linear solve of the RD Newton iteration is asked for cg_rtol x
-                                           its right-hand side (and the midpoint correction of a step's first right-hand side is
-                                           switched on by steps of four iterations): round 3's rules.  Default: a step's FIRST
-                                           solve runs at 0.3 cg_rtol, with that correction once steps start taking a third
-                                           iteration; from the second solve on the tolerance follows the quadratic remainder the
-                                           iteration is about to leave (q |R_k|^2 / |R_0|, q observed in the step's first
-                                           iteration) -- two Newton iterations per step where the fixed rules take three to four */
+                                           its right-hand side and no right-hand side gets the midpoint correction (steps of
+                                           three to four Newton iterations: the textbook inexact Newton the tests compare
+                                           with).  Default: a step's FIRST solve runs at 0.3 cg_rtol, with that correction once
+                                           steps start taking a third iteration; from the second solve on the tolerance follows
+                                           the quadratic remainder the iteration is about to leave (q |R_k|^2 / |R_0|, q observed
+                                           in the step's first iteration) -- two Newton iterations per step */
+#define GLIMS_FLAG_MG_NO_LUMPING 512      /* OFF by default.  Mesh -> first-grid Galerkin product of the multigrid hierarchies: mesh
+                                           edges whose end points' parents lie more than the stencil radius apart lose their
+                                           cross terms only.  Default: a far POSITIVE coupling is lumped onto the two rows' own
+                                           diagonals (the edge's term taken out whole: positive semi-definite, row sums kept) --
+                                           sliver meshes 51 / 45 / 35 -> 48 / 39 / 32 iterations; lattices and quality-controlled
+                                           meshes have no such edges and are not affected (rebuilds the hierarchies) */
 #define GLIMS_FLAG_WARM_START 2         /* first linear solve of a step starts from the increment extrapolated from the previous two steps'
                                            (ignored when GLIMS_FLAG_EXTRAPOLATE_GUESS is set) */
 
@@ -230,6 +263,21 @@ typedef struct glims_stats {
   int64_t reduce_transport; /* how they travel: 0 single rank, 1 node mailbox (inside the reduction kernel), 2 ncclAllReduce,
                                3 host callback */
   int64_t mg_grid1_bytes;   /* elasticity multigrid: bytes of the first Cartesian grid's operator held by this rank */
+  /* ---- ABI 6 */
+  int64_t halo_exchanges_timed; /* exchanges that carried an event pair (ms_exchange / this = time per exchange; the event pools hold
+                               4096 pairs per glims_step call, exchanges of the multigrid's first grid and of host transports
+                               carry none) */
+  int64_t cheb_solves;      /* RD linear solves by the dot-free Chebyshev iteration (glims_options.rd_linear) */
+  int64_t cheb_its;         /* ... their operator passes (also counted in cg_its: "Krylov iterations") */
+  int64_t cheb_fallbacks;   /* ... taken back because the Newton residual did not contract; repeated with PCG */
+  int64_t cheb_learn_solves;/* PCG solves whose Lanczos coefficients (re)measured the interval */
+  double  cheb_lmin;        /* the interval of Dinv A(c) in use (0 = none yet) */
+  double  cheb_lmax;
+  double  ms_cheb_steps;    /* time_kernels != 0: launches of the dot-free iteration's kernel (k_cheb) inside glims_step */
+  int64_t n_cheb_steps;
+  double  us_cheb_median;
+  int64_t stream_nontemporal; /* what stream_policy resolved to: 1 non-temporal, 0 cached */
+  int64_t krylov_working_set; /* bytes the operator pass + vector update of one Krylov iteration touch (what AUTO decides on) */
 } glims_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------------------- */

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for name in _declared():
         assert hasattr(lib, name), "libglimship.so does not export %s" % name
     assert set(_declared()) == set(_backend.SIGNATURES), "ctypes table and header disagree"
-    assert lib.glims_abi_version() == _backend.ABI_VERSION == 5
+    assert lib.glims_abi_version() == _backend.ABI_VERSION == 6
 
 
 def test_struct_layouts_match_header_field_order():

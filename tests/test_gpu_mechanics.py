@@ -335,21 +335,15 @@ def test_multigrid_on_a_larger_delaunay_mesh_with_slivers(backend):
     assert rel_l2(us["half"], us["single"]) < 1e-6 and rel_l2(us["half"], us["block-jacobi"]) < 1e-5
 
 
-def test_sliver_mesh_far_couplings_lumped_and_the_polynomial_cycle_is_an_option(backend, monkeypatch):
+def test_sliver_mesh_far_couplings_are_lumped(backend):
     """Random-point Delaunay meshes have edges whose end points' parents lie more than the stencil radius apart on the first
-    grid.  (1) Default: far POSITIVE couplings are lumped onto the row's own diagonal in the mesh -> grid Galerkin product
+    grid.  Default: far POSITIVE couplings are lumped onto the rows' own diagonals in the mesh -> grid Galerkin product
     (mg.hip, k_mg_kp) -- never more iterations than with those couplings losing their cross terms only
-    (GLIMS_MG_NO_LUMPING=1), same displacement.  (2) GLIMS_MG_POLY=4 (opt-in): the second grid is solved by a Chebyshev
-    polynomial in (V-cycle x operator); a linear symmetric preconditioner, so PCG still converges to the same displacement.
-    On a lattice mesh the set-up finds nothing to accelerate and the cycle stays the plain one (same iteration count)."""
+    (GLIMS_FLAG_MG_NO_LUMPING), same displacement.  On a lattice mesh nothing is dropped: the flag changes nothing."""
     w = workloads.config_unstructured(60000, mechanics=True)
     res = {}
-    for name, env in (("default", {}), ("no lumping", {"GLIMS_MG_NO_LUMPING": "1"}), ("polynomial", {"GLIMS_MG_POLY": "4"})):
-        for k in ("GLIMS_MG_NO_LUMPING", "GLIMS_MG_POLY"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        h, dofs = _c5_handle(backend, w, mech_history=0)
+    for name, flags in (("default", backend.FLAG_WARM_START), ("no lumping", backend.FLAG_WARM_START | backend.FLAG_MG_NO_LUMPING)):
+        h, dofs = _c5_handle(backend, w, mech_history=0, flags=flags)
         assert h.solve_mechanics() == 0
         res[name] = (h.stats()['mech_cg_its'], h.get_state()[1], _free_residual(h, w.c0, h.get_state()[1], dofs))
         h.close()
@@ -358,15 +352,10 @@ def test_sliver_mesh_far_couplings_lumped_and_the_polynomial_cycle_is_an_option(
         assert res[name][2] < 1e-8
         assert rel_l2(res[name][1], res["default"][1]) < 1e-6
     assert res["default"][0] <= res["no lumping"][0] + 1
-    assert res["polynomial"][0] <= 2 * res["default"][0]     # (at par or worse on the device: DESIGN.md section 10)
-    # lattice: nothing is dropped, the spectrum of (V-cycle x operator) is [0.46, 1]: the option changes nothing
     wl = _c5_reduced(40)
     its = []
-    for poly in (None, "4"):
-        monkeypatch.delenv("GLIMS_MG_POLY", raising=False)
-        if poly:
-            monkeypatch.setenv("GLIMS_MG_POLY", poly)
-        h, _ = _c5_handle(backend, wl, mech_history=0)
+    for flags in (backend.FLAG_WARM_START, backend.FLAG_WARM_START | backend.FLAG_MG_NO_LUMPING):
+        h, _ = _c5_handle(backend, wl, mech_history=0, flags=flags)
         assert h.solve_mechanics() == 0
         its.append(h.stats()['mech_cg_its'])
         h.close()
