@@ -18,6 +18,12 @@ import os
 import sys
 import time
 
+# numpy's BLAS threads busy-wait after a call, one per VISIBLE core (256 on the GPU boxes), while the job's CPU share is 16:
+# the cgroup is then throttled for tens of milliseconds, which shows as 2-3x slower time steps at 1 M rows
+# (profiles/r05_blas_threads_throttle.txt).  This program needs BLAS for a few norms only: one thread.
+for _v in ("OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "1")
+
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -28,6 +34,40 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-leve
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def kernels_sha16():
+    """Hash of the library's sources: figures measured by another run (profiles/*.json) are only quoted for the same kernels."""
+    import glob
+    import hashlib
+    hs = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(HERE, "glimslib_amd", "csrc", "*.hip")) +
+                    glob.glob(os.path.join(HERE, "glimslib_amd", "csrc", "*.h")) +
+                    glob.glob(os.path.join(HERE, "glimslib_amd", "csrc", "*.cpp"))):
+        hs.update(open(f, "rb").read())
+    return hs.hexdigest()[:16]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process (torch.distributed.run), relay its one
+    JSON line and return its exit code.  Nothing in this process has touched the GPU (torch is not even imported yet)."""
+    import socket
+    import subprocess
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("[bench] --gpus %d without WORLD_SIZE: launching %s" % (args.gpus, " ".join(cmd[1:9])))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    return r.returncode
 
 
 def _time_c_oracle(w, budget_s, min_steps, warm=True):
@@ -212,6 +252,124 @@ def alt_c5(Handle, device, steps=10, warmup=10):
     return out
 
 
+def cheb_bytes(nnz, n_rows):
+    """Algorithmic bytes of one pass of the dot-free Krylov iteration (k_cheb): the CSR SpMV's 12 nnz + 4 rows + 8 rows of
+    gathered direction, plus the recurrence's vector work: r read + written, Dinv, delta read + written, new direction
+    (48 B per row) = 12 nnz + 60 rows."""
+    return 12 * int(nnz) + 60 * int(n_rows)
+
+
+def load_pmc(st, candidates):
+    """Committed PMC summary (tools/pmc_summary.py) of the same operator, or (None, None)."""
+    for cand in candidates:
+        try:
+            q = json.load(open(os.path.join(HERE, "profiles", cand)))
+            if q["n_rows"] == st['n_rows'] and q["nnz"] == st['nnz']:
+                return q, "profiles/" + cand
+        except Exception:   # noqa: BLE001
+            continue
+    return None, None
+
+
+def pmc_lookup(pmc, prefix):
+    if pmc is None:
+        return None
+    keys = [k for k in pmc["kernels"] if k.startswith(prefix)]
+    if not keys:
+        return None
+    if prefix in ("k_rd_assemble", "k_rd_quad"):      # one launch per slice class: a sweep is the sum of them
+        return sum(pmc["kernels"][k]["hbm_bytes_per_launch"] for k in keys)
+    return pmc["kernels"][keys[0]]["hbm_bytes_per_launch"]
+
+
+def kernel_list(s, k, steps, step_ms, k_steps, unr, pmc=None):
+    """Per-kernel roofline entries: s = stats of the timed steps (time_kernels = 1: operator passes), k = stats of the short
+    pass with event pairs around every hot kernel (time_kernels = 2), or None."""
+    out = []
+
+    def entry(name, what, alg, ms, cnt, med, n_steps, ms_step, where, pmc_prefix):
+        if cnt <= 0:
+            return
+        mean_us = 1e3 * ms / cnt
+        tb = pmc_lookup(pmc, pmc_prefix)
+        out.append({"name": name, "does": what, "algorithmic_bytes_per_launch": alg, "median_us": med,
+                    "mean_us": mean_us, "launches_per_step": cnt / float(n_steps),
+                    "achieved_GBps": alg / (mean_us * 1e-6) / 1e9, "frac": alg / (mean_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                    "share_of_step": ms / (ms_step * n_steps), "traffic_bytes_per_launch": tb,
+                    "achieved_real_GBps": None if tb is None else tb / (mean_us * 1e-6) / 1e9, "timed": where})
+
+    where = "HIP events inside the %d timed steps" % steps
+    entry("k_cheb<%d, NT, 1, double>" % unr, "one pass of the dot-free Krylov iteration: r -= A d (SELL-64, 16-bit column codes) "
+          "with the Chebyshev recurrence in the epilogue (algorithmic bytes: 12 nnz + 60 rows)",
+          cheb_bytes(s['nnz'], s['n_rows']), s['ms_cheb_steps'], s['n_cheb_steps'], s['us_cheb_median'], steps, step_ms,
+          where, "k_cheb")
+    entry("k_spmv<1, %d, NT, 1, double>" % unr, "y = A(c) x, SELL-64 with 16-bit column codes, fused w.u partials (PCG solves of "
+          "the learning steps; algorithmic bytes: CSR with 4-byte columns, 12 nnz + 20 rows)",
+          12 * s['nnz'] + 20 * s['n_rows'], s['ms_spmv_steps'], s['n_spmv_steps'], s['us_spmv_median'], steps, step_ms, where,
+          "k_spmv<1")
+    if k is not None:
+        kms = k['ms_steps'] / k_steps
+        where = "HIP events in a separate pass of %d steps right after the timed ones" % k_steps
+        entry("k_rd_assemble_s<4, CAP, RB, 1, double> (one launch per slice class)", "Jacobian + Newton residual(s) in one "
+              "sweep over the (row, cell) incidences (algorithmic bytes: 12 per incidence + 20 per stored entry + 32 per row)",
+              12 * s['n_corners'] + 20 * s['nnz'] + 32 * s['n_rows'], k['ms_sweep_steps'], k['n_sweep_steps'],
+              k['us_sweep_median'], k_steps, kms, where, "k_rd_assemble")
+        entry("k_rd_quad_s<4, CAP, RB, 1> (one launch per slice class)", "Newton residual from the quadratic structure "
+              "(algorithmic bytes: 8 per incidence + 4 per stored entry + 24 per row)",
+              8 * s['n_corners'] + 4 * s['nnz'] + 24 * s['n_rows'], k['ms_quad_steps'], k['n_quad_steps'],
+              k['us_quad_median'], k_steps, kms, where, "k_rd_quad")
+        entry("k_cg_update<1>", "PCG recurrence + vector update (96 B per row; learning steps only)", 96 * s['n_rows'],
+              k['ms_update_steps'], k['n_update_steps'], k['us_update_median'], k_steps, kms, where, "k_cg_update<1>")
+    return out
+
+
+def solver_counts(s, steps):
+    return {"newton_its_per_step": s['newton_its'] / steps, "krylov_passes_per_step": s['cg_its'] / steps,
+            "chebyshev_solves_per_step": s['cheb_solves'] / steps, "chebyshev_passes_per_step": s['cheb_its'] / steps,
+            "chebyshev_fallbacks": int(s['cheb_fallbacks']), "pcg_learning_solves": int(s['cheb_learn_solves']),
+            "spectral_interval": [s['cheb_lmin'], s['cheb_lmax']],
+            "assemblies_per_step": s['rd_assemblies'] / steps,
+            "quadratic_residual_updates_per_step": s['rd_quad_updates'] / steps,
+            "stream_policy": "non-temporal" if s['stream_nontemporal'] else "cached",
+            "krylov_working_set_bytes": int(s['krylov_working_set'])}
+
+
+def alt_rank_sized(Handle, device, headline_ns_per_row, steps=20, warmup=5, n=107):
+    """The per-rank share of an 8-GPU run of config C4 on ONE GPU: the brain-extent box at n = 107 (1.26 M rows = C4 / 8), same
+    parameters -- the regime that decides the 8-GPU number (small-problem efficiency, not communication): ms per step, the
+    per-row rate relative to the headline's, and the per-kernel list."""
+    from glimslib_amd import workloads
+    w = workloads.by_name("c4", n)
+    rows = w.mesh.num_vertices()
+    h = Handle(w.mesh.points, w.mesh.cells, w.cell_label, device=device)
+    t = w.tables
+    h.set_materials(t['D'], t['rho'], t['gamma'], t['E'], t['nu'])
+    h.set_options(dt=w.dt, time_kernels=1)
+    h.setup(with_mechanics=False)
+    h.set_state(w.c0)
+    st = h.step(warmup)
+    h.reset_stats()
+    t0 = time.perf_counter()
+    st |= h.step(steps)
+    el = time.perf_counter() - t0
+    s = h.stats()
+    k_steps = 5
+    h.set_options(time_kernels=2)
+    h.reset_stats()
+    st |= h.step(k_steps)
+    k = h.stats()
+    ns_row = 1e9 * el / steps / rows
+    out = {"workload": w.name + " (1/8 of config C4)", "dofs": rows, "steps": steps, "warmup": warmup,
+           "ms_per_step": 1e3 * el / steps, "value": rows * steps / el, "solver_status": int(st),
+           "ns_per_row_and_step": ns_row, "headline_ns_per_row_and_step": headline_ns_per_row,
+           "per_row_rate_relative_to_headline": (headline_ns_per_row / ns_row) if headline_ns_per_row else None,
+           "projected_8gpu_speedup_without_communication": (8.0 * headline_ns_per_row / ns_row) if headline_ns_per_row else None}
+    out.update(solver_counts(s, steps))
+    out["kernels"] = kernel_list(s, k, steps, 1e3 * el / steps, k_steps, 8)
+    h.close()
+    return out
+
+
 def alt_unstructured(Handle, device, steps=20, warmup=5, n_points=1000000):
     """The brain-like unstructured mesh (workloads.config_brain_like: ~1 M nodes, quality-controlled Delaunay tetrahedra,
     curved two-tissue interface, config C3's parameters) under the driver's clock -- the stand-in for the CGAL atlas
@@ -238,42 +396,19 @@ def alt_unstructured(Handle, device, steps=20, warmup=5, n_points=1000000):
     s = h.stats()
     out = {"workload": w.name, "dofs": n, "cells": w.mesh.num_cells(), "steps": steps, "warmup": warmup,
            "ms_per_step": 1e3 * el / steps, "value": n * steps / el, "solver_status": int(st),
-           "newton_its_per_step": s['newton_its'] / steps, "pcg_its_per_step": s['cg_its'] / steps,
-           "assemblies_per_step": s['rd_assemblies'] / steps, "quadratic_residual_updates_per_step": s['rd_quad_updates'] / steps,
+           "pcg_its_per_step": s['cg_its'] / steps,
            "preconditioner": {1: "jacobi", 2: "multigrid"}.get(int(s['rd_precond_used']), "?"),
            "nnz": int(s['nnz']), "nnz_padded": int(s['nnz_padded']), "n_corners": int(s['n_corners']),
            "mesh_seconds": t_mesh, "setup_seconds": t_setup}
+    out.update(solver_counts(s, steps))
     k_steps = 5
     h.set_options(time_kernels=2)
     h.reset_stats()
     st |= h.step(k_steps)
     k = h.stats()
-    kms = k['ms_steps'] / k_steps
-    kernels = []
-
-    def entry(name, what, alg, ms, cnt, med, n_steps, step_ms, where):
-        if cnt <= 0:
-            return
-        mean_us = 1e3 * ms / cnt
-        kernels.append({"name": name, "does": what, "algorithmic_bytes_per_launch": alg, "median_us": med,
-                        "mean_us": mean_us, "launches_per_step": cnt / float(n_steps),
-                        "achieved_GBps": alg / (mean_us * 1e-6) / 1e9, "frac": alg / (mean_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                        "share_of_step": ms / (step_ms * n_steps), "timed": where})
-
-    entry("k_spmv<1, 16, 1, 1, double>", "y = A(c) x, SELL-64 with 16-bit column codes, fused w.u partials (algorithmic "
-          "bytes: CSR with 4-byte columns, 12 nnz + 20 rows)", workloads.b_spmv_bytes(s['nnz'], s['n_rows']),
-          s['ms_spmv_steps'], s['n_spmv_steps'], s['us_spmv_median'], steps, 1e3 * el / steps,
-          "HIP events inside the %d timed steps" % steps)
-    where = "HIP events in a separate pass of %d steps right after the timed ones" % k_steps
-    entry("k_rd_assemble_s<4, CAP, RB, 1, double> (one launch per slice class)", "Jacobian + Newton residual(s) in one sweep over the (row, cell) incidences "
-          "(algorithmic bytes: 12 per incidence + 20 per stored entry + 32 per row; unpadded counts)",
-          12 * s['n_corners'] + 20 * s['nnz'] + 32 * s['n_rows'],
-          k['ms_sweep_steps'], k['n_sweep_steps'], k['us_sweep_median'], k_steps, kms, where)
-    entry("k_rd_quad_s<4, CAP, RB, 1> (one launch per slice class)", "Newton residual from the quadratic structure (algorithmic bytes: 8 per incidence + 4 per "
-          "stored entry + 24 per row)", 8 * s['n_corners'] + 4 * s['nnz'] + 24 * s['n_rows'],
-          k['ms_quad_steps'], k['n_quad_steps'], k['us_quad_median'], k_steps, kms, where)
-    entry("k_cg_update<1>", "PCG recurrence + vector update (96 B per row)", 96 * s['n_rows'],
-          k['ms_update_steps'], k['n_update_steps'], k['us_update_median'], k_steps, kms, where)
+    pmc, pmc_file = load_pmc(s, ("r05_pmc_bl.json", "r04_a_pmc_bl.json"))
+    kernels = kernel_list(s, k, steps, 1e3 * el / steps, k_steps, 16, pmc)
+    out["traffic_source"] = None if pmc is None else "lookup, not measured in this run: " + pmc_file
     out["kernels"] = kernels
     out["solver_status"] = int(st)
     h.close()
@@ -306,6 +441,9 @@ def main():
                          "the residual after a solve from the quadratic structure)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
     # stdout carries exactly ONE line, the JSON result of rank 0.  Libraries below us write there too (gloo announces
     # "[Gloo] Rank r is connected to n peer ranks" on stdout when a process group forms): everything written to fd 1
     # from here on goes to stderr, the result line is written to the saved descriptor at the end.
@@ -317,9 +455,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            log("bench.py: --gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
-            sys.exit(2)
         args.gpus = world
 
     import torch
@@ -349,7 +484,20 @@ def main():
     # N > 1 on the box configs: every rank builds only its own share of the mesh (same partition, array by array, as
     # cutting the whole mesh: tests/test_partition_box.py)
     lw = workloads.local_by_name(args.workload, args.n or None, world, rank) if world > 1 else None
+    if lw is None and world > 1 and args.workload.lower() in ("bl", "brain_like", "brain-like"):
+        # the unstructured mesh is built ONCE (rank 0, worker processes of a child interpreter) and handed to the other ranks
+        # through the mesh cache in shared memory; every rank then cuts its own part out of it
+        cache = os.path.join("/dev/shm", "glims_mesh_%s" % os.environ.get("MASTER_PORT", "0"))
+        os.environ["GLIMS_MESH_CACHE"] = cache
+        if rank == 0:
+            workloads.by_name(args.workload, args.n or None)
+        dist.barrier()
     w = lw if lw is not None else workloads.by_name(args.workload, args.n or None)
+    if lw is None and world > 1 and "GLIMS_MESH_CACHE" in os.environ and os.environ["GLIMS_MESH_CACHE"].startswith("/dev/shm/glims_mesh_"):
+        dist.barrier()
+        if rank == 0:
+            import shutil
+            shutil.rmtree(os.environ["GLIMS_MESH_CACHE"], ignore_errors=True)
     n_global = lw.n_nodes if lw is not None else w.mesh.num_vertices()
     if rank == 0:
         log("[bench] workload %s: %d nodes, %d cells (%s in %.1f s)" %
@@ -472,115 +620,61 @@ def main():
         log("[bench] WARNING: solver status %d after %d of %d steps; throughput counts completed steps only" %
             (status, steps_done, args.steps))
 
-    # ---- roofline of the dominant kernel: SELL-64 SpMV with the RD Jacobian A(c) ------------------------
-    # algorithmic bytes per launch = 12*nnz + 20*rows of THIS rank's operator;
-    # duration (a) inside the timed region: HIP events on the library's stream around every Krylov SpMV launch of the
-    # steps (glims_options.time_kernels), (b) after it: `spmv_reps` back-to-back launches of the same operator
-    # without the fused dot product (glims_apply).  The same event pairs time the other two hot kernels of a step.
+    # ---- roofline of the dominant kernel --------------------------------------------------------------------------------
+    # The step's dominant kernel is the operator pass of the Krylov iteration: k_cheb (dot-free Chebyshev iteration, the default
+    # wherever the RD solves are Jacobi-preconditioned) or k_spmv<1,..> (PCG: learning steps, multigrid-preconditioned solves,
+    # rd_linear = PCG).  Algorithmic bytes per launch = SURVEY 8(d)'s CSR figure 12 nnz + 20 rows for the SpMV, plus the
+    # recurrence's 40 B per row of vector traffic for k_cheb (cheb_bytes);
+    # duration (a) inside the timed region: HIP events attached to every such launch of the steps (glims_options.time_kernels),
+    # (b) after it: `spmv_reps` back-to-back launches of the plain SpMV (glims_apply).
     x = np.random.default_rng(0).standard_normal(h.n_nodes)
     h.apply(0, x, reps=5)
     _, ms = h.apply(0, x, reps=args.spmv_reps)
-    t_spmv = ms * 1e-3 / args.spmv_reps
-    b_alg = workloads.b_spmv_bytes(st['nnz'], st['n_rows'])
-    t_isolated = t_spmv
-    in_step = st.get('n_spmv_steps', 0) > 0
-    post_pass = (not in_step) and st_k is not None and st_k.get('n_spmv_steps', 0) > 0
-    if in_step:
-        t_spmv = st['ms_spmv_steps'] * 1e-3 / st['n_spmv_steps']
-    elif post_pass:
-        t_spmv = st_k['ms_spmv_steps'] * 1e-3 / st_k['n_spmv_steps']
-    achieved = b_alg / t_spmv / 1e9
+    t_isolated = ms * 1e-3 / args.spmv_reps
+    cheb_dominant = st.get('n_cheb_steps', 0) > 0 and st['ms_cheb_steps'] >= st['ms_spmv_steps']
+    in_step = cheb_dominant or st.get('n_spmv_steps', 0) > 0
+    if cheb_dominant:
+        t_op = st['ms_cheb_steps'] * 1e-3 / st['n_cheb_steps']
+        b_alg = cheb_bytes(st['nnz'], st['n_rows'])
+        n_timed, med_us = int(st['n_cheb_steps']), st['us_cheb_median']
+    elif in_step:
+        t_op = st['ms_spmv_steps'] * 1e-3 / st['n_spmv_steps']
+        b_alg = workloads.b_spmv_bytes(st['nnz'], st['n_rows'])
+        n_timed, med_us = int(st['n_spmv_steps']), st['us_spmv_median']
+    else:
+        t_op = t_isolated
+        b_alg = workloads.b_spmv_bytes(st['nnz'], st['n_rows'])
+        n_timed, med_us = args.spmv_reps, None
+    achieved = b_alg / t_op / 1e9
     # HBM-side bytes per launch from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate rocprofv3 runs,
     # calibrated on kernels with exactly known byte counts).  A LOOKUP into the committed summary of those passes, not
     # a measurement of this run: only reported when this run's operator is the one the passes measured, and
     # `traffic_source` names the file.
-    pmc, pmc_file = None, None
-    for cand in ("r04_a_pmc_c4.json", "r03_f_pmc_c4.json", "r03_e_pmc_c4.json", "r03_d_pmc_c4.json", "r03_c_pmc_c4.json", "r03_b_pmc_c4.json", "r02_pmc_c4.json", "r01_pmc_c4.json"):
-        try:
-            q = json.load(open(os.path.join(HERE, "profiles", cand)))
-            if world == 1 and q["n_rows"] == st['n_rows'] and q["nnz"] == st['nnz']:
-                pmc, pmc_file = q, "profiles/" + cand
-                break
-        except Exception:   # noqa: BLE001
-            continue
-
-    def pmc_bytes(prefix):
-        if pmc is None:
-            return None
-        keys = [k for k in pmc["kernels"] if k.startswith(prefix)]
-        if not keys:
-            return None
-        if prefix in ("k_rd_assemble", "k_rd_quad"):      # one launch per slice class: a sweep is the sum of them
-            return sum(pmc["kernels"][k]["hbm_bytes_per_launch"] for k in keys)
-        return pmc["kernels"][keys[0]]["hbm_bytes_per_launch"]
-
-    traffic = pmc_bytes("k_spmv<1" if (in_step or post_pass) else "k_spmv<0")
+    pmc, pmc_file = load_pmc(st, ("r05_pmc_c4.json", "r04_a_pmc_c4.json")) if world == 1 else (None, None)
+    unr = 16 if args.workload.lower() in ("bl", "brain_like", "brain-like", "u", "unstructured") else 8
+    traffic = pmc_lookup(pmc, "k_cheb" if cheb_dominant else "k_spmv<1" if in_step else "k_spmv<0")
     steps_n = max(1, steps_done)
     ms_step = 1e3 * elapsed / steps_n
-    kernels = []
-
-    def kernel_entry(name, what, alg_bytes, sum_ms, count, median_us, pmc_prefix, n_steps, step_ms, where):
-        if count <= 0:
-            return
-        mean_us = 1e3 * sum_ms / count
-        tb = pmc_bytes(pmc_prefix)
-        kernels.append({"name": name, "does": what, "algorithmic_bytes_per_launch": alg_bytes,
-                        "median_us": median_us, "mean_us": mean_us, "launches_per_step": count / float(n_steps),
-                        "achieved_GBps": alg_bytes / (mean_us * 1e-6) / 1e9,
-                        "frac": alg_bytes / (mean_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                        "share_of_step": sum_ms / (step_ms * n_steps),
-                        "traffic_bytes_per_launch": tb,
-                        "achieved_real_GBps": None if tb is None else tb / (mean_us * 1e-6) / 1e9,
-                        "timed": where})
-
-    spmv_name = "k_spmv<1, %d, 1, 1, double>" % (16 if args.workload.lower() in ("bl", "brain_like", "brain-like", "u", "unstructured") else 8)
-    if world == 1 and in_step:
-        kernel_entry(spmv_name, "y = A(c) x, SELL-64 with 16-bit column codes, fused w.u partials "
-                     "(algorithmic bytes: CSR with 4-byte columns, 12 nnz + 20 rows)", b_alg,
-                     st['ms_spmv_steps'], st['n_spmv_steps'], st['us_spmv_median'], "k_spmv<1", steps_n, ms_step,
-                     "HIP events inside the %d timed steps" % steps_n)
-    elif world == 1 and post_pass:
-        kernel_entry(spmv_name, "y = A(c) x, SELL-64 with 16-bit column codes, fused w.u partials "
-                     "(algorithmic bytes: CSR with 4-byte columns, 12 nnz + 20 rows)", b_alg,
-                     st_k['ms_spmv_steps'], st_k['n_spmv_steps'], st_k['us_spmv_median'], "k_spmv<1", st_k['_steps'],
-                     st_k['ms_steps'] / st_k['_steps'],
-                     "HIP events in a separate pass of %d steps right after the timed region" % st_k['_steps'])
-    if st_k is not None:
-        ks, kms = st_k['_steps'], st_k['ms_steps'] / st_k['_steps']
-        where = "HIP events in a separate pass of %d steps right after the timed region" % ks
-        kernel_entry("k_rd_assemble_s<4, CAP, RB, 1, double> (one launch per slice class)", "Jacobian + Newton residual(s) in one sweep over the "
-                     "(row, cell) incidences (algorithmic bytes: 12 per incidence + 20 per stored entry [S read, A write, "
-                     "4-byte column] + 32 per row)", 12 * st['n_corners'] + 20 * st['nnz_padded'] + 32 * st['n_rows'],
-                     st_k['ms_sweep_steps'], st_k['n_sweep_steps'], st_k['us_sweep_median'], "k_rd_assemble", ks, kms,
-                     where)
-        kernel_entry("k_rd_quad_s<4, CAP, RB, 1> (one launch per slice class)", "Newton residual after a solve from the quadratic structure: r - dt N(a) delta "
-                     "over the (row, cell) incidences, neither S nor A touched (algorithmic bytes: 8 per incidence [slot "
-                     "word + single-precision weight] + 4 per stored entry [column] + 24 per row [(a, delta) pair gathered "
-                     "once, r read + written])",
-                     8 * st['n_corners'] + 4 * st['nnz_padded'] + 24 * st['n_rows'],
-                     st_k['ms_quad_steps'], st_k['n_quad_steps'], st_k['us_quad_median'], "k_rd_quad", ks, kms, where)
-        kernel_entry("k_cg_update<1>", "PCG recurrence scalars + p, s, x, r, u update + next (r.u, r.r) partials "
-                     "(algorithmic bytes: 12 vector passes x 8 B per row)", 96 * st['n_rows'],
-                     st_k['ms_update_steps'], st_k['n_update_steps'], st_k['us_update_median'], "k_cg_update<1>", ks, kms,
-                     where)
+    kernels = kernel_list(st, st_k, steps_n, ms_step, st_k['_steps'] if st_k is not None else 1, unr, pmc) if world == 1 else []
+    dom_name = ("k_cheb<%d, %d, 1, double>" % (unr, st['stream_nontemporal'])) if cheb_dominant else \
+               ("k_spmv<%d, %d, %d, 1, double>" % (1 if in_step else 0, unr, st['stream_nontemporal']))
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": None if traffic is None else
                 "lookup, not measured in this run: %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same "
                 "operator, tools/pmc_summary.py)" % pmc_file,
-                "achieved_real": None if traffic is None else traffic / t_spmv / 1e9,
-                "frac_real": None if traffic is None else traffic / t_spmv / 1e9 / HBM_PEAK_GBS,
-                "kernel": ("k_spmv<1, 8, 1, 1, double>" if (in_step or post_pass) else "k_spmv<0, 8, 1, 1, double>") +
-                " (SELL-64, fp64 values, columns streamed as 16-bit window codes; algorithmic bytes still count 4-byte "
-                "CSR columns)",
-                "algorithmic_bytes_per_launch": b_alg, "avg_launch_us": t_spmv * 1e6,
-                "median_launch_us": st['us_spmv_median'] if in_step else st_k['us_spmv_median'] if post_pass else None,
-                "launches_timed": int(st['n_spmv_steps']) if in_step else int(st_k['n_spmv_steps']) if post_pass
-                else args.spmv_reps,
-                "timed": "inside the timed steps (k_spmv<1,..>, fused dot product)" if in_step
-                         else "inside the steps of a separate pass right after the timed region (k_spmv<1,..>)" if post_pass
+                "achieved_real": None if traffic is None else traffic / t_op / 1e9,
+                "frac_real": None if traffic is None else traffic / t_op / 1e9 / HBM_PEAK_GBS,
+                "kernel": dom_name + (" (one pass of the dot-free Krylov iteration: SELL-64 operator pass, fp64 values, 16-bit "
+                                      "column codes, Chebyshev recurrence in the epilogue; algorithmic bytes 12 nnz + 60 rows)"
+                                      if cheb_dominant else
+                                      " (SELL-64, fp64 values, columns streamed as 16-bit window codes; algorithmic bytes "
+                                      "still count 4-byte CSR columns: 12 nnz + 20 rows)"),
+                "algorithmic_bytes_per_launch": b_alg, "avg_launch_us": t_op * 1e6,
+                "median_launch_us": med_us, "launches_timed": n_timed,
+                "timed": "HIP events attached to the launches inside the timed steps" if in_step
                          else "back-to-back launches after the timed steps (k_spmv<0,..>)",
-                "isolated_launch_us": t_isolated * 1e6,
+                "isolated_spmv_launch_us": t_isolated * 1e6,
                 "kernels": kernels}
 
     # practical HBM ceiling of THIS device next to the nominal peak: streaming scale kernel y = 2 x over
@@ -643,7 +737,9 @@ def main():
     # solves) and C5 (coupled, 1 M nodes) under the same clock, each a few seconds; the headline handle is released first
     if world == 1 and not args.no_alt and args.workload.lower() == "c4" and not args.n:
         h.close()
-        for key, fn in (("unstructured", alt_unstructured), ("c2", alt_c2), ("c5_coupled", alt_c5)):
+        head_ns = 1e9 * elapsed / max(1, steps_done) / n_global if status == GLIMS_OK else None
+        for key, fn in (("rank_sized", lambda H, d: alt_rank_sized(H, d, head_ns)), ("unstructured", alt_unstructured),
+                        ("c2", alt_c2), ("c5_coupled", alt_c5)):
             try:
                 ta = time.perf_counter()
                 res = fn(Handle, local_rank)
@@ -665,7 +761,8 @@ def main():
                 "halo_bytes_per_step": st['halo_bytes'] / max(1, steps_done),
                 # HIP events on the communication stream (pack -> last receive) and around the compute stream's wait for it;
                 # 0 under the host-staged rehearsal transport (GLIMS_FORCE_DEVICE), whose callback is synchronous
-                "exchange_us_per_exchange": 1e3 * st['ms_exchange'] / max(1, st['halo_exchanges']),
+                "exchange_us_per_exchange": 1e3 * st['ms_exchange'] / max(1, st['halo_exchanges_timed']),
+                "halo_exchanges_timed": int(st['halo_exchanges_timed']),
                 "exchange_ms_per_step": st['ms_exchange'] / max(1, steps_done),
                 "exchange_exposed_ms_per_step": st['ms_exchange_exposed'] / max(1, steps_done),
                 "exchange_hidden_share": (1.0 - st['ms_exchange_exposed'] / st['ms_exchange']) if st['ms_exchange'] > 0 else None,
@@ -675,6 +772,10 @@ def main():
                 "device_ms_per_step": st['ms_steps'] / max(1, steps_done),
                 # the Krylov SpMV's launch over the INTERIOR slices (the part that hides the halo exchange), HIP events
                 "spmv_interior_us_in_step": (1e3 * st['ms_spmv_steps'] / st['n_spmv_steps']) if st['n_spmv_steps'] > 0 else None,
+                "cheb_interior_us_in_step": (1e3 * st['ms_cheb_steps'] / st['n_cheb_steps']) if st['n_cheb_steps'] > 0 else None,
+                "krylov_passes_per_step": st['cg_its'] / max(1, steps_done),
+                "chebyshev_passes_per_step": st['cheb_its'] / max(1, steps_done),
+                "chebyshev_fallbacks": int(st['cheb_fallbacks']),
                 "mg_complexity": st['mg_complexity'] if coupled else None,
                 "mg_first_grid_operator_bytes": int(st['mg_grid1_bytes']) if coupled else None,
                 "mech_ms_per_step": st['ms_mech'] / max(1, steps_done) if coupled else None}
@@ -706,28 +807,40 @@ def main():
                                                                                st['ms_mg_setup']))
                                                if st['mg_levels'] else "block-Jacobi") if coupled else None,
                        "mech_ms_per_step": st['ms_mech'] / max(1, steps_done) if coupled else None,
-                       "partition": "morton-node x%d" % world if world > 1 else "single GPU",
+                       "partition": "recursive coordinate bisection (equal work) x%d" % world if world > 1 else "single GPU",
                        "newton_its_per_step": st['newton_its'] / max(1, steps_done),
                        "cg_its_per_step": st['cg_its'] / max(1, steps_done),
+                       "chebyshev_passes_per_step": st['cheb_its'] / max(1, steps_done),
+                       "chebyshev_solves_per_step": st['cheb_solves'] / max(1, steps_done),
+                       "chebyshev_fallbacks": int(st['cheb_fallbacks']),
+                       "pcg_learning_solves": int(st['cheb_learn_solves']),
+                       "spectral_interval_lo": st['cheb_lmin'], "spectral_interval_hi": st['cheb_lmax'],
+                       "stream_policy": "non-temporal" if st['stream_nontemporal'] else "cached",
                        "assemblies_per_step": st['rd_assemblies'] / max(1, steps_done),
                        "quadratic_residual_updates_per_step": st['rd_quad_updates'] / max(1, steps_done),
                        "device_ms_per_step": st['ms_steps'] / max(1, steps_done),
                        "steps_completed": steps_done,
                        "solver_status": int(status),
-                       # the config's FULL length (test_case_comparison_3D_atlas.py:84: 500 steps) as measured on this path
-                       "full_run": ({"steps_requested": 500, "steps_completed": 482, "final_status": 1,
-                                     "cause": "consistent-mass P1 scheme without a discrete maximum principle: the front "
-                                              "(sqrt(D/rho) = 0.45 mm) is under-resolved on the 1.1 mm mesh, undershoots "
-                                              "grow through rho c (1 - c) until A(c) turns indefinite at step 483; the C "
-                                              "oracle breaks at the same step (tests/test_gpu_parity.py::test_long_run_"
-                                              "breakdown_...); handled as the reference does (warn, stop, return the last "
-                                              "solution, simulation_base.py:301-305)",
-                                     "ms_per_step_mean_over_the_run": 8.6,
-                                     "ms_per_step_range_over_the_run": [7.5, 12.3],
-                                     "source": "profiles/r04_c_long_c4_run.txt (20-step windows of the 482 steps)"}
-                                    if (args.workload.lower() == "c4" and not args.n and not coupled) else None)},
+                       },
             "roofline": roofline,
         }
+        # The config's FULL length (test_case_comparison_3D_atlas.py:84: 500 steps) as measured on this path by tools/run_long.py:
+        # scalar keys read from the committed summary, quoted only while the library's sources are the ones that run measured
+        if args.workload.lower() == "c4" and not args.n and not coupled:
+            try:
+                fr = json.load(open(os.path.join(HERE, "profiles", "long_c4_run.json")))
+                if fr.get("kernels_sha16") == kernels_sha16():
+                    out["config"].update({"full_run_steps_requested": fr["steps_requested"],
+                                          "full_run_steps_completed": fr["steps_completed"],
+                                          "full_run_status": fr["final_status"],
+                                          "full_run_ms_per_step_mean": fr["ms_per_step_mean"],
+                                          "full_run_ms_per_step_min_window": fr["ms_per_step_min_window"],
+                                          "full_run_ms_per_step_max_window": fr["ms_per_step_max_window"],
+                                          "full_run_source": "profiles/long_c4_run.json (tools/run_long.py, kernels %s)" % fr["kernels_sha16"]})
+                else:
+                    out["config"]["full_run_source"] = "profiles/long_c4_run.json is of other kernels (%s): not quoted" % fr.get("kernels_sha16")
+            except Exception as e:   # noqa: BLE001 -- informational only
+                log("[bench] full-run summary not quoted: %r" % (e,))
         if ranks_info is not None:
             out["ranks"] = ranks_info
         if alt is not None:

@@ -32,21 +32,22 @@ LIB = os.environ.get("GLIMSHIP_LIB", os.path.join(HERE, "..", "glimslib_amd", "l
 dp, i32p, i64p = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
 
 
-class Options(C.Structure):      # glims_options, include/glims_hip.h (ABI 4)
+class Options(C.Structure):      # glims_options, include/glims_hip.h (ABI 6)
     _fields_ = [("dt", C.c_double), ("newton_rtol", C.c_double), ("newton_atol", C.c_double),
                 ("newton_maxit", C.c_int), ("cg_rtol", C.c_double), ("cg_atol", C.c_double), ("cg_maxit", C.c_int),
                 ("mech_rtol", C.c_double), ("mech_atol", C.c_double), ("mech_maxit", C.c_int),
                 ("check_every", C.c_int), ("flags", C.c_int), ("mech_precond", C.c_int), ("mech_mixed", C.c_int),
                 ("mech_history", C.c_int), ("mg_smooth", C.c_int), ("mg_coarse_nodes", C.c_int),
                 ("mg_h_factor", C.c_double), ("mg_cheb_ratio", C.c_double), ("time_kernels", C.c_int),
-                ("rd_precond", C.c_int), ("rd_mg_smooth", C.c_int)]
+                ("rd_precond", C.c_int), ("rd_mg_smooth", C.c_int),
+                ("rd_linear", C.c_int), ("stream_policy", C.c_int)]
 
 
 def _load():
     lib = C.CDLL(LIB)
     h = C.c_void_p
     lib.glims_abi_version.restype = C.c_int
-    assert lib.glims_abi_version() == 5, "rebuild libglimship.so: this binding is written for ABI 5"
+    assert lib.glims_abi_version() == 6, "rebuild libglimship.so: this binding is written for ABI 6"
     lib.glims_create.argtypes = [C.POINTER(h), C.c_int, C.c_int64, C.c_int64, C.c_int64, dp, i32p, i32p, C.c_int]
     lib.glims_destroy.argtypes = [h]
     lib.glims_last_error.restype = C.c_char_p

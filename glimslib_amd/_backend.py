@@ -77,7 +77,8 @@ class Stats(C.Structure):
                 ("halo_exchanges_timed", C.c_int64), ("cheb_solves", C.c_int64), ("cheb_its", C.c_int64),
                 ("cheb_fallbacks", C.c_int64), ("cheb_learn_solves", C.c_int64), ("cheb_lmin", C.c_double),
                 ("cheb_lmax", C.c_double), ("ms_cheb_steps", C.c_double), ("n_cheb_steps", C.c_int64),
-                ("us_cheb_median", C.c_double), ("stream_nontemporal", C.c_int64), ("krylov_working_set", C.c_int64)]
+                ("us_cheb_median", C.c_double), ("stream_nontemporal", C.c_int64), ("krylov_working_set", C.c_int64),
+                ("mg_box_fraction", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -395,6 +395,7 @@ int glims_set_options(glims_ctx* h, const glims_options* opt) {
 int glims_set_dirichlet_c(glims_ctx* h, int64_t n, const int64_t* node_ids, const double* values) {
   return guarded(h, [&]() {
     h->pending = false;
+    h->dirichlet_c_exchange = h->world > 1;
     if (n <= 0) {
       if (h->have_fixed_c) h->mg_rd.ready = false;   // the RD hierarchy eliminates the constrained nodes
       h->have_fixed_c = false;
@@ -546,6 +547,7 @@ int glims_set_state(glims_ctx* h, const double* c, const double* u) {
     to_device_perm(h, c, h->c.p, 1);
     h->have_state = true;
     h->dirichlet_c_dirty = h->have_fixed_c;
+    h->dirichlet_c_exchange = h->world > 1;
     if (h->U.p) {
       if (u)
         to_device_perm(h, u, h->U.p, h->dim);
@@ -604,6 +606,7 @@ int glims_reset_stats(glims_ctx* h) {
   h->stats.ms_rd_mg_setup = keep.ms_rd_mg_setup;
   h->stats.reduce_transport = keep.reduce_transport;
   h->stats.mg_grid1_bytes = keep.mg_grid1_bytes;
+  h->stats.mg_box_fraction = keep.mg_box_fraction;
   h->stats.cheb_lmin = keep.cheb_lmin;
   h->stats.cheb_lmax = keep.cheb_lmax;
   h->stats.stream_nontemporal = keep.stream_nontemporal;

@@ -445,6 +445,7 @@ struct glims_ctx {
   dvec<uint8_t> label;                     // per cell, INTERNAL cell order (= celem's indices)
   dvec<int32_t> cell_new2old;              // internal cell index -> caller's (device-side symbolic phase: cells sorted by first owner; empty = identity)
   dvec<double> egeo;                       // per cell: |T|, grad(lambda_a) [nv][dim]
+  dvec<double> evol;                       // per cell: |T| once more, compact (the per-incidence weights read 8 B, not a 104-B record)
   dvec<double> mat;                        // [5][GL_MAX_LABELS]: D, rho, gamma, mu, lambda
   bool have_materials = false, is_setup = false, have_mech = false, have_state = false;
 
@@ -509,6 +510,15 @@ struct glims_ctx {
     double acc_lmin = 0.0, acc_lmax = 0.0; // ... being accumulated by the current learning step
     int learned = 0;                       // PCG solves that contributed to acc_*
     int age = 0;                           // steps since the interval was measured
+    int m_hint = 0;                        // passes the device chose for the last warm-started solve (bounds the next one's launches)
+    // Which iteration a solve AFTER a step's first one uses (the first, loose one always takes the dot-free iteration): PCG
+    // needs fewer operator passes for a tight solve (superlinear convergence: 8 iterations where the Chebyshev bound asks for
+    // 13-15 at config C4), the dot-free iteration cheaper ones.  cost_ratio = cost of a Chebyshev pass / cost of a PCG
+    // iteration from a byte model of the two (solver.hip, cheb_cost_ratio: 0.74 at 10 M rows, 0.66 at 1.26 M -- measured 0.74 /
+    // 0.6), pcg_its_per_decade from the tightest PCG solve of the last learning step.  Deterministic (no timings): the
+    // iteration path of a run stays reproducible bit for bit.  0 = unknown (then: Chebyshev).
+    double cost_ratio = 0.0, pcg_its_per_decade = 0.0;
+    int pcg_best_its = 0;                  // iterations of the solve pcg_its_per_decade comes from
   } cheb;
   double cheb_test_hi = 1.0;               // TEST HOOK GLIMS_CHEB_TEST_SCALE_HI (read by glims_create): factor on the measured upper end
   dvec<double> cg_hist;                    // [2 * GL_CG_HIST] (alpha_k, beta_k) of the running PCG solve
@@ -554,6 +564,10 @@ struct glims_ctx {
   MeshMetrics mm;
   dvec<double> fixed_c_val;                 // Dirichlet values of the concentration [n_nodes] (internal numbering)
   bool dirichlet_c_dirty = false;           // values not yet written into the iterate (done by the next step)
+  // partitioned runs: SOME rank may have new Dirichlet values on nodes this rank holds as ghosts -- set by every
+  // glims_set_dirichlet_c / glims_set_state (collective calls: every rank makes them, with n = 0 where it owns no constrained
+  // node), so that the next step's halo exchange of the iterate happens on all ranks or on none
+  bool dirichlet_c_exchange = false;
   std::vector<dvec<double>*> snapshots;     // device-resident recorded concentrations (owned)
   dvec<double> stage;                      // staging for host<->device permuted transfers [n_nodes*dim]
 

@@ -40,7 +40,8 @@ __device__ __forceinline__ void spmv_dot_partial(double pd, int b, double* __res
 // ---------------------------------------------------------------------------------------------------
 template <int D>
 __global__ void k_egeo(int64_t n_cells, const double* __restrict__ xyz, const int32_t* __restrict__ cells,
-                       double* __restrict__ egeo, unsigned long long* __restrict__ bad /*[2]: count, first (caller's) index*/,
+                       double* __restrict__ egeo, double* __restrict__ evol,
+                       unsigned long long* __restrict__ bad /*[2]: count, first (caller's) index*/,
                        const int32_t* __restrict__ cell_new2old /*internal -> caller's cell index, or null*/) {
   constexpr int NV = D + 1, GE = 1 + NV * D;
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -89,6 +90,7 @@ __global__ void k_egeo(int64_t n_cells, const double* __restrict__ xyz, const in
       g[1 + 3 * 3 + a] = g3;
     }
   }
+  evol[e] = g[0];   // the volumes once more, compact: what the per-incidence reaction weights read (k_corner_weights)
   if (!(g[0] > 0.0) || !isfinite(1.0 / g[0])) {   // degenerate (zero-volume) or non-finite cell
     atomicAdd(bad, 1ull);
     atomicMin(bad + 1, (unsigned long long)(cell_new2old ? cell_new2old[e] : e));
@@ -104,11 +106,11 @@ template <int D>
 __global__ __launch_bounds__(GL_WAVE) void k_corner_weights(const int64_t* __restrict__ cslice_ptr,
                                                              const int32_t* __restrict__ celem,
                                                              const uint8_t* __restrict__ label,
-                                                             const double* __restrict__ egeo, const double* __restrict__ mat,
+                                                             const double* __restrict__ evol, const double* __restrict__ mat,
                                                              const uint8_t* __restrict__ diag_k,
                                                              const uint32_t* __restrict__ cslots, double* __restrict__ cw,
                                                              uint32_t* __restrict__ cs2, uint2* __restrict__ cq) {
-  constexpr int NV = D + 1, GE = 1 + NV * D;
+  constexpr int NV = D + 1;
   constexpr double fact = D == 2 ? 1.0 / 60.0 : 1.0 / 120.0;
   const int s = blockIdx.x, lane = threadIdx.x;
   const int64_t cbase = cslice_ptr[s];
@@ -117,7 +119,9 @@ __global__ __launch_bounds__(GL_WAVE) void k_corner_weights(const int64_t* __res
   for (int q = 0; q < clen; ++q) {
     const int64_t i = cbase + (int64_t)q * GL_WAVE + lane;
     const int32_t e = celem[i];
-    const double w = e < 0 ? 0.0 : mat[1 * GL_MAX_LABELS + label[e]] * egeo[(int64_t)e * GE] * fact;
+    // (|T| from the compact array: through the 104-byte geometry records this kernel fetched a whole line per incidence,
+    //  41.8 GB at 10 M rows -- profiles/r04_a_pmc_c4.json)
+    const double w = e < 0 ? 0.0 : mat[1 * GL_MAX_LABELS + label[e]] * evol[e] * fact;
     const uint32_t sl = cslots[i];
     uint32_t out = dk, pos = 1;
     if (e < 0) {
@@ -162,7 +166,8 @@ __global__ __launch_bounds__(GL_WAVE) void k_assemble_static(
     const uint8_t* __restrict__ label, const double* __restrict__ mat, double dt, const PlaneOut po, int max_len) {
   constexpr int NV = D + 1, GE = 1 + NV * D;
   constexpr double mfac = 1.0 / ((D + 1) * (D + 2));
-  extern __shared__ double acc[];   // [NP][max_len][64]
+  extern __shared__ double acc[];   // [NP][max_len][64], then the 64 geometry records of the current round [GE][64]
+  double* rec = acc + (size_t)NP * max_len * GL_WAVE;
   const int s = blockIdx.x, lane = threadIdx.x;
   const int64_t row = (int64_t)s * GL_WAVE + lane;
   const int64_t base = slice_ptr[s], cbase = cslice_ptr[s];
@@ -174,9 +179,23 @@ __global__ __launch_bounds__(GL_WAVE) void k_assemble_static(
   for (int q = 0; q < clen; ++q) {
     const int64_t ci = cbase + (int64_t)q * GL_WAVE + lane;
     const int32_t e = celem[ci];
+    // The 64 geometry records of this round, fetched by the WAVE: lane l of pass t reads double (t * 64 + l) of the 64 x GE
+    // block, i.e. consecutive lanes read consecutive doubles of a record (5-6 lines per load instruction instead of 64, each
+    // record's line requested once instead of 13 times by a lane that has long lost it from L1: 47.7 GB of fabric reads per
+    // launch at 10 M rows, profiles/r04_a_pmc_c4.json), staged in LDS record-component-major.
+    __syncthreads();   // (one wave per block: orders the previous round's reads before these writes)
+#pragma unroll
+    for (int t = 0; t < GE; ++t) {
+      const int f = t * GL_WAVE + lane, r = f / GE, j = f - r * GE;
+      const int32_t er = __shfl(e, r, GL_WAVE);
+      rec[j * GL_WAVE + r] = er < 0 ? 0.0 : egeo[(int64_t)er * GE + j];
+    }
+    __syncthreads();
     if (e < 0) continue;
     const uint32_t slots = cslots[ci];
-    const double* g = egeo + (int64_t)e * GE;
+    double g[GE];
+#pragma unroll
+    for (int j = 0; j < GE; ++j) g[j] = rec[j * GL_WAVE + lane];
     const double vol = g[0];
     const int lab = label[e];
     int li = 0;
@@ -185,7 +204,7 @@ __global__ __launch_bounds__(GL_WAVE) void k_assemble_static(
       if ((int)((slots >> (8 * m)) & 255u) == dk) li = m;
     double gi[D];
 #pragma unroll
-    for (int a = 0; a < D; ++a) gi[a] = g[1 + li * D + a];
+    for (int a = 0; a < D; ++a) gi[a] = rec[(1 + li * D + a) * GL_WAVE + lane];   // (li is a run-time index: from LDS, not from the register copy)
     const double Dc = mat[0 * GL_MAX_LABELS + lab], rho = mat[1 * GL_MAX_LABELS + lab],
                  gam = mat[2 * GL_MAX_LABELS + lab], mu = mat[3 * GL_MAX_LABELS + lab],
                  lam = mat[4 * GL_MAX_LABELS + lab];
@@ -1320,15 +1339,16 @@ static void set_lds(K kern, size_t bytes) {
 void gl_compute_egeo(glims_ctx* h, const double* d_xyz, const int32_t* d_cells) {
   const int GE = 1 + h->nv * h->dim;
   h->egeo.alloc((size_t)h->n_cells * GE);
+  h->evol.alloc((size_t)h->n_cells);
   dvec<unsigned long long> bad;
   const unsigned long long init[2] = {0ull, ~0ull};
   bad.upload(init, 2, h->st);
   const int bs = 256;
   const unsigned grid = (unsigned)((h->n_cells + bs - 1) / bs);
   if (h->dim == 2)
-    hipLaunchKernelGGL(k_egeo<2>, dim3(grid), dim3(bs), 0, h->st, h->n_cells, d_xyz, d_cells, h->egeo.p, bad.p, h->cell_new2old.p);
+    hipLaunchKernelGGL(k_egeo<2>, dim3(grid), dim3(bs), 0, h->st, h->n_cells, d_xyz, d_cells, h->egeo.p, h->evol.p, bad.p, h->cell_new2old.p);
   else
-    hipLaunchKernelGGL(k_egeo<3>, dim3(grid), dim3(bs), 0, h->st, h->n_cells, d_xyz, d_cells, h->egeo.p, bad.p, h->cell_new2old.p);
+    hipLaunchKernelGGL(k_egeo<3>, dim3(grid), dim3(bs), 0, h->st, h->n_cells, d_xyz, d_cells, h->egeo.p, h->evol.p, bad.p, h->cell_new2old.p);
   GL_HIP(hipGetLastError());
   unsigned long long res[2];
   GL_HIP(hipMemcpyAsync(res, bad.p, sizeof(res), hipMemcpyDeviceToHost, h->st));
@@ -1364,7 +1384,7 @@ __global__ void k_to_float(int64_t n, const double* __restrict__ a, float* __res
 template <int D, int NP>
 static void assemble_planes(glims_ctx* h, int mode, int ca, const PlaneOut& po) {
   const DevPattern& p = h->pat;
-  const size_t lds = (size_t)NP * p.max_len * GL_WAVE * sizeof(double);
+  const size_t lds = ((size_t)NP * p.max_len + (1 + (D + 1) * D)) * GL_WAVE * sizeof(double);
   set_lds(k_assemble_static<D, NP>, lds);
   hipLaunchKernelGGL((k_assemble_static<D, NP>), dim3(p.n_slices), dim3(GL_WAVE), lds, h->st, mode, ca, h->n_own,
                      p.slice_ptr.p, p.cslice_ptr.p, p.cslots.p, p.celem.p, p.diag_k.p, h->egeo.p, h->label.p,
@@ -1391,7 +1411,7 @@ static void assemble_static_t(glims_ctx* h, int with_mechanics) {
   p.cs2.alloc((size_t)p.total_corners);
   p.cq.alloc((size_t)2 * p.total_corners);
   hipLaunchKernelGGL(k_corner_weights<D>, dim3(p.n_slices), dim3(GL_WAVE), 0, h->st, p.cslice_ptr.p, p.celem.p, h->label.p,
-                     h->egeo.p, h->mat.p, p.diag_k.p, p.cslots.p, p.cw.p, p.cs2.p, (uint2*)p.cq.p);
+                     h->evol.p, h->mat.p, p.diag_k.p, p.cslots.p, p.cw.p, p.cs2.p, (uint2*)p.cq.p);
   GL_HIP(hipGetLastError());
   if (with_mechanics) {
     h->vKel.alloc(ne * D * D);

@@ -833,6 +833,7 @@ void gl_mg_setup_mech(glims_ctx* h) {
     const MgLevel& L = *mg.lv[0];
     h->stats.mg_grid1_bytes = (int64_t)(L.half ? L.A16.n * sizeof(uint16_t) : L.A.n * sizeof(float));
   }
+  h->stats.mg_box_fraction = mg.box_fraction;
 }
 
 // RD block: the hierarchy is built ONCE per glims_setup on the static part S = (1 - dt rho) M + dt K_D of the Newton
@@ -1232,6 +1233,23 @@ static void cheb_learn(glims_ctx* h, int64_t its) {
   h->stats.cheb_learn_solves++;
 }
 
+// Cost of one Chebyshev pass relative to one PCG iteration (operator pass + reduction + vector update): algorithmic bytes of
+// the two plus a per-launch overhead worth B0 bytes at the streaming rate (launch gap + write-back of the predecessor's dirty
+// lines: ~5-8 us), from the rows and entries of the average rank -- the same number on every rank.
+static double cheb_cost_ratio(glims_ctx* h) {
+  double v[2] = {(double)h->n_own, (double)h->nnz};
+  if (h->world > 1) {   // one collective per glims_setup (end of the first learning step)
+    GL_HIP(hipMemcpyAsync(h->partials.p, v, sizeof(v), hipMemcpyHostToDevice, h->st));
+    reduce_partials(h, 1, 2, nullptr);
+    allreduce_sum(h, h->red.p, 2);
+    read_red(h, 2, v);
+    v[0] /= h->world;
+    v[1] /= h->world;
+  }
+  const double B0 = 40e6;
+  return (12.0 * v[1] + 60.0 * v[0] + B0) / (12.0 * v[1] + 136.0 * v[0] + 3.0 * B0);
+}
+
 // Safety factors on the measured interval.  A lower end set too low only costs iterations (prototype: 0.5 x -> +50 %); an upper
 // end set too low makes the iteration diverge on what lies above it, so the Ritz value -- an estimate from inside -- gets more room.
 static const double GL_CHEB_LO = 0.85, GL_CHEB_HI = 1.08;
@@ -1266,7 +1284,13 @@ static ChebRun cheb_solve(glims_ctx* h, const CgVecs& v, double tol_abs, double 
   run.planned = !(r_norm > 0.0);
   const int m_min = want_res ? 1 : 2;
   int m = 0;
-  if (run.planned) m = std::min(GL_CHEB_MAX, std::max(m_min, rec.iterations(tol_abs / std::max(r_bound, tol_abs)) + 3));
+  if (run.planned) {
+    // upper bound of the launches: from the residual before the warm start -- or, once known, what the device chose last time
+    // + 2 (like the PCG solves' hints: the launches beyond the device's count return at once, but each still costs a dispatch
+    // and, in a partitioned run, a halo exchange); a count clipped by the bound is a slightly weaker Newton step
+    m = std::min(GL_CHEB_MAX, std::max(m_min, rec.iterations(tol_abs / std::max(r_bound, tol_abs)) + 3));
+    if (h->cheb.m_hint > 0) m = std::max(m_min, std::min(m, h->cheb.m_hint + 2));
+  }
   else if (r_norm > tol_abs) m = std::min(GL_CHEB_MAX, std::max(m_min, rec.iterations(tol_abs / r_norm)));
   const unsigned g = grid_for(n);
   double* info_dev = h->scal.p + 2 * SC_COUNT;
@@ -1502,6 +1526,8 @@ int gl_step(glims_ctx* h, int n_steps) {
     const bool cheb_learning = cheb_allowed && !cb.valid;
     if (cheb_learning) {
       cb.learned = 0;
+      cb.pcg_best_its = 0;
+      cb.m_hint = 0;
       h->cg_hist.alloc((size_t)2 * GL_CG_HIST);
     }
     if (h->pending) {
@@ -1514,9 +1540,16 @@ int gl_step(glims_ctx* h, int n_steps) {
                      nullptr);
       // new Dirichlet data enter the ITERATE, after the old state went into b = M c^n: the reference's u_previous
       // keeps the previous step's boundary values while the DirichletBC constrains the unknown
-      if (h->dirichlet_c_dirty) {
-        gl_apply_dirichlet_c(h);
-        gl_halo_exchange(h, h->c.p, 1);   // a rank lists its OWN constrained nodes; their ghost copies follow
+      // (a rank lists its OWN constrained nodes; their ghost copies on the neighbours follow by a halo exchange that every
+      //  rank takes part in -- also the ranks that own no constrained node: dirichlet_c_exchange)
+      if (h->dirichlet_c_dirty) gl_apply_dirichlet_c(h);
+      if (h->dirichlet_c_exchange) {
+        gl_halo_exchange(h, h->c.p, 1);
+        h->dirichlet_c_exchange = false;
+        // new boundary values are a jump in the iterate: no warm start from the previous increments -- on EVERY rank (the
+        // rank that wrote the values has dropped its own in gl_apply_dirichlet_c; a rank that kept it would run a differently
+        // shaped first solve -- the warm-started dot-free solve reduces |r| first -- and the ranks' collectives would no longer pair up)
+        h->have_c_old = false;
       }
       if (extrapolate) {
         hipLaunchKernelGGL(k_extrapolate, dim3(grid_exact(n)), dim3(256), 0, h->st, n, h->c.p, h->c_old.p,
@@ -1621,7 +1654,16 @@ int gl_step(glims_ctx* h, int n_steps) {
         GL_HIP(hipMemcpyAsync(ck_is_c0 ? h->nq_c0.p : h->nq_ck.p, h->c.p, (size_t)h->n_nodes * sizeof(double),
                               hipMemcpyDeviceToDevice, h->st));
       }
-      const bool use_cheb = cheb_allowed && cb.valid;
+      bool use_cheb = cheb_allowed && cb.valid;
+      if (use_cheb && it >= 1 && o.rd_linear == GLIMS_RD_LINEAR_AUTO && cb.cost_ratio > 0.0 && cb.pcg_its_per_decade > 0.0 &&
+          tol_lin < nr) {
+        // a tight solve: PCG's iterations (from its rate in the last learning step) against the passes the Chebyshev bound
+        // asks for, weighted by what each costs
+        ChebRec rec(GL_CHEB_LO * cb.lmin, GL_CHEB_HI * cb.lmax * h->cheb_test_hi);
+        const int passes = rec.iterations(tol_lin / nr) - (cheap_next ? 0 : 1);
+        const double its_pcg = std::ceil(cb.pcg_its_per_decade * std::log10(nr / tol_lin)) + 1.0;
+        if (its_pcg < 0.95 * cb.cost_ratio * passes) use_cheb = false;
+      }
       bool warm = false, ws_fused = false;
       if (it == 0 && (o.flags & GLIMS_FLAG_WARM_START) && !extrapolate) {   // both options own the c_old buffer
         // initial guess of the first linear solve = the increment predicted from the previous steps' (k_ws_delta): same linear
@@ -1690,7 +1732,14 @@ int gl_step(glims_ctx* h, int n_steps) {
           h->cg_hint[slot] = (int)its;
           h->stats.cg_its += its;
           h->stats.last_cg_res = res;
-          if (cheb_learning && cs == GLIMS_OK) cheb_learn(h, its);
+          if (cheb_learning && cs == GLIMS_OK) {
+            cheb_learn(h, its);
+            // PCG's iterations per decade in the tightest solve whose initial residual the host knows (not a warm-started one)
+            if (!warm && its > cb.pcg_best_its && res > 0.0 && res < nr) {
+              cb.pcg_best_its = (int)its;
+              cb.pcg_its_per_decade = (double)its / std::log10(nr / res);
+            }
+          }
         }
       }
       h->stats.newton_its++;
@@ -1712,6 +1761,7 @@ int gl_step(glims_ctx* h, int n_steps) {
       }
       if (deferred && use_cheb) {   // the count the device chose for the warm-started solve
         const int64_t m_dev = (int64_t)km.info[0];
+        cb.m_hint = (int)std::max<int64_t>(1, m_dev);
         const int64_t passes = std::max<int64_t>(0, std::min<int64_t>(crun.passes, cheap ? m_dev : m_dev - 1));
         h->stats.cg_its += passes;
         h->stats.cheb_its += passes;
@@ -1788,6 +1838,12 @@ int gl_step(glims_ctx* h, int n_steps) {
     }
     ++h->nw_steps;
     if (cheb_learning && status == GLIMS_OK && cb.learned > 0) {
+      if (cb.cost_ratio == 0.0) cb.cost_ratio = cheb_cost_ratio(h);
+      // (the interval forgets slowly: an upper end that one step's right-hand sides did not excite is not dropped at once)
+      if (cb.lmax > 0.0) {
+        cb.acc_lmax = std::max(cb.acc_lmax, 0.5 * (cb.acc_lmax + cb.lmax));
+        cb.acc_lmin = std::min(cb.acc_lmin, 0.5 * (cb.acc_lmin + cb.lmin));
+      }
       cb.lmin = cb.acc_lmin;
       cb.lmax = cb.acc_lmax;
       cb.valid = true;

@@ -279,14 +279,23 @@ __global__ __launch_bounds__(256) void k_slice_lengths(int32_t n_slices, int64_t
   }
 }
 
+// out[i] = map[in[i]]
+__global__ void k_translate_ids(int64_t n, const int32_t* __restrict__ in, const int32_t* __restrict__ map,
+                                int32_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = map[in[i]];
+}
+
 // a thread per row of the final numbering (padding rows of the last slice included): columns, diagonal slot, incidences
+// (the cells' vertex ids arrive translated to the final numbering -- ONE gather through old2new per vertex of a cell instead of
+//  two per (row, cell, vertex): the per-incidence gathers through the caller's numbering were most of this kernel's 118 GB of
+//  fabric reads at 10 M rows, profiles/r04_a_pmc_c4.json)
 __global__ __launch_bounds__(GL_WAVE) void k_fill_pattern(int64_t n_own, int nv, const int64_t* __restrict__ slice_ptr,
                                                            const int64_t* __restrict__ cslice_ptr,
                                                            const int32_t* __restrict__ row_m,
                                                            const int64_t* __restrict__ adj_ptr,
                                                            const int32_t* __restrict__ adj,
-                                                           const int32_t* __restrict__ cells,
-                                                           const int32_t* __restrict__ old2new,
+                                                           const int32_t* __restrict__ cells /*vertex ids in the FINAL numbering*/,
                                                            int32_t* __restrict__ cols, uint8_t* __restrict__ diag_k,
                                                            uint8_t* __restrict__ rlen,
                                                            uint32_t* __restrict__ cslots, int32_t* __restrict__ celem,
@@ -313,7 +322,7 @@ __global__ __launch_bounds__(GL_WAVE) void k_fill_pattern(int64_t n_own, int nv,
     const int64_t q0 = adj_ptr[i], q1 = adj_ptr[i + 1];
     for (int64_t q = q0; q < q1; ++q) {
       const int32_t* cv = cells + (int64_t)adj[q] * nv;
-      for (int m = 0; m < nv; ++m) n = a.insert(n, old2new[cv[m]]);
+      for (int m = 0; m < nv; ++m) n = a.insert(n, cv[m]);
     }
     for (int k = 0; k < n; ++k) {
       const int32_t ak = a.get(k);
@@ -328,7 +337,7 @@ __global__ __launch_bounds__(GL_WAVE) void k_fill_pattern(int64_t n_own, int nv,
       const int32_t e = adj[p];
       uint32_t packed = 0;
       for (int m = 0; m < nv; ++m) {
-        const int32_t vn = old2new[cells[(int64_t)e * nv + m]];
+        const int32_t vn = cells[(int64_t)e * nv + m];
         packed |= (uint32_t)a.lower_bound(n, vn) << (8 * m);
       }
       celem[cbase + (int64_t)q * GL_WAVE + l] = e;
@@ -699,9 +708,16 @@ void gl_build_pattern_device(glims_ctx* h, const double* d_xyz, const int32_t* d
   p.celem.alloc((size_t)p.total_corners);
   dvec<uint8_t> is_boundary;
   is_boundary.alloc((size_t)n_slices);
-  hipLaunchKernelGGL(k_fill_pattern, dim3(n_slices), dim3(GL_WAVE), 0, st, n_own, nv, p.slice_ptr.p, p.cslice_ptr.p, row_m.p,
-                     adj_ptr.p, adj.p, cells_p.p, h->d_old2new.p, p.cols.p, p.diag_k.p, p.rlen.p, p.cslots.p, p.celem.p, is_boundary.p);
-  GL_HIP(hipGetLastError());
+  {
+    dvec<int32_t> cells_n;   // the cells (internal order) with vertex ids in the final numbering
+    cells_n.alloc((size_t)n_cells * nv);
+    hipLaunchKernelGGL(k_translate_ids, dim3(gridn(n_cells * nv)), dim3(256), 0, st, n_cells * nv, cells_p.p,
+                       h->d_old2new.p, cells_n.p);
+    hipLaunchKernelGGL(k_fill_pattern, dim3(n_slices), dim3(GL_WAVE), 0, st, n_own, nv, p.slice_ptr.p, p.cslice_ptr.p, row_m.p,
+                       adj_ptr.p, adj.p, cells_n.p, p.cols.p, p.diag_k.p, p.rlen.p, p.cslots.p, p.celem.p, is_boundary.p);
+    GL_HIP(hipGetLastError());
+    GL_HIP(hipStreamSynchronize(st));   // cells_n is released here
+  }
   lap("slice offsets, columns + incidences");
 
   // ---- 5. 16-bit column codes ---------------------------------------------------------------------------------------

@@ -117,6 +117,17 @@ class HostStagedTransport:
         self.hip = hip
         self.halo_cb = _backend.HALO_FN(self._halo)
         self.allreduce_cb = _backend.ALLREDUCE_FN(self._allreduce)
+        # GLIMS_TRANSPORT_TRACE=<prefix>: every collective this rank enters, one line each, in <prefix><rank>.txt -- ranks whose
+        # call sequences differ show where a partitioned run went out of step
+        pre = os.environ.get("GLIMS_TRANSPORT_TRACE")
+        self._trace = open("%s%d.txt" % (pre, dist.get_rank()), "w") if pre else None
+        self._n = 0
+
+    def _note(self, what):
+        if self._trace:
+            self._n += 1
+            self._trace.write("%d %s\n" % (self._n, what))
+            self._trace.flush()
 
     def _d2h(self, ptr, n):
         a = np.empty(n)
@@ -131,6 +142,7 @@ class HostStagedTransport:
 
     def _halo(self, user, sendbuf, send_ptr, ghosts, recv_ptr, n_peers, peers, bs, stream):
         try:
+            self._note("halo bs=%d peers=%s" % (bs, [int(peers[p]) for p in range(n_peers)]))
             self.hip.hipStreamSynchronize(stream)
             reqs, rbufs = [], []
             for p in range(n_peers):
@@ -154,6 +166,7 @@ class HostStagedTransport:
 
     def _allreduce(self, user, values, n, stream):
         try:
+            self._note("allreduce n=%d" % n)
             self.hip.hipStreamSynchronize(stream)
             t = self.torch.from_numpy(self._d2h(values, n))
             self.dist.all_reduce(t, group=self.group)
@@ -162,6 +175,106 @@ class HostStagedTransport:
         except Exception as e:   # noqa: BLE001
             print("glimslib_amd: allreduce transport failed: %r" % (e,), flush=True)
             return 1
+
+
+class ThreadGroup:
+    """Meeting point of ThreadedTransport's ranks (one process, one thread per rank)."""
+
+    def __init__(self, world):
+        import queue
+        import threading
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.pipes = {(a, b): queue.Queue() for a in range(world) for b in range(world) if a != b}
+        self.values = [None] * world
+
+
+class ThreadedTransport:
+    """glims_halo_fn / glims_allreduce_fn for ranks that are THREADS of one process sharing one GPU -- a rehearsal transport:
+    the GPU boxes allow a handful of processes on a card, so rank counts like 8 cannot be rehearsed with one process per rank
+    (tests/test_gpu_multirank.py, tools/rehearse_partition.py).  Everything else is the product path: each rank its own handle
+    and streams, its own sub-mesh, the library's halo packing, slice split and reduction points.  Messages travel through
+    FIFO queues per ordered rank pair (both sides derive the same sequence of exchanges), all-reduces through a barrier and
+    a sum in rank order."""
+
+    def __init__(self, group, rank):
+        self.g, self.rank = group, rank
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+        self.hip = hip
+        self.halo_cb = _backend.HALO_FN(self._halo)
+        self.allreduce_cb = _backend.ALLREDUCE_FN(self._allreduce)
+        self.failed = None
+
+    def _d2h(self, ptr, n):
+        a = np.empty(n)
+        if self.hip.hipMemcpy(a.ctypes.data, ptr, n * 8, 2) != 0:
+            raise RuntimeError("hipMemcpy D2H failed")
+        return a
+
+    def _h2d(self, ptr, a):
+        if self.hip.hipMemcpy(ptr, a.ctypes.data, a.size * 8, 1) != 0:
+            raise RuntimeError("hipMemcpy H2D failed")
+
+    def _halo(self, user, sendbuf, send_ptr, ghosts, recv_ptr, n_peers, peers, bs, stream):
+        try:
+            self.hip.hipStreamSynchronize(stream)
+            for p in range(n_peers):
+                lo, hi = send_ptr[p] * bs, send_ptr[p + 1] * bs
+                if hi > lo:
+                    self.g.pipes[(self.rank, int(peers[p]))].put(self._d2h(sendbuf + lo * 8, hi - lo))
+            for p in range(n_peers):
+                nr = int((recv_ptr[p + 1] - recv_ptr[p]) * bs)
+                if nr > 0:
+                    a = self.g.pipes[(int(peers[p]), self.rank)].get(timeout=120)
+                    assert a.size == nr, (a.size, nr)
+                    self._h2d(ghosts + recv_ptr[p] * bs * 8, a)
+            return 0
+        except Exception as e:   # noqa: BLE001 -- must not unwind through the C frame
+            self.failed = e
+            print("glimslib_amd: threaded halo transport failed on rank %d: %r" % (self.rank, e), flush=True)
+            return 1
+
+    def _allreduce(self, user, values, n, stream):
+        try:
+            self.hip.hipStreamSynchronize(stream)
+            self.g.values[self.rank] = self._d2h(values, n)
+            self.g.barrier.wait(timeout=120)
+            t = np.zeros(n)
+            for r in range(self.g.world):       # rank order: the same bits on every rank
+                t += self.g.values[r]
+            self.g.barrier.wait(timeout=120)    # nobody overwrites its slot before everybody has read it
+            self._h2d(values, t)
+            return 0
+        except Exception as e:   # noqa: BLE001
+            self.failed = e
+            print("glimslib_amd: threaded allreduce transport failed on rank %d: %r" % (self.rank, e), flush=True)
+            return 1
+
+
+def run_threaded_ranks(world, fn):
+    """Runs fn(rank, ThreadedTransport) on `world` threads and returns their results in rank order (exceptions re-raised)."""
+    import threading
+    group = ThreadGroup(world)
+    res, err = [None] * world, [None] * world
+
+    def body(r):
+        try:
+            res[r] = fn(r, ThreadedTransport(group, r))
+        except BaseException as e:   # noqa: BLE001
+            err[r] = e
+            group.barrier.abort()
+
+    ts = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for e in err:
+        if e is not None:
+            raise e
+    return res
 
 
 class DistributedHandle:

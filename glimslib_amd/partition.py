@@ -4,8 +4,9 @@ Node-based mesh partition for the single-node multi-GPU path (one process per GP
 The reference's only parallel mode is DOLFIN's MPI domain decomposition (README.md:142-183; glimslib contributes
 nothing but ``mesh.mpi_comm()`` handles).  This module produces the same kind of decomposition as plain arrays:
 
-  * nodes are ordered along a Morton curve and cut into ``n_parts`` contiguous ranges of equal work (cumulative
-    cells-per-node, i.e. equal nnz / equal (row, cell) incidences; owner map);
+  * nodes are cut into ``n_parts`` axis-aligned boxes of equal work by recursive coordinate bisection (cumulative
+    cells-per-node, i.e. equal nnz / equal (row, cell) incidences; owner map) -- or, method='morton', into contiguous
+    ranges of the Morton order;
   * rank r keeps every cell that touches one of its nodes; the cells' foreign vertices are its ghosts;
   * local numbering = [owned (ascending global id) | ghosts grouped by owner rank, ascending global id];
   * the send list to peer p is "my owned nodes that share a cell with a node owned by p", ascending global id --
@@ -71,9 +72,42 @@ def box_node_weights(nx, ny, nz):
     return w.ravel() + 1.0
 
 
-def node_owners(points, n_parts, cells=None, weights=None):
+def rcb_owners(points, n_parts, weights):
     """
-    owner[node] in [0, n_parts): contiguous ranges of the Morton order.  With ``cells`` the ranges carry equal WORK
+    Recursive coordinate bisection: the node set is cut by a plane normal to the longest axis of its
+    bounding box into two sets whose WORK is in the ratio of the ranks they will hold (floor / ceil halves of the rank count, so
+    any count works), recursively.  Every part is the set of nodes inside an axis-aligned box -- by construction, on any mesh
+    and for any rank count; contiguous Morton ranges are boxes only on uniform lattices with power-of-two counts.  That is what
+    the partitioned elasticity multigrid wants (a rank's core on the first auxiliary grid is then a compact box:
+    MgHierarchy::box_fraction) and it keeps halos near the surface minimum.  Ties (lattice nodes on the cutting plane) go by
+    global id, so the result is deterministic.  DOLFIN's counterpart: ParMETIS / SCOTCH under mpirun (README.md:142-158).
+    """
+    points = np.asarray(points, dtype=np.float64)
+    n = len(points)
+    owner = np.zeros(n, dtype=np.int32)
+    w = np.asarray(weights, dtype=np.float64)
+    stack = [(np.arange(n, dtype=np.int64), 0, n_parts)]
+    while stack:
+        idx, first, k = stack.pop()
+        if k == 1:
+            owner[idx] = first
+            continue
+        kl = k // 2
+        p = points[idx]
+        axis = int(np.argmax(p.max(axis=0) - p.min(axis=0)))
+        order = np.lexsort((idx, p[:, axis]))                 # by coordinate, ties by global id
+        cum = np.cumsum(w[idx][order])
+        cut = int(np.searchsorted(cum, cum[-1] * kl / k, side='left')) + 1
+        cut = min(max(cut, kl), len(idx) - (k - kl))          # every rank owns at least one node
+        stack.append((idx[order[:cut]], first, kl))
+        stack.append((idx[order[cut:]], first + kl, k - kl))
+    return owner
+
+
+def node_owners(points, n_parts, cells=None, weights=None, method='rcb'):
+    """
+    owner[node] in [0, n_parts).  method = 'rcb' (default): recursive coordinate bisection, parts are boxes (rcb_owners);
+    'morton': contiguous ranges of the Morton order (rounds 1-4).  With ``cells`` / ``weights`` the parts carry equal WORK
     (cumulative node_weights, SURVEY section 8e "equal-nnz ranges"); without, equal node counts.
     DOLFIN/ParMETIS balance vertices too, under mpirun (README.md:142-158); on the structured BASELINE meshes the two
     rules coincide, on an unstructured mesh (rows 6..46 long) equal counts leave ~5-10 % more nnz on some rank.
@@ -81,6 +115,10 @@ def node_owners(points, n_parts, cells=None, weights=None):
     n = len(points)
     if n_parts == 1:
         return np.zeros(n, dtype=np.int32)
+    if method == 'rcb':
+        if weights is None:
+            weights = node_weights(n, cells) if cells is not None else np.ones(n)
+        return rcb_owners(points, n_parts, weights)
     order = np.argsort(morton_keys(points), kind='stable')
     owner = np.empty(n, dtype=np.int32)
     if cells is None and weights is None:
@@ -165,16 +203,16 @@ def build_local_part(points, cells, owner, rank, n_parts, cell_global_ids=None):
                      recv_count.astype(np.int64))
 
 
-def partition_mesh(points, cells, n_parts, rank=None, balance='work'):
+def partition_mesh(points, cells, n_parts, rank=None, balance='work', method='rcb'):
     """Returns the LocalPart of ``rank`` (or the list of all parts when rank is None).  ``balance``: 'work' (equal
-    cumulative row work per rank, the default) or 'nodes' (equal node counts)."""
-    owner = node_owners(points, n_parts, cells if balance == 'work' else None)
+    cumulative row work per rank, the default) or 'nodes' (equal node counts); ``method``: 'rcb' | 'morton' (node_owners)."""
+    owner = node_owners(points, n_parts, cells if balance == 'work' else None, method=method)
     if rank is not None:
         return build_local_part(points, cells, owner, rank, n_parts)
     return [build_local_part(points, cells, owner, r, n_parts) for r in range(n_parts)]
 
 
-def partition_box_mesh(p0, p1, nx, ny, nz, n_parts, rank, slab=8):
+def partition_box_mesh(p0, p1, nx, ny, nz, n_parts, rank, slab=8, method='rcb'):
     """The LocalPart ``partition_mesh(BoxMesh(p0, p1, nx, ny, nz).points, .cells, n_parts, rank)`` returns, without
     building the whole mesh's cells: node weights from the box's connectivity rule, and only the hexahedra around the
     rank's own nodes are generated (slabs of ``slab`` layers, each cut to the (ix, iy) range of the own nodes it holds).
@@ -182,7 +220,7 @@ def partition_box_mesh(p0, p1, nx, ny, nz, n_parts, rank, slab=8):
     intermediates) to its share."""
     from .mesh import box_points, box_cells
     points = box_points(p0, p1, nx, ny, nz)
-    owner = node_owners(points, n_parts, weights=box_node_weights(nx, ny, nz))
+    owner = node_owners(points, n_parts, weights=box_node_weights(nx, ny, nz), method=method)
     owned = np.flatnonzero(owner == rank)
     oi = owned % (nx + 1)
     oj = (owned // (nx + 1)) % (ny + 1)

@@ -278,6 +278,9 @@ typedef struct glims_stats {
   double  us_cheb_median;
   int64_t stream_nontemporal; /* what stream_policy resolved to: 1 non-temporal, 0 cached */
   int64_t krylov_working_set; /* bytes the operator pass + vector update of one Krylov iteration touch (what AUTO decides on) */
+  double  mg_box_fraction;  /* elasticity multigrid, partitioned runs: this rank's work box / the replicated first grid (1 = the
+                               whole grid: not box-limited); with parts that are boxes (recursive coordinate bisection) ~ 1 / ranks
+                               + the smoothers' margin */
 } glims_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------------------- */
@@ -312,7 +315,8 @@ int glims_set_dirichlet_u(glims_ctx* h, int64_t n, const int64_t* dof_ids, const
  * data constrain the UNKNOWN of a step: the state that enters the step's 'u_previous' term keeps the values it has
  * (simulation_tumor_growth.py:115-117), the new values are written into the Newton iterate.  Time-dependent data: call
  * again before the next glims_step, as BoundaryConditions.time_update_bcs does for every step
- * (helper_classes.py:839-859). */
+ * (helper_classes.py:839-859).  Partitioned runs: a COLLECTIVE call -- every rank makes it, with its own constrained nodes
+ * (n = 0 where it owns none): the next glims_step exchanges the halo of the iterate on all ranks. */
 int glims_set_dirichlet_c(glims_ctx* h, int64_t n, const int64_t* node_ids, const double* values);
 
 /* Load vectors already integrated by the host (NULL clears):

@@ -92,3 +92,24 @@ def test_bench_and_public_api_refuse_to_run_without_a_gpu(tmp_path):
     with pytest.raises(Exception) as ei:
         sim.run(save_method=None, plot=False, output_dir=str(tmp_path))
     assert "HIP" in str(ei.value) or "device" in str(ei.value).lower()
+
+
+def test_bench_gpus_n_without_a_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (how a driver that mirrors its 1-GPU command would call it) must not be
+    a usage error: bench.py starts torch.distributed.run as a child process before anything touches the GPU and hands back the
+    child's exit code.  Here (no GPU) both ranks must come up and refuse loudly: exit code 3 per rank -> non-zero overall,
+    the message twice, nothing on stdout."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this box has a GPU (covered by tests/test_gpu_multirank.py::test_bench_self_launch_two_ranks_on_one_device)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["GLIMS_FORCE_DEVICE"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "c1", "--steps", "1",
+                        "--warmup", "0"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0 and r.returncode != 2, (r.returncode, r.stderr[-2000:])
+    assert "launching -m torch.distributed.run" in r.stderr and "--nproc-per-node 2" in r.stderr
+    assert r.stderr.count("no GPU visible") == 2, r.stderr[-2000:]
+    assert not r.stdout.strip()

@@ -502,3 +502,76 @@ def test_framed_multigrid_with_the_solve_history_over_five_solves(tmp_path, back
     assert not np.isnan(u).any() and rel_l2(u.reshape(-1), u1) < 1e-7
     assert np.all(np.abs(its2 - its1) <= 1)
     assert its1[-1] < its1[0]                                  # the history pays
+
+
+def test_bench_self_launch_two_ranks_on_one_device():
+    """`python bench.py --gpus 2` WITHOUT a launcher (WORLD_SIZE unset): bench.py starts torch.distributed.run itself as a child
+    process, relays the one JSON line and the exit code.  Rehearsed here with both ranks on this box's one GPU
+    (GLIMS_FORCE_DEVICE: torch side on gloo, halos through the host-staged transport); the line must be a 2-rank strong-scaling
+    line with per-rank diagnostics and a converged solver."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["GLIMS_FORCE_DEVICE"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "c3", "--size", "40",
+                        "--steps", "4", "--warmup", "3", "--no-cpu-baseline", "--no-alt"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    print("self-launched 2-rank line: %.3f ms/step, status %d, Krylov passes per step %.1f (Chebyshev %.1f), all-reduces per "
+          "step %s" % (out["ms_per_step"], out["solver_status"], out["config"]["cg_its_per_step"],
+                       out["config"]["chebyshev_passes_per_step"], [x["allreduces_per_step"] for x in out["ranks"]]))
+    assert out["n_gpus"] == 2 and out["solver_status"] == 0 and out["steps_completed"] == 4
+    assert len(out["ranks"]) == 2 and sum(x["rows"] for x in out["ranks"]) == 41 ** 3
+    assert out["config"]["chebyshev_passes_per_step"] > 0          # the dot-free iteration ran in the partitioned run
+
+
+# ---- unstructured mesh, recursive-coordinate-bisection parts, 4 and 8 ranks as threads of one process -------------------------
+def _rehearse():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("rehearse_partition", os.path.join(root, "tools", "rehearse_partition.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [4, 8])
+def test_brain_like_mesh_partitioned_into_boxes_matches_single_rank_and_oracle(backend, world):
+    """The brain-like unstructured mesh (reduced) cut into `world` boxes by recursive coordinate bisection, the ranks run as
+    threads of this process (parallel.ThreadedTransport: the GPU boxes allow at most 6 processes on a card): three RD steps
+    (dot-free Krylov iteration with halo exchange per pass, no all-reduce inside the solves) and one elasticity solve with the
+    framed multigrid (box-limited first grid) equal the single-rank run -- fields and iteration counts -- and the numpy oracle.
+    DOLFIN's counterpart: ParMETIS parts + PETSc under mpirun (README.md:142-158)."""
+    from glimslib_amd import workloads
+    rp = _rehearse()
+    w = workloads.config_brain_like(24000, mechanics=True, isolate=True)
+    st1, c1, u1, s1 = rp.run_single(w, 3, 1, world_for_h=world)
+    st, c, u, ss = rp.run_partitioned(w, world, 3, 1, method='rcb', box_min_nodes=6001)
+    assert st1 == 0 and st == 0
+    print("brain-like %d nodes on %d ranks: work boxes %s %% of the first grid, operator bytes per rank %s (single rank %d); "
+          "elasticity PCG %s vs %d single; Krylov passes %s vs %d; rows %s" %
+          (w.mesh.num_vertices(), world, [round(100 * s['mg_box_fraction']) for s in ss], [int(s['mg_grid1_bytes']) for s in ss],
+           s1['mg_grid1_bytes'], [int(s['mech_cg_its']) for s in ss], s1['mech_cg_its'], [int(s['cg_its']) for s in ss],
+           s1['cg_its'], [int(s['n_rows']) for s in ss]))
+    assert rp.rel_l2(c, c1) < 1e-9 and rp.rel_l2(u, u1) < 1e-7
+    assert all(abs(int(s['mech_cg_its']) - int(s1['mech_cg_its'])) <= 2 for s in ss)
+    assert all(int(s['newton_its']) == int(s1['newton_its']) for s in ss)
+    assert all(int(s['cheb_its']) > 0 and int(s['cheb_fallbacks']) == 0 for s in ss)
+    # equal work: rows within 12 % of the mean; parts are boxes: every rank has at most 7 + (world > 4) * 10 peers
+    rows = np.array([s['n_rows'] for s in ss], dtype=float)
+    assert rows.max() < 1.12 * rows.mean()
+    # numpy oracle (Newton + sparse LU), same steps
+    per = {k: w.per_cell(k) for k in ('D', 'rho', 'gamma', 'E', 'nu')}
+    dofs = (np.asarray(w.dirichlet_nodes)[:, None] * 3 + np.arange(3)).ravel()
+    o = OracleTumorGrowth(w.mesh.points, w.mesh.cells, per['D'], per['rho'], per['gamma'], per['E'], per['nu'], w.dt,
+                          dirichlet_u=(dofs, np.zeros(len(dofs))))
+    co = w.c0
+    for _ in range(3):
+        co, _ = o.rd_step(co, linear='cg')
+    assert rel_l2(c, co) < 1e-8

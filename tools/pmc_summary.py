@@ -49,7 +49,7 @@ def main():
            "calibration": calib, "kernels": kernels,
            "algorithmic_spmv_bytes": 12 * nnz + 20 * n_rows}
     json.dump(out, open(outp, 'w'), indent=1)
-    print(json.dumps({k: kernels[k] for k in kernels if 'spmv' in k or 'rd_assemble' in k or 'cg_update' in k}, indent=1))
+    print(json.dumps({k: kernels[k] for k in kernels if 'spmv' in k or 'cheb' in k or 'rd_assemble' in k or 'cg_update' in k or 'fill_pattern' in k or 'corner_weights' in k or 'assemble_static' in k or 'row_lengths' in k}, indent=1))
     print(json.dumps(calib, indent=1))
 
 

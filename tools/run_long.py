@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
-"""Long run of a BASELINE config in chunks, printing the solver statistics of every chunk (robustness check)."""
-import os, sys
+"""Long run of a BASELINE config in chunks, printing the solver statistics of every chunk (robustness check).
+    python tools/run_long.py [c4] [500] [20] [summary.json]
+The JSON summary (steps completed, status, mean / min / max ms per step over the chunks, hash of the library sources) is what
+bench.py quotes as config.full_run_* -- commit it as profiles/long_c4_run.json together with the printed log."""
+import json, os, sys
+for _v in ("OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "1")
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from glimslib_amd import workloads
@@ -18,6 +23,8 @@ h.setup(False)
 h.set_state(w.c0)
 done = 0
 prev = h.stats()
+windows = []
+final_status = 0
 while done < total:
     st = h.step(min(chunk, total - done))
     s = h.stats()
@@ -30,8 +37,24 @@ while done < total:
            (s['cg_its'] - prev['cg_its']) / max(n, 1), s['last_newton_res'], s['last_cg_res'],
            (s['ms_steps'] - prev['ms_steps']) / max(n, 1),
            "" if c is None else "  c in [%.3e, %.6f], mass %.6e" % (c.min(), c.max(), c.sum())), flush=True)
+    if n > 0:
+        windows.append((n, (s['ms_steps'] - prev['ms_steps']) / n))
+    final_status = st
     prev = s
     done += max(n, 1) if st == 0 else chunk
     if st != 0:
         print("FAILED with status", st, flush=True)
         break
+
+if len(sys.argv) > 4:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernels_sha16
+    s = h.stats()
+    full = [m for k, m in windows if k == chunk]
+    tot = sum(k for k, _ in windows)
+    json.dump({"workload": w.name, "steps_requested": total, "steps_completed": int(tot), "final_status": int(final_status),
+               "chunk": chunk, "ms_per_step_mean": sum(k * m for k, m in windows) / max(1, tot),
+               "ms_per_step_min_window": min(full) if full else None, "ms_per_step_max_window": max(full) if full else None,
+               "newton_its_per_step": s['newton_its'] / max(1, tot), "krylov_passes_per_step": s['cg_its'] / max(1, tot),
+               "chebyshev_fallbacks": int(s['cheb_fallbacks']), "kernels_sha16": kernels_sha16()},
+              open(sys.argv[4], "w"), indent=1)
