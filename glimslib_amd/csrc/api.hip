@@ -663,6 +663,9 @@ int glims_apply(glims_ctx* h, int which, const double* x, double* y, int reps, d
     if (ms_total) *ms_total = ms;
     h->stats.ms_spmv += ms;
     from_device_perm(h, yout.p, y, blk_out ? d : 1, h->n_own);
+    // which = 8 has left A(x) and its diagonal where A(c) belongs: put A(c) back (one more sweep, outside the timed region), so
+    // that every later glims_apply(0 | 5), glims_project or glims_step sees the operator of the STATE, as after any other `which`
+    if (which == 8 && h->have_state) gl_rd_assemble(h, h->c.p, zero_b.p, nullptr, xin.p, h->cg_r2.p, h->partials.p);
     return GLIMS_OK;
   });
 }

@@ -27,7 +27,8 @@
 // gathers) share one L2 while the XCDs together still walk the matrix front to back (measured: time of the plain
 // mapping, fabric reads 2.21 -> 1.97 GB per SpMV at 10 M rows; contiguous eighths are 1-5 % slower).
 // glims_options.stream_policy = AUTO: Krylov working sets up to this many bytes stream the operator with the default cache policy
-#define GL_STREAM_CACHED_LIMIT (192ll << 20)
+// (measured, profiles/r05_ab_rank_sized.txt: at 269 MB -- C4 / 8 -- cached loads win by 6-7 %, at 2.2 GB -- C4 -- the two are equal)
+#define GL_STREAM_CACHED_LIMIT (1024ll << 20)
 // (chunks of 128-512 blocks change the in-step kernel times by <= 2 %: profiles/r04_ab_xcd_chunk.txt)
 #define GL_XCD_CHUNK 64
 
@@ -506,9 +507,14 @@ struct glims_ctx {
   // of this run excite, from the Lanczos coefficients of recorded PCG solves
   struct ChebState {
     bool valid = false;                    // [lmin, lmax] usable
-    double lmin = 0.0, lmax = 0.0;         // union of the Ritz intervals of the last learning step's PCG solves
+    // Two intervals: [1] from all PCG solves of the last learning step, [0] from its LOOSE ones only (reduction >= GL_CHEB_LOOSE):
+    // what a tight solve has to resolve (components of relative size 1e-7 at the ends of the spectrum) a solve to 3e-4 may
+    // ignore -- brain-like mesh at 1 M nodes: [0.70, 1.96] against [0.033, 3.63]
+    double lmin = 0.0, lmax = 0.0;         // [1]
+    double lmin0 = 0.0, lmax0 = 0.0;       // [0]; lmax0 = 0: none (then [1] serves)
     double acc_lmin = 0.0, acc_lmax = 0.0; // ... being accumulated by the current learning step
-    int learned = 0;                       // PCG solves that contributed to acc_*
+    double acc_lmin0 = 0.0, acc_lmax0 = 0.0;
+    int learned = 0, learned0 = 0;         // PCG solves that contributed to acc_* / acc_*0
     int age = 0;                           // steps since the interval was measured
     int m_hint = 0;                        // passes the device chose for the last warm-started solve (bounds the next one's launches)
     // Which iteration a solve AFTER a step's first one uses (the first, loose one always takes the dot-free iteration): PCG

@@ -1154,6 +1154,11 @@ static int cg_solve(glims_ctx* h, const CgVecs& v, double tol_abs, int maxit, in
 }
 
 // ---- the dot-free solve -------------------------------------------------------------------------------------------------
+// Safety factors on the chosen interval.  A lower end set too low only costs iterations (prototype: 0.5 x -> +50 %); an upper
+// end set too low makes the iteration diverge on what lies above it, so that end gets more room.
+static const double GL_CHEB_LO = 0.9, GL_CHEB_HI = 1.06;
+static const double GL_CHEB_LOOSE = 3e-5;   // reductions down to this use the interval of the loose learning solves
+#define GL_CHEB_HIST GL_CG_HIST
 // Chebyshev recurrence on [a, b]: d_0 = z_0 / theta;  d_k = rho_k rho_(k-1) d_(k-1) + (2 rho_k / delta) z_k,  z = Dinv r
 struct ChebRec {
   double theta, delta, sigma, rho;
@@ -1173,64 +1178,141 @@ struct ChebRec {
   }
 };
 
-// Extreme eigenvalues of the Lanczos matrix of a PCG solve (recorded alpha_k, beta_k; beta_0 = 0): the Ritz interval of
-// Dinv A on the Krylov space of THIS right-hand side.  Bisection on the Sturm sequence (m <= GL_CG_HIST).
-static bool ritz_interval(const double* hist, int m, double* lo, double* hi) {
+// The interval for the dot-free solves from one recorded PCG solve (alpha_k, beta_k; beta_0 = 0; m <= GL_CHEB_HIST iterations,
+// residual reduction eps).  The Lanczos matrix T of the solve gives the spectral measure of ITS right-hand side in Dinv A:
+// Ritz values theta_i with weights w_i = (first component of T's i-th eigenvector)^2 (Gauss quadrature: for any polynomial q
+// of degree < 2m, |q(Dinv A) r|^2 / |r|^2 = sum_i w_i q(theta_i)^2).  The extreme Ritz values converge to the ends of the TRUE
+// spectrum however little of the right-hand side lives there (brain-like mesh at 1 M nodes: [0.033, 3.63], kappa = 110, from
+// components far below the tolerance; the bulk sits in [0.6, 2.1]) -- a Chebyshev iteration sized for that interval needs 4x
+// PCG's passes.  So the interval is CHOSEN: starting from all Ritz values, the end points move inwards as long as the degree
+// k that brings sqrt(sum_i w_i (T_k(x_i) / T_k(sigma))^2) below eps gets smaller -- Ritz values left outside are weighed with
+// the polynomial's growth there, not ignored.
+static double cheb_poly_ratio(int k, double x, double sigma) {   // |T_k(x)| / T_k(sigma), sigma > 1
+  const double as = std::log(sigma + std::sqrt(sigma * sigma - 1.0));
+  const double ax = std::fabs(x);
+  if (ax <= 1.0) return std::fabs(std::cos(k * std::acos(ax))) / std::cosh(k * as);
+  const double ao = std::log(ax + std::sqrt(ax * ax - 1.0));
+  return std::exp(k * (ao - as)) * (1.0 + std::exp(-2.0 * k * ao)) / (1.0 + std::exp(-2.0 * k * as));
+}
+static int cheb_degree_for(const std::vector<double>& th, const std::vector<double>& w, double a, double b, double eps) {
+  if (!(b > a) || !(a > 0.0)) return GL_CHEB_HIST * 4;
+  const double theta = 0.5 * (a + b), delta = 0.5 * (b - a), sigma = theta / delta;
+  for (int k = 1; k <= 4 * GL_CHEB_HIST; ++k) {
+    double s2 = 0.0;
+    for (size_t i = 0; i < th.size(); ++i) {
+      const double q = cheb_poly_ratio(k, (theta - th[i]) / delta, sigma);
+      s2 += w[i] * q * q;
+    }
+    if (std::sqrt(s2) <= eps) return k;
+  }
+  return 4 * GL_CHEB_HIST;
+}
+static bool ritz_interval(const double* hist, int m, double eps, double* lo, double* hi, double* full_lo, double* full_hi) {
   if (m < 2) return false;
-  std::vector<double> a((size_t)m), b2((size_t)m, 0.0);   // diagonal, squared off-diagonal (b2[k] couples k-1 and k)
+  // T (dense, m <= 64) and its eigen-decomposition by cyclic Jacobi rotations
+  std::vector<double> T((size_t)m * m, 0.0), V((size_t)m * m, 0.0);
   for (int k = 0; k < m; ++k) {
     const double al = hist[2 * k], be = hist[2 * k + 1];
     if (!(al > 0.0) || !std::isfinite(al) || !(be >= 0.0) || !std::isfinite(be)) return false;
-    a[(size_t)k] = 1.0 / al + (k > 0 ? be / hist[2 * (k - 1)] : 0.0);
-    if (k > 0) b2[(size_t)k] = be / (hist[2 * (k - 1)] * hist[2 * (k - 1)]);
+    T[(size_t)k * m + k] = 1.0 / al + (k > 0 ? be / hist[2 * (k - 1)] : 0.0);
+    if (k > 0) T[(size_t)k * m + k - 1] = T[(size_t)(k - 1) * m + k] = std::sqrt(be) / hist[2 * (k - 1)];
+    V[(size_t)k * m + k] = 1.0;
   }
-  double glo = 1e300, ghi = -1e300;
-  for (int k = 0; k < m; ++k) {
-    const double rad = (k > 0 ? std::sqrt(b2[(size_t)k]) : 0.0) + (k + 1 < m ? std::sqrt(b2[(size_t)k + 1]) : 0.0);
-    glo = std::min(glo, a[(size_t)k] - rad);
-    ghi = std::max(ghi, a[(size_t)k] + rad);
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0;
+    for (int p = 0; p < m; ++p)
+      for (int q = p + 1; q < m; ++q) off += T[(size_t)p * m + q] * T[(size_t)p * m + q];
+    if (off < 1e-28) break;
+    for (int p = 0; p < m; ++p)
+      for (int q = p + 1; q < m; ++q) {
+        const double apq = T[(size_t)p * m + q];
+        if (std::fabs(apq) < 1e-300) continue;
+        const double app = T[(size_t)p * m + p], aqq = T[(size_t)q * m + q];
+        const double tau = (aqq - app) / (2.0 * apq);
+        const double t = (tau >= 0.0 ? 1.0 : -1.0) / (std::fabs(tau) + std::sqrt(1.0 + tau * tau));
+        const double c = 1.0 / std::sqrt(1.0 + t * t), sn = t * c;
+        for (int k = 0; k < m; ++k) {
+          const double akp = T[(size_t)k * m + p], akq = T[(size_t)k * m + q];
+          T[(size_t)k * m + p] = c * akp - sn * akq;
+          T[(size_t)k * m + q] = sn * akp + c * akq;
+        }
+        for (int k = 0; k < m; ++k) {
+          const double apk = T[(size_t)p * m + k], aqk = T[(size_t)q * m + k];
+          T[(size_t)p * m + k] = c * apk - sn * aqk;
+          T[(size_t)q * m + k] = sn * apk + c * aqk;
+        }
+        for (int k = 0; k < m; ++k) {
+          const double vkp = V[(size_t)k * m + p], vkq = V[(size_t)k * m + q];
+          V[(size_t)k * m + p] = c * vkp - sn * vkq;
+          V[(size_t)k * m + q] = sn * vkp + c * vkq;
+        }
+      }
   }
-  auto below = [&](double x) {   // eigenvalues < x
-    int cnt = 0;
-    double q = 1.0;
-    for (int k = 0; k < m; ++k) {
-      q = a[(size_t)k] - x - (k > 0 ? b2[(size_t)k] / q : 0.0);
-      if (q == 0.0) q = 1e-300;
-      if (q < 0.0) ++cnt;
+  std::vector<int> ord((size_t)m);
+  for (int i = 0; i < m; ++i) ord[(size_t)i] = i;
+  std::sort(ord.begin(), ord.end(), [&](int x, int y) { return T[(size_t)x * m + x] < T[(size_t)y * m + y]; });
+  std::vector<double> th((size_t)m), w((size_t)m);
+  for (int i = 0; i < m; ++i) {
+    th[(size_t)i] = T[(size_t)ord[(size_t)i] * m + ord[(size_t)i]];
+    w[(size_t)i] = V[(size_t)0 * m + ord[(size_t)i]] * V[(size_t)0 * m + ord[(size_t)i]];   // first component of eigenvector i
+  }
+  if (!(th[0] > 0.0) || !std::isfinite(th[(size_t)m - 1])) return false;
+  *full_lo = th[0];
+  *full_hi = th[(size_t)m - 1];
+  eps = std::min(0.5, std::max(1e-12, eps));
+  int ia = 0, ib = m - 1;
+  auto deg = [&](int a, int b) { return cheb_degree_for(th, w, GL_CHEB_LO * th[(size_t)a], GL_CHEB_HI * th[(size_t)b], eps); };
+  int best = deg(ia, ib);
+  for (bool moved = true; moved && ib - ia >= 2;) {
+    moved = false;
+    const int da = deg(ia + 1, ib);
+    if (da < best) {
+      best = da;
+      ++ia;
+      moved = true;
     }
-    return cnt;
-  };
-  double l0 = glo, l1 = ghi;   // smallest: the x where below(x) turns >= 1
-  for (int i = 0; i < 80; ++i) {
-    const double mid = 0.5 * (l0 + l1);
-    if (below(mid) >= 1) l1 = mid; else l0 = mid;
+    if (ib - ia < 2) break;
+    const int db = deg(ia, ib - 1);
+    if (db < best) {
+      best = db;
+      --ib;
+      moved = true;
+    }
   }
-  double h0 = glo, h1 = ghi;   // largest: the x where below(x) turns == m
-  for (int i = 0; i < 80; ++i) {
-    const double mid = 0.5 * (h0 + h1);
-    if (below(mid) >= m) h1 = mid; else h0 = mid;
-  }
-  *lo = 0.5 * (l0 + l1);
-  *hi = 0.5 * (h0 + h1);
-  return *lo > 0.0 && *hi > *lo && std::isfinite(*hi);
+  *lo = th[(size_t)ia];
+  *hi = th[(size_t)ib];
+  return *lo > 0.0 && *hi > *lo;
 }
 
-// A finished PCG solve of `its` iterations contributes its Ritz interval to the one being learnt
-static void cheb_learn(glims_ctx* h, int64_t its) {
+// A finished PCG solve of `its` iterations (residual reduction eps) contributes its interval to the one being learnt
+static void cheb_learn(glims_ctx* h, int64_t its, double eps) {
   const int m = (int)std::min<int64_t>(its, GL_CG_HIST);
   if (m < 2 || !h->cg_hist.p) return;
   double hist[2 * GL_CG_HIST];
   GL_HIP(hipMemcpyAsync(hist, h->cg_hist.p, (size_t)2 * m * sizeof(double), hipMemcpyDeviceToHost, h->st));
   GL_HIP(hipStreamSynchronize(h->st));
-  double lo, hi;
-  if (!ritz_interval(hist, m, &lo, &hi)) return;
-  glims_ctx::ChebState& cs = h->cheb;
+  double lo, hi, flo, fhi;
+  if (!ritz_interval(hist, m, eps, &lo, &hi, &flo, &fhi)) return;
   if (getenv("GLIMS_VERBOSE"))
-    fprintf(stderr, "glims dot-free solves: PCG solve of %lld iterations, Ritz interval [%.4f, %.4f]\n", (long long)its, lo, hi);
+    fprintf(stderr, "glims dot-free solves: PCG solve of %lld iterations (reduction %.1e): Ritz values in [%.4f, %.4f], interval chosen "
+            "[%.4f, %.4f]\n", (long long)its, eps, flo, fhi, lo, hi);
+  glims_ctx::ChebState& cs = h->cheb;
   cs.acc_lmin = cs.learned ? std::min(cs.acc_lmin, lo) : lo;
   cs.acc_lmax = cs.learned ? std::max(cs.acc_lmax, hi) : hi;
   cs.learned++;
+  if (eps >= GL_CHEB_LOOSE) {
+    cs.acc_lmin0 = cs.learned0 ? std::min(cs.acc_lmin0, lo) : lo;
+    cs.acc_lmax0 = cs.learned0 ? std::max(cs.acc_lmax0, hi) : hi;
+    cs.learned0++;
+  }
   h->stats.cheb_learn_solves++;
+}
+// the interval a solve that wants the reduction `red` uses
+static void cheb_interval(const glims_ctx* h, double red, double* a, double* b) {
+  const glims_ctx::ChebState& cs = h->cheb;
+  const bool loose = red >= GL_CHEB_LOOSE && cs.lmax0 > 0.0;
+  *a = GL_CHEB_LO * (loose ? cs.lmin0 : cs.lmin);
+  *b = GL_CHEB_HI * (loose ? cs.lmax0 : cs.lmax) * h->cheb_test_hi;
 }
 
 // Cost of one Chebyshev pass relative to one PCG iteration (operator pass + reduction + vector update): algorithmic bytes of
@@ -1250,10 +1332,8 @@ static double cheb_cost_ratio(glims_ctx* h) {
   return (12.0 * v[1] + 60.0 * v[0] + B0) / (12.0 * v[1] + 136.0 * v[0] + 3.0 * B0);
 }
 
-// Safety factors on the measured interval.  A lower end set too low only costs iterations (prototype: 0.5 x -> +50 %); an upper
-// end set too low makes the iteration diverge on what lies above it, so the Ritz value -- an estimate from inside -- gets more room.
-static const double GL_CHEB_LO = 0.85, GL_CHEB_HI = 1.08;
-static const int GL_CHEB_MAX = 96;
+static const int GL_CHEB_MAX = 96;    // launches of one solve at most
+static const int GL_CHEB_LONG = 48;   // solves that would need more passes than this run PCG
 
 struct ChebRun {
   int passes = 0;        // operator passes enqueued that can run (host-known count), or the upper bound when planned
@@ -1272,7 +1352,9 @@ static ChebRun cheb_solve(glims_ctx* h, const CgVecs& v, double tol_abs, double 
   const int64_t n = h->n_own;
   h->cheb_delta.alloc((size_t)h->n_nodes);
   h->cheb_plan.alloc(1);
-  ChebRec rec(GL_CHEB_LO * h->cheb.lmin, GL_CHEB_HI * h->cheb.lmax * h->cheb_test_hi);
+  double ia, ib;
+  cheb_interval(h, tol_abs / std::max(r_norm > 0.0 ? r_norm : r_bound, tol_abs), &ia, &ib);
+  ChebRec rec(ia, ib);
   PackMap pm;
   if (split && h->n_send > 0) {
     pm.ref = h->send_ref.p;
@@ -1525,7 +1607,7 @@ int gl_step(glims_ctx* h, int n_steps) {
     if (cheb_allowed && cb.valid && ++cb.age >= 32) cb.valid = false;
     const bool cheb_learning = cheb_allowed && !cb.valid;
     if (cheb_learning) {
-      cb.learned = 0;
+      cb.learned = cb.learned0 = 0;
       cb.pcg_best_its = 0;
       cb.m_hint = 0;
       h->cg_hist.alloc((size_t)2 * GL_CG_HIST);
@@ -1655,14 +1737,21 @@ int gl_step(glims_ctx* h, int n_steps) {
                               hipMemcpyDeviceToDevice, h->st));
       }
       bool use_cheb = cheb_allowed && cb.valid;
-      if (use_cheb && it >= 1 && o.rd_linear == GLIMS_RD_LINEAR_AUTO && cb.cost_ratio > 0.0 && cb.pcg_its_per_decade > 0.0 &&
-          tol_lin < nr) {
-        // a tight solve: PCG's iterations (from its rate in the last learning step) against the passes the Chebyshev bound
-        // asks for, weighted by what each costs
-        ChebRec rec(GL_CHEB_LO * cb.lmin, GL_CHEB_HI * cb.lmax * h->cheb_test_hi);
+      if (use_cheb && tol_lin < nr) {
+        double ia, ib;
+        cheb_interval(h, tol_lin / nr, &ia, &ib);
+        ChebRec rec(ia, ib);
         const int passes = rec.iterations(tol_lin / nr) - (cheap_next ? 0 : 1);
-        const double its_pcg = std::ceil(cb.pcg_its_per_decade * std::log10(nr / tol_lin)) + 1.0;
-        if (its_pcg < 0.95 * cb.cost_ratio * passes) use_cheb = false;
+        if (passes > GL_CHEB_LONG) {
+          // an ill-conditioned system (stiff step with the Jacobi preconditioner forced): the Chebyshev bound grows like
+          // sqrt(kappa) per decade, PCG converges superlinearly there -- and a count cut off at GL_CHEB_MAX would be a weak solve
+          use_cheb = false;
+        } else if (it >= 1 && o.rd_linear == GLIMS_RD_LINEAR_AUTO && cb.cost_ratio > 0.0 && cb.pcg_its_per_decade > 0.0) {
+          // a tight solve: PCG's iterations (from its rate in the last learning step) against the passes the Chebyshev bound
+          // asks for, weighted by what each costs
+          const double its_pcg = std::ceil(cb.pcg_its_per_decade * std::log10(nr / tol_lin)) + 1.0;
+          if (its_pcg < 0.95 * cb.cost_ratio * passes) use_cheb = false;
+        }
       }
       bool warm = false, ws_fused = false;
       if (it == 0 && (o.flags & GLIMS_FLAG_WARM_START) && !extrapolate) {   // both options own the c_old buffer
@@ -1733,7 +1822,8 @@ int gl_step(glims_ctx* h, int n_steps) {
           h->stats.cg_its += its;
           h->stats.last_cg_res = res;
           if (cheb_learning && cs == GLIMS_OK) {
-            cheb_learn(h, its);
+            // (reduction the solve achieved; a warm-started solve's initial residual is not known to the host: what was asked for)
+            cheb_learn(h, its, (!warm && res > 0.0 && res < nr) ? res / nr : tol_lin / nr);
             // PCG's iterations per decade in the tightest solve whose initial residual the host knows (not a warm-started one)
             if (!warm && its > cb.pcg_best_its && res > 0.0 && res < nr) {
               cb.pcg_best_its = (int)its;
@@ -1795,6 +1885,7 @@ int gl_step(glims_ctx* h, int n_steps) {
         hipLaunchKernelGGL(k_sub_inplace, dim3(grid_exact(n)), dim3(256), 0, h->st, n, h->c.p, h->cheb_delta.p);
         GL_HIP(hipGetLastError());
         cb.valid = false;
+        cb.lmax0 = cb.lmin0 = 0.0;   // (the loose interval is re-learnt from scratch)
         h->stats.cheb_fallbacks++;
         h->pending = false;
         rd_sweep(h, nullptr, norms, nullptr, /*exchange_c=*/true);
@@ -1846,6 +1937,14 @@ int gl_step(glims_ctx* h, int n_steps) {
       }
       cb.lmin = cb.acc_lmin;
       cb.lmax = cb.acc_lmax;
+      if (cb.learned0 > 0) {
+        if (cb.lmax0 > 0.0) {
+          cb.acc_lmax0 = std::max(cb.acc_lmax0, 0.5 * (cb.acc_lmax0 + cb.lmax0));
+          cb.acc_lmin0 = std::min(cb.acc_lmin0, 0.5 * (cb.acc_lmin0 + cb.lmin0));
+        }
+        cb.lmin0 = cb.acc_lmin0;
+        cb.lmax0 = cb.acc_lmax0;
+      }
       cb.valid = true;
       cb.age = 0;
       h->stats.cheb_lmin = cb.lmin;

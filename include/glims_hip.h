@@ -362,7 +362,7 @@ int glims_reset_stats(glims_ctx* h);
  *        for the current state c (equals which = 0 once A(c) has been assembled for that state; not used by the solver:
  *        measured 4.2x slower than the assembled product at 10 M rows -- 1.38 ms and 5.15 GB against 0.33 ms and 1.77 GB --
  *        profiles/r02_matfree_ab.txt);  8 = the assembly sweep at c = x with a zero right-hand side, y = -1/2 (A(x) + S) x
- *        (timing hook, tools/ab_sweep.py: A(x) and its diagonal are left in place, the next glims_step re-assembles);
+ *        (timing hook, tools/ab_sweep.py; with a state set, A(c) and its diagonal are re-assembled before the call returns);
  *        9 = the quadratic-term pass with a = delta = x, y -= dt N(x) x per repetition (timing hook).
  *        Ghost rows of y are returned as 0. */
 int glims_apply(glims_ctx* h, int which, const double* x, double* y, int reps, double* ms_total);

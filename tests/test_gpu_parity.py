@@ -66,6 +66,33 @@ def test_operators_match_oracle(backend, dim, ragged):
     h.close()
 
 
+def test_timing_hooks_leave_the_operator_of_the_state_in_place(backend):
+    """glims_apply(which = 8 | 9) are timing hooks that run the assembly sweep / the quadratic-term pass at c = x; once a state
+    is set, A(c) of the STATE must be back in place when they return: a following which = 0 / 5 product and the next step see
+    the same operator as without the hook."""
+    rng = np.random.default_rng(5)
+    mesh, lab = _case(3)
+    n = mesh.num_vertices()
+    h = _handle(backend, mesh, lab, 0.7, mechanics=False)
+    o = _oracle(mesh, lab, 0.7)
+    c = rng.random(n)
+    h.set_state(c)
+    assert h.step(1) == 0
+    c1 = h.get_state(want_u=False)[0]
+    h.rd_residual(c1, c)                       # assembles A(c1)
+    x = rng.standard_normal(n)
+    ref = h.apply(0, x)[0]
+    assert rel_l2(ref, o.rd_jacobian(c1) @ x) < 1e-13
+    y8 = h.apply(8, x, reps=2)[0]
+    A_x = o.rd_jacobian(x)
+    assert rel_l2(y8, -0.5 * ((A_x + o.S) @ x)) < 1e-12
+    h.apply(9, x, reps=2)
+    # (the state is c1: the hook re-assembled A(c1), not A(x))
+    assert np.array_equal(h.apply(0, x)[0], ref) or rel_l2(h.apply(0, x)[0], ref) < 1e-15
+    assert rel_l2(h.apply(5, x)[0], ref) < 1e-14
+    h.close()
+
+
 @pytest.mark.parametrize("dim", [2, 3])
 def test_time_stepping_matches_oracle_split_and_monolithic(backend, dim):
     mesh, lab = _case(dim)
@@ -730,7 +757,7 @@ def test_brain_like_mesh_reduced_matches_the_numpy_oracle(backend):
     """The brain-like unstructured workload (jittered-lattice Delaunay mesh, curved two-tissue interface, config C3's
     parameters; stand-in for the CGAL atlas meshes of test_case_comparison_3D_atlas.py:84-121) at reduced size: operators
     and 5 coupled steps against the numpy oracle's split loop (Newton + sparse LU), displacement clamped on the hull."""
-    w = workloads.config_brain_like(4000, mechanics=True, workers=2)
+    w = workloads.config_brain_like(4000, mechanics=True, workers=2, isolate=True)
     n = w.mesh.num_vertices()
     dofs = (w.dirichlet_nodes[:, None] * 3 + np.arange(3)).ravel()
     # a wider seed than the workload's (node spacing is ~13 mm at this size): the front must cross the tissue interface
@@ -755,7 +782,7 @@ def test_brain_like_mesh_full_size_matches_the_c_oracle(backend):
     static operators against the C/OpenMP oracle, plus size-independent properties (symmetry of S, row sums of M = nodal
     volumes adding up to the box)."""
     from oracle.c_port import COracle
-    w = workloads.config_brain_like(1000000)
+    w = workloads.config_brain_like(1000000, isolate=True)
     n = w.mesh.num_vertices()
     co = COracle(w.mesh.points, w.mesh.cells, w.per_cell('D'), w.per_cell('rho'), w.dt)
     ref = co.step(w.c0, 5, rtol=1e-11, cg_rtol=1e-4)

@@ -212,7 +212,7 @@ def test_brain_like_mesh_with_stiff_steps(backend):
     there the auxiliary-grid hierarchy keeps the lattice's iteration count (4-5 per Newton solve; a Delaunay mesh of random
     points, slivers included, needs ~40).  Reduced size against the oracle's Newton + sparse LU, then at 200 k nodes against
     the Jacobi path with the iteration counts asserted."""
-    w = workloads.config_brain_like(12000, workers=2)
+    w = workloads.config_brain_like(12000, workers=2, isolate=True)
     t = dict(w.tables)
     t['D'] = [3000.0 * d for d in w.tables['D']]                          # dt D / h^2 of 50-300 at a node spacing of ~9 mm
     c0 = np.exp(-0.002 * ((w.mesh.points - np.array([118.0, -109.0, 72.0])) ** 2).sum(axis=1))
@@ -229,7 +229,7 @@ def test_brain_like_mesh_with_stiff_steps(backend):
         assert rel_l2(h.get_state(want_u=False)[0], co) < 1e-9
         h.close()
     # 200 k nodes, diffusivities x 300 (the stiff case of tools/run_rd_precond.py)
-    w = workloads.config_brain_like(200000)
+    w = workloads.config_brain_like(200000, isolate=True)
     t = dict(w.tables)
     t['D'] = [300.0 * d for d in w.tables['D']]
     res = {}

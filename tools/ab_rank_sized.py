@@ -42,7 +42,7 @@ def main():
     variants = [v for v in VARIANTS if not only or any(tok in v[0] for tok in only.split(","))]
     for spec in specs:
         name, _, size = spec.partition(":")
-        w = workloads.by_name(name, int(size) if size else None)
+        w = workloads.by_name(name, int(size) if size else None)   # (bl:<points> = the brain-like unstructured mesh)
         h = B.Handle(w.mesh.points, w.mesh.cells, w.cell_label)
         t = w.tables
         h.set_materials(t['D'], t['rho'], t['gamma'], t['E'], t['nu'])
