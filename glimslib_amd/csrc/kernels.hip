@@ -112,7 +112,9 @@ __global__ __launch_bounds__(GL_WAVE) void k_corner_weights(const int64_t* __res
                                                              uint32_t* __restrict__ cs2, uint2* __restrict__ cq) {
   constexpr int NV = D + 1;
   constexpr double fact = D == 2 ? 1.0 / 60.0 : 1.0 / 120.0;
-  const int s = blockIdx.x, lane = threadIdx.x;
+  // (neighbouring slices on ONE XCD: the four rows that share a cell then share an L2 -- with block b on XCD b % 8 each of them
+  //  fetched the cell's data from memory on its own)
+  const int s = xcd_chunk_remap(blockIdx.x, gridDim.x, GL_XCD_CHUNK), lane = threadIdx.x;
   const int64_t cbase = cslice_ptr[s];
   const int clen = (int)((cslice_ptr[s + 1] - cbase) >> 6);
   const uint32_t dk = diag_k[(int64_t)s * GL_WAVE + lane];
@@ -166,9 +168,8 @@ __global__ __launch_bounds__(GL_WAVE) void k_assemble_static(
     const uint8_t* __restrict__ label, const double* __restrict__ mat, double dt, const PlaneOut po, int max_len) {
   constexpr int NV = D + 1, GE = 1 + NV * D;
   constexpr double mfac = 1.0 / ((D + 1) * (D + 2));
-  extern __shared__ double acc[];   // [NP][max_len][64], then the 64 geometry records of the current round [GE][64]
-  double* rec = acc + (size_t)NP * max_len * GL_WAVE;
-  const int s = blockIdx.x, lane = threadIdx.x;
+  extern __shared__ double acc[];   // [NP][max_len][64]
+  const int s = xcd_chunk_remap(blockIdx.x, gridDim.x, GL_XCD_CHUNK), lane = threadIdx.x;   // (see k_corner_weights)
   const int64_t row = (int64_t)s * GL_WAVE + lane;
   const int64_t base = slice_ptr[s], cbase = cslice_ptr[s];
   const int len = (int)((slice_ptr[s + 1] - base) >> 6), clen = (int)((cslice_ptr[s + 1] - cbase) >> 6);
@@ -179,23 +180,12 @@ __global__ __launch_bounds__(GL_WAVE) void k_assemble_static(
   for (int q = 0; q < clen; ++q) {
     const int64_t ci = cbase + (int64_t)q * GL_WAVE + lane;
     const int32_t e = celem[ci];
-    // The 64 geometry records of this round, fetched by the WAVE: lane l of pass t reads double (t * 64 + l) of the 64 x GE
-    // block, i.e. consecutive lanes read consecutive doubles of a record (5-6 lines per load instruction instead of 64, each
-    // record's line requested once instead of 13 times by a lane that has long lost it from L1: 47.7 GB of fabric reads per
-    // launch at 10 M rows, profiles/r04_a_pmc_c4.json), staged in LDS record-component-major.
-    __syncthreads();   // (one wave per block: orders the previous round's reads before these writes)
-#pragma unroll
-    for (int t = 0; t < GE; ++t) {
-      const int f = t * GL_WAVE + lane, r = f / GE, j = f - r * GE;
-      const int32_t er = __shfl(e, r, GL_WAVE);
-      rec[j * GL_WAVE + r] = er < 0 ? 0.0 : egeo[(int64_t)er * GE + j];
-    }
-    __syncthreads();
     if (e < 0) continue;
     const uint32_t slots = cslots[ci];
-    double g[GE];
-#pragma unroll
-    for (int j = 0; j < GE; ++j) g[j] = rec[j * GL_WAVE + lane];
+    // (The record staged through LDS by the whole wave -- consecutive lanes reading consecutive doubles of a record, 5-6 lines per
+    //  load instruction instead of 64 -- was built and measured in round 5: 42 instead of 48 GB of fabric reads, but 15.2 instead of
+    //  10.3 ms at 10 M rows (two barriers, 13 cross-lane reads and 26 LDS accesses per incidence round): taken out again.)
+    const double* g = egeo + (int64_t)e * GE;
     const double vol = g[0];
     const int lab = label[e];
     int li = 0;
@@ -204,7 +194,7 @@ __global__ __launch_bounds__(GL_WAVE) void k_assemble_static(
       if ((int)((slots >> (8 * m)) & 255u) == dk) li = m;
     double gi[D];
 #pragma unroll
-    for (int a = 0; a < D; ++a) gi[a] = rec[(1 + li * D + a) * GL_WAVE + lane];   // (li is a run-time index: from LDS, not from the register copy)
+    for (int a = 0; a < D; ++a) gi[a] = g[1 + li * D + a];
     const double Dc = mat[0 * GL_MAX_LABELS + lab], rho = mat[1 * GL_MAX_LABELS + lab],
                  gam = mat[2 * GL_MAX_LABELS + lab], mu = mat[3 * GL_MAX_LABELS + lab],
                  lam = mat[4 * GL_MAX_LABELS + lab];
@@ -1384,7 +1374,7 @@ __global__ void k_to_float(int64_t n, const double* __restrict__ a, float* __res
 template <int D, int NP>
 static void assemble_planes(glims_ctx* h, int mode, int ca, const PlaneOut& po) {
   const DevPattern& p = h->pat;
-  const size_t lds = ((size_t)NP * p.max_len + (1 + (D + 1) * D)) * GL_WAVE * sizeof(double);
+  const size_t lds = (size_t)NP * p.max_len * GL_WAVE * sizeof(double);
   set_lds(k_assemble_static<D, NP>, lds);
   hipLaunchKernelGGL((k_assemble_static<D, NP>), dim3(p.n_slices), dim3(GL_WAVE), lds, h->st, mode, ca, h->n_own,
                      p.slice_ptr.p, p.cslice_ptr.p, p.cslots.p, p.celem.p, p.diag_k.p, h->egeo.p, h->label.p,

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(GL_WAVE) void k_row_lengths(int64_t n_own, int nv, 
                                                           int32_t* __restrict__ len, int32_t* __restrict__ clen,
                                                           const int32_t* __restrict__ m2o, int* __restrict__ flags) {
   __shared__ int32_t sl[LIST_LDS * GL_WAVE];
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = (int64_t)xcd_chunk_remap(blockIdx.x, gridDim.x, GL_XCD_CHUNK) * blockDim.x + threadIdx.x;
   if (i >= n_own) return;
   RowList a;
   a.lds = sl + threadIdx.x;
@@ -301,7 +301,8 @@ __global__ __launch_bounds__(GL_WAVE) void k_fill_pattern(int64_t n_own, int nv,
                                                            uint32_t* __restrict__ cslots, int32_t* __restrict__ celem,
                                                            uint8_t* __restrict__ is_boundary) {
   __shared__ int32_t sl[LIST_LDS * GL_WAVE];
-  const int s = blockIdx.x, l = threadIdx.x;
+  // (neighbouring slices on one XCD: rows that share cells share an L2)
+  const int s = xcd_chunk_remap(blockIdx.x, gridDim.x, GL_XCD_CHUNK), l = threadIdx.x;
   const int64_t r = (int64_t)s * GL_WAVE + l;
   const int64_t base = slice_ptr[s], cbase = cslice_ptr[s];
   const int len = (int)((slice_ptr[s + 1] - base) >> 6), clen = (int)((cslice_ptr[s + 1] - cbase) >> 6);

@@ -21,7 +21,9 @@
  *   - all floating point is IEEE fp64.
  *
  * Environment variables read by the library (everything else is a glims_options field):
- *   GLIMS_VERBOSE        any value: timing lines of the set-up phases on stderr
+ *   GLIMS_VERBOSE        any value: timing lines of the set-up phases and the solver's one-off decisions (preconditioner,
+ *                        spectral interval of the dot-free solves, solves taken back) on stderr
+ *   GLIMS_VERBOSE_CHEB   any value: one line per dot-free RD solve (residual before / after, tolerance, passes)
  *   GLIMS_HOST_THREADS   OpenMP team of the host-side symbolic phase (default: the CPUs this process may use,
  *                        divided by the ranks on the host)
  *   GLIMS_HOST_SYMBOLIC  TEST HOOK: glims_create runs the host (OpenMP) implementation of the symbolic phase instead of
