@@ -55,3 +55,32 @@ def test_structured_mesh_partition_is_unchanged_in_quality_and_plans_stay_consis
             sent = other.global_ids[other.send_idx[other.send_ptr[j]:other.send_ptr[j + 1]]]
             lo = p.n_own + int(p.recv_count[:k].sum())
             assert np.array_equal(sent, p.global_ids[lo:lo + int(p.recv_count[k])])
+
+
+def test_rcb_parts_are_boxes_of_equal_work_for_any_rank_count():
+    """Recursive coordinate bisection (the default since round 5): on an unstructured mesh and for rank counts that are no powers
+    of two every part is the node set inside an axis-aligned box (the parts' bounding boxes overlap in no node), work is
+    balanced to a few per cent, and the halo (ghost nodes per rank) is no larger than with contiguous Morton ranges."""
+    from glimslib_amd.partition import build_local_part
+    w = workloads.config_unstructured(40000)
+    pts, cells = w.mesh.points, w.mesh.cells
+    n = len(pts)
+    corners = np.bincount(cells.ravel(), minlength=n) + 1.0
+    for parts in (3, 5, 8):
+        own_rcb = node_owners(pts, parts, cells)                       # method='rcb' is the default
+        own_mor = node_owners(pts, parts, cells, method='morton')
+        assert np.bincount(own_rcb, minlength=parts).min() > 0
+        lo = np.array([pts[own_rcb == r].min(axis=0) for r in range(parts)])
+        hi = np.array([pts[own_rcb == r].max(axis=0) for r in range(parts)])
+        for r in range(parts):                                         # no node of another part inside part r's bounding box
+            inside = ((pts >= lo[r]) & (pts <= hi[r])).all(axis=1)
+            assert (own_rcb[inside] == r).all(), "part %d of %d is not a box" % (r, parts)
+        work = np.array([corners[own_rcb == r].sum() for r in range(parts)])
+        assert work.max() / work.mean() - 1.0 < 0.03
+        ghosts = {}
+        for name, own in (("rcb", own_rcb), ("morton", own_mor)):
+            g = [build_local_part(pts, cells, own, r, parts) for r in range(parts)]
+            ghosts[name] = (max(p.n_local - p.n_own for p in g), max(len(p.peer_rank) for p in g))
+        print("%d parts: largest halo %d ghosts / %d peers (rcb) against %d / %d (morton ranges)" %
+              (parts, ghosts["rcb"][0], ghosts["rcb"][1], ghosts["morton"][0], ghosts["morton"][1]))
+        assert ghosts["rcb"][0] <= 1.1 * ghosts["morton"][0]
