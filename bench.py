@@ -435,6 +435,8 @@ def main():
     ap.add_argument("--fp32-jacobian", type=int, default=0,
                     help="1: GLIMS_FLAG_FP32_JACOBIAN (study runs only; the line then says dtype f64/f32-jacobian)")
     ap.add_argument("--warm-start", type=int, default=None, help="override GLIMS_FLAG_WARM_START (tuning runs only)")
+    ap.add_argument("--stream-policy", type=int, default=None, help="glims_options.stream_policy: 1 non-temporal, 2 cached (A/B runs)")
+    ap.add_argument("--rd-linear", type=int, default=None, help="glims_options.rd_linear: 1 PCG, 2 Chebyshev (A/B runs)")
     ap.add_argument("--fixed-forcing", type=int, default=0,
                     help="1: GLIMS_FLAG_FIXED_FORCING, cg_rtol for every linear solve (A/B against the default forcing that "
                          "follows the quadratic remainder from a step's second solve on)")
@@ -540,6 +542,10 @@ def main():
         extra["check_every"] = args.check_every
     if args.newton_rtol is not None:
         extra["newton_rtol"] = args.newton_rtol
+    if args.stream_policy is not None:
+        extra["stream_policy"] = args.stream_policy
+    if args.rd_linear is not None:
+        extra["rd_linear"] = args.rd_linear
     flags = FLAG_EXTRAPOLATE_GUESS if args.extrapolate else h.options.flags
     if args.warm_start is not None:
         flags = (flags | 2) if args.warm_start else (flags & ~2)
@@ -725,6 +731,8 @@ def main():
             if n_post:
                 a_status |= h.step(n_post)
             c_alt = h.get_state(want_u=False)[0]
+            log("[bench] alt fp32 Jacobian storage: sum(c) %r vs default %r, max |diff| %.3e" %
+                (float(c_alt.sum()), float(c_ref.sum()), float(np.abs(c_alt - c_ref).max())))
             alt = {"fp32_jacobian_storage": {
                 "ms_per_step": 1e3 * ta / args.steps, "value": n_global * args.steps / ta, "solver_status": int(a_status),
                 "newton_its_per_step": sa['newton_its'] / args.steps, "cg_its_per_step": sa['cg_its'] / args.steps,
