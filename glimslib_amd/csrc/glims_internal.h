@@ -634,7 +634,8 @@ void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* s
 void gl_launch_cheb(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* slice_list, const double* vals,
                     const float* vals32, const double* d_in, double* d_out, double* r, const double* dinv, double* delta,
                     double* x, const uint8_t* fixed, double c1, double c2, int k, int m_host, const int* plan, int want_res,
-                    const PackMap& pm, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+                    const PackMap& pm, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, int shift = 0,
+                    double* nrm = nullptr);
 void gl_launch_spmv_block(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* slice_list, const double* x,
                           double* y, const uint8_t* fixed, const double* r, double* partials, int partial_off,
                           const int* done, bool single_precision_operator = false);

@@ -987,11 +987,16 @@ __global__ __launch_bounds__(256) void k_cheb(int n_launch, int chunk, const int
                                                const double* __restrict__ dinv, double* __restrict__ delta,
                                                double* __restrict__ x, const uint8_t* __restrict__ fixed, double c1,
                                                double c2, int k, int m_host, const int* __restrict__ plan, int want_res,
-                                               const PackMap pm, int remap) {
+                                               const PackMap pm, int remap, int shift, double* __restrict__ nrm) {
+  // shift = 1: the solve started from a non-zero guess u that serves as direction 0 (d_in of pass 1 = u, delta = u): pass 1 turns
+  // r into the residual of that guess and takes the first Chebyshev direction from it -- the product A u the warm start needs
+  // anyway IS this pass, no separate SpMV and no start kernel; every count moves by one.  nrm (pass 1 of such a solve): the
+  // partial sums of |r|^2 per block, from which the device chooses the iteration count.
   const int m = plan ? *plan : m_host;
-  const int last = want_res ? m : m - 1;
+  const int last = (want_res ? m : m - 1) + shift;
   if (k > last) return;
-  const bool direction = !want_res || k < m, fin = k == last;
+  const bool direction = !want_res || k < m + shift, fin = k == last;
+  double pn = 0.0;
   const int b = remap > 1 ? xcd_chunk_remap(blockIdx.x, gridDim.x, remap) : blockIdx.x;
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int s_end = min(n_launch, (b + 1) * chunk);
@@ -1014,6 +1019,7 @@ __global__ __launch_bounds__(256) void k_cheb(int n_launch, int chunk, const int
     if (fixed && fixed[row]) acc = 0.0;   // constrained rows: r = 0 there, so every direction stays 0
     const double rn = r[row] - acc;
     r[row] = rn;
+    pn += rn * rn;
     double dl = delta[row];
     if (direction) {
       const double dn = c1 * dd + c2 * dinv[row] * rn;
@@ -1029,6 +1035,7 @@ __global__ __launch_bounds__(256) void k_cheb(int n_launch, int chunk, const int
       x[row] += dl;
     }
   }
+  if (nrm) spmv_dot_partial(pn, b, nrm, 0);
 }
 
 // Pipelined block SpMV: KB block entries per batch -- all column loads, then all KB*BS*BS value loads (non-temporal:
@@ -1660,7 +1667,7 @@ void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* s
 void gl_launch_cheb(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* slice_list, const double* vals,
                     const float* vals32, const double* d_in, double* d_out, double* r, const double* dinv, double* delta,
                     double* x, const uint8_t* fixed, double c1, double c2, int k, int m_host, const int* plan, int want_res,
-                    const PackMap& pm, hipEvent_t ev0, hipEvent_t ev1) {
+                    const PackMap& pm, hipEvent_t ev0, hipEvent_t ev1, int shift, double* nrm) {
   if (n_launch <= 0) return;
   const DevPattern& p = h->pat;
   const int grid = gl_spmv_grid(n_launch);
@@ -1673,12 +1680,12 @@ void gl_launch_cheb(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* s
       hipExtLaunchKernelGGL((k_cheb<UNR, NT, CIDX, VT>), dim3(grid), dim3(256), 0, st, ev0, ev1, 0, n_launch, chunk,  \
                             slice_list, h->n_own, p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, p.win_ok.p,     \
                             p.diag_k.p, p.rlen.p, VPTR, d_in, d_out, r, dinv, delta, x, fixed, c1, c2, k, m_host,    \
-                            plan, want_res, pm, remap);                                                              \
+                            plan, want_res, pm, remap, shift, nrm);                                                  \
     else                                                                                                             \
       hipLaunchKernelGGL((k_cheb<UNR, NT, CIDX, VT>), dim3(grid), dim3(256), 0, st, n_launch, chunk, slice_list,      \
                          h->n_own, p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, p.win_ok.p, p.diag_k.p,        \
                          p.rlen.p, VPTR, d_in, d_out, r, dinv, delta, x, fixed, c1, c2, k, m_host, plan, want_res,   \
-                         pm, remap);                                                                                 \
+                         pm, remap, shift, nrm);                                                                     \
   } while (0)
 #define GL_CH3(UNR, CIDX, VT, VPTR)                                                                                  \
   do {                                                                                                               \

@@ -486,12 +486,14 @@ __global__ void k_extrapolate(int64_t n, double* __restrict__ c, double* __restr
 // ms; C3 17.95 -> 16.55, 1.60 -> 1.53 ms; brain-like mesh 29.65 -> 28.65.  A quadratic extrapolation (three increments) buys
 // C3 another 1.6 iterations and costs C4 0.1 ms: not taken.
 __global__ void k_ws_delta(int64_t n, const double* __restrict__ c, double* __restrict__ c_old, double* __restrict__ u,
-                           double* __restrict__ du, int second_order) {
+                           double* __restrict__ du, int second_order, double* __restrict__ delta) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double ci = c[i];
   const double d1 = ci - c_old[i];
-  u[i] = second_order ? 2.0 * d1 - du[i] : d1;
+  const double ui = second_order ? 2.0 * d1 - du[i] : d1;
+  u[i] = ui;
+  if (delta) delta[i] = ui;   // dot-free solve: the guess is direction 0 of the solve, the accumulated correction starts as u
   du[i] = d1;
   c_old[i] = ci;
 }
@@ -972,12 +974,14 @@ __global__ __launch_bounds__(256) void k_cheb_start(int64_t n_own, double* __res
 // iterate by pass m - 1), at most m_max; 0 = the warm start alone meets the tolerance.  Left in plan[0] for the launches and
 // in the Krylov info slot for the host's statistics (travels with the next decision mail).
 __global__ void k_cheb_plan(const double* __restrict__ red, double tol2, double inv_acosh_sigma, int m_min, int m_max,
-                            int* __restrict__ plan, double* __restrict__ info) {
+                            int m_done, int* __restrict__ plan, double* __restrict__ info) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const double rr = red[0];
   int m = m_max;
   if (isfinite(rr)) {
-    if (rr <= tol2) m = 0;
+    // (m_done: the count when the tolerance is met already -- 0, or 2 for a solve whose first pass has run: the pass that adds
+    //  the correction to the iterate is still to come)
+    if (rr <= tol2) m = m_done;
     else {
       const double q = sqrt(rr / tol2);
       m = (int)ceil(log(q + sqrt(q * q - 1.0)) * inv_acosh_sigma);
@@ -1346,7 +1350,7 @@ struct ChebRun {
 // midpoint correction) -- `norm_in_partials` says where the start of the solve finds it: 0 = the start kernel computes it,
 // n > 0 = the caller has left n pairs (|r|^2, .) in h->partials.
 static ChebRun cheb_solve(glims_ctx* h, const CgVecs& v, double tol_abs, double r_norm, double r_bound, bool want_res,
-                          const double* ws_w, const double* ws_u, int norm_in_partials) {
+                          const double* warm_u) {
   const DevPattern& p = h->pat;
   const bool split = h->world > 1 && h->n_peers > 0;
   const int64_t n = h->n_own;
@@ -1363,7 +1367,7 @@ static ChebRun cheb_solve(glims_ctx* h, const CgVecs& v, double tol_abs, double 
     pm.sendbuf = h->sendbuf.p;
   }
   ChebRun run;
-  run.planned = !(r_norm > 0.0);
+  run.planned = warm_u != nullptr;   // (then |r| on entry of the Chebyshev recurrence is only known to the device)
   const int m_min = want_res ? 1 : 2;
   int m = 0;
   if (run.planned) {
@@ -1376,37 +1380,47 @@ static ChebRun cheb_solve(glims_ctx* h, const CgVecs& v, double tol_abs, double 
   else if (r_norm > tol_abs) m = std::min(GL_CHEB_MAX, std::max(m_min, rec.iterations(tol_abs / r_norm)));
   const unsigned g = grid_for(n);
   double* info_dev = h->scal.p + 2 * SC_COUNT;
-  const bool start_norm = run.planned && norm_in_partials == 0;
-  hipLaunchKernelGGL(k_cheb_start, dim3(g), dim3(256), 0, h->st, n, v.r, ws_w, v.x, ws_u, v.dinv, 1.0 / rec.theta, v.p,
-                     h->cheb_delta.p, start_norm ? h->partials.p : (double*)nullptr, pm);
-  GL_HIP(hipGetLastError());
-  if (run.planned) {
-    reduce_partials(h, start_norm ? (int)g : norm_in_partials, 2, nullptr);
-    allreduce_sum(h, h->red.p, 2);
+  // Warm-started solve (warm_u = the predicted increment u, ghosts valid; cheb_delta = u on entry): u is direction 0.  Pass 1
+  // computes r - A u -- the product the warm start needs anyway -- takes the first Chebyshev direction from it and leaves
+  // the partial sums of |r|^2, from which the device chooses the count; no separate SpMV, no start kernel.
+  const int shift = warm_u ? 1 : 0;
+  double *d_in = v.p, *d_out = v.s;
+  if (warm_u) {
+    hipEvent_t* ev = h->timing(glims_ctx::TK_CHEB) ? h->pair(glims_ctx::TK_CHEB) : nullptr;
+    // (one launch over all slices: the ghosts of u are current, nothing to exchange; the payload of d_1 is packed for pass 2)
+    gl_launch_cheb(h, h->st, p.n_slices, nullptr, v.vals, v.vals32, warm_u, v.p, v.r, v.dinv, h->cheb_delta.p, v.x, v.fixed,
+                   0.0, 1.0 / rec.theta, 1, GL_CHEB_MAX + 8, nullptr, want_res ? 1 : 0, pm, ev ? ev[0] : nullptr,
+                   ev ? ev[1] : nullptr, shift, h->partials.p);
+    reduce_partials(h, gl_spmv_grid(p.n_slices), 1, nullptr);
+    allreduce_sum(h, h->red.p, 1);
     hipLaunchKernelGGL(k_cheb_plan, dim3(1), dim3(1), 0, h->st, (const double*)h->red.p, tol_abs * tol_abs,
-                       rec.inv_acosh_sigma(), m_min, m, h->cheb_plan.p, info_dev);
+                       rec.inv_acosh_sigma(), 2, std::max(2, m), 2, h->cheb_plan.p, info_dev);
+    GL_HIP(hipGetLastError());
+    m = std::max(2, m);
+  } else {
+    hipLaunchKernelGGL(k_cheb_start, dim3(g), dim3(256), 0, h->st, n, v.r, (const double*)nullptr, v.x, (const double*)nullptr,
+                       v.dinv, 1.0 / rec.theta, v.p, h->cheb_delta.p, (double*)nullptr, pm);
     GL_HIP(hipGetLastError());
   }
-  const int last = want_res ? m : m - 1;
+  const int last = (want_res ? m : m - 1) + shift;
   run.passes = std::max(0, last);
-  double *d_in = v.p, *d_out = v.s;
-  for (int k = 1; k <= last; ++k) {
+  for (int k = 1 + shift; k <= last; ++k) {
     double c1 = 0.0, c2 = 0.0;
-    if (!want_res || k < m) rec.next(&c1, &c2);
+    if (!want_res || k < m + shift) rec.next(&c1, &c2);
     const int* plan = run.planned ? h->cheb_plan.p : nullptr;
     hipEvent_t* ev = h->timing(glims_ctx::TK_CHEB) ? h->pair(glims_ctx::TK_CHEB) : nullptr;
     if (!split) {
       gl_launch_cheb(h, h->st, p.n_slices, nullptr, v.vals, v.vals32, d_in, d_out, v.r, v.dinv, h->cheb_delta.p, v.x,
-                     v.fixed, c1, c2, k, m, plan, want_res ? 1 : 0, pm, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr);
+                     v.fixed, c1, c2, k, m, plan, want_res ? 1 : 0, pm, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr, shift);
     } else {
       // the ghosts of d_in travel (payload packed by the kernel that produced it) while the slices without ghost columns run
       halo_start(h, d_in, 1, /*prepacked=*/true);
       gl_launch_cheb(h, h->st, p.n_interior, p.interior_slices.p, v.vals, v.vals32, d_in, d_out, v.r, v.dinv,
                      h->cheb_delta.p, v.x, v.fixed, c1, c2, k, m, plan, want_res ? 1 : 0, pm, ev ? ev[0] : nullptr,
-                     ev ? ev[1] : nullptr);
+                     ev ? ev[1] : nullptr, shift);
       halo_finish(h);
       gl_launch_cheb(h, h->st, p.n_boundary, p.boundary_slices.p, v.vals, v.vals32, d_in, d_out, v.r, v.dinv,
-                     h->cheb_delta.p, v.x, v.fixed, c1, c2, k, m, plan, want_res ? 1 : 0, pm);
+                     h->cheb_delta.p, v.x, v.fixed, c1, c2, k, m, plan, want_res ? 1 : 0, pm, nullptr, nullptr, shift);
     }
     std::swap(d_in, d_out);
   }
@@ -1758,19 +1772,23 @@ int gl_step(glims_ctx* h, int n_steps) {
         // initial guess of the first linear solve = the increment predicted from the previous steps' (k_ws_delta): same linear
         // system, same solution, the Krylov iteration just starts closer.  One SpMV with the already assembled A(c^n).
         h->ws_du.alloc((size_t)h->n_nodes);
+        // (dot-free solve: the guess u becomes direction 0 of the solve -- the product A u is then the solve's first operator
+        //  pass and the correction accumulates from u: cheb_solve, warm_u)
+        ws_fused = use_cheb && h->have_c_old;
+        if (ws_fused) h->cheb_delta.alloc((size_t)h->n_nodes);
         hipLaunchKernelGGL(k_ws_delta, dim3(grid_exact(h->n_nodes)), dim3(256), 0, h->st, h->n_nodes, h->c.p,
-                           h->c_old.p, h->cg_u.p, h->ws_du.p, (h->have_c_old && h->ws_depth >= 1) ? 1 : 0);
+                           h->c_old.p, h->cg_u.p, h->ws_du.p, (h->have_c_old && h->ws_depth >= 1) ? 1 : 0,
+                           ws_fused ? h->cheb_delta.p : (double*)nullptr);
         h->ws_depth = h->have_c_old ? 1 : 0;   // (ws_du holds a real increment from the second warm-started step on)
         if (h->have_c_old) {
-          gl_launch_spmv(h, h->st, p.n_slices, nullptr, h->vA.p, h->cg_u.p, h->cg_w.p,
-                         h->have_fixed_c ? h->fixed_c.p : nullptr, nullptr, nullptr, nullptr, 0, nullptr,
-                         h->jac32 ? h->vA32.p : nullptr);
           warm = true;
-          // (dot-free solve without the midpoint correction: its start kernel applies the warm start and measures |r|)
-          ws_fused = use_cheb && !midpoint;
-          if (!ws_fused)
-          hipLaunchKernelGGL(k_ws_apply, dim3(grid_exact(n)), dim3(256), 0, h->st, n, h->cg_r.p, h->cg_w.p, h->c.p,
-                             h->cg_u.p);
+          if (!ws_fused) {
+            gl_launch_spmv(h, h->st, p.n_slices, nullptr, h->vA.p, h->cg_u.p, h->cg_w.p,
+                           h->have_fixed_c ? h->fixed_c.p : nullptr, nullptr, nullptr, nullptr, 0, nullptr,
+                           h->jac32 ? h->vA32.p : nullptr);
+            hipLaunchKernelGGL(k_ws_apply, dim3(grid_exact(n)), dim3(256), 0, h->st, n, h->cg_r.p, h->cg_w.p, h->c.p,
+                               h->cg_u.p);
+          }
           // Midpoint correction of the step's first right-hand side.  For the exactly quadratic residual the whole step
           // delta* = c* - c_0 satisfies  A(c_0 + delta* / 2) delta* = -R(c_0)  -- the midpoint Jacobian solves the step in
           // ONE linear solve -- i.e.  A(c_0) delta* = -R(c_0) - dt N(delta*) delta*.  With delta* predicted by the previous
@@ -1802,11 +1820,9 @@ int gl_step(glims_ctx* h, int n_steps) {
       bool deferred = false;
       ChebRun crun;
       if (use_cheb) {
-        // |r| on entry: known to the host unless a warm start (and the midpoint correction) has just changed r -- then the
-        // count is chosen on the device from the norm the start of the solve measures (midpoint: the correction's pass has
-        // left the partial sums of |r|^2 already)
-        crun = cheb_solve(h, v, tol_lin, warm ? 0.0 : nr, nr, cheap_next, ws_fused ? h->cg_w.p : nullptr,
-                          ws_fused ? h->cg_u.p : nullptr, (warm && midpoint) ? gl_rd_grid(h) : 0);
+        // |r| on entry: known to the host unless the solve starts from the warm-start guess -- then the count is chosen on the
+        // device from the norm its first pass measures
+        crun = cheb_solve(h, v, tol_lin, nr, nr, cheap_next, ws_fused ? h->cg_u.p : (const double*)nullptr);
         deferred = crun.planned;
         if (!deferred) {
           h->stats.cg_its += crun.passes;
@@ -1852,7 +1868,7 @@ int gl_step(glims_ctx* h, int n_steps) {
       if (deferred && use_cheb) {   // the count the device chose for the warm-started solve
         const int64_t m_dev = (int64_t)km.info[0];
         cb.m_hint = (int)std::max<int64_t>(1, m_dev);
-        const int64_t passes = std::max<int64_t>(0, std::min<int64_t>(crun.passes, cheap ? m_dev : m_dev - 1));
+        const int64_t passes = std::max<int64_t>(0, std::min<int64_t>(crun.passes, (cheap ? m_dev : m_dev - 1) + 1));
         h->stats.cg_its += passes;
         h->stats.cheb_its += passes;
         h->stats.last_cg_res = tol_lin;
