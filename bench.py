@@ -254,9 +254,9 @@ def alt_c5(Handle, device, steps=10, warmup=10):
 
 def cheb_bytes(nnz, n_rows):
     """Algorithmic bytes of one pass of the dot-free Krylov iteration (k_cheb): the CSR SpMV's 12 nnz + 4 rows + 8 rows of
-    gathered direction, plus the recurrence's vector work: r read + written, Dinv, delta read + written, new direction
-    (48 B per row) = 12 nnz + 60 rows."""
-    return 12 * int(nnz) + 60 * int(n_rows)
+    gathered iterate, plus the recurrence's vector work: right-hand side, Dinv, direction read + written, new iterate
+    (40 B per row) = 12 nnz + 52 rows."""
+    return 12 * int(nnz) + 52 * int(n_rows)
 
 
 def load_pmc(st, candidates):
@@ -299,8 +299,8 @@ def kernel_list(s, k, steps, step_ms, k_steps, unr, pmc=None):
                     "achieved_real_GBps": None if tb is None else tb / (mean_us * 1e-6) / 1e9, "timed": where})
 
     where = "HIP events inside the %d timed steps" % steps
-    entry("k_cheb<%d, NT, 1, double>" % unr, "one pass of the dot-free Krylov iteration: r -= A d (SELL-64, 16-bit column codes) "
-          "with the Chebyshev recurrence in the epilogue (algorithmic bytes: 12 nnz + 60 rows)",
+    entry("k_cheb<%d, NT, 1, double>" % unr, "one pass of the dot-free Krylov iteration: t = b - A y (SELL-64, 16-bit column codes) "
+          "with the Chebyshev recurrence in the epilogue (algorithmic bytes: 12 nnz + 52 rows)",
           cheb_bytes(s['nnz'], s['n_rows']), s['ms_cheb_steps'], s['n_cheb_steps'], s['us_cheb_median'], steps, step_ms,
           where, "k_cheb")
     entry("k_spmv<1, %d, NT, 1, double>" % unr, "y = A(c) x, SELL-64 with 16-bit column codes, fused w.u partials (PCG solves of "
@@ -632,7 +632,7 @@ def main():
     # The step's dominant kernel is the operator pass of the Krylov iteration: k_cheb (dot-free Chebyshev iteration, the default
     # wherever the RD solves are Jacobi-preconditioned) or k_spmv<1,..> (PCG: learning steps, multigrid-preconditioned solves,
     # rd_linear = PCG).  Algorithmic bytes per launch = SURVEY 8(d)'s CSR figure 12 nnz + 20 rows for the SpMV, plus the
-    # recurrence's 40 B per row of vector traffic for k_cheb (cheb_bytes);
+    # recurrence's 32 B per row of extra vector traffic for k_cheb (cheb_bytes);
     # duration (a) inside the timed region: HIP events attached to every such launch of the steps (glims_options.time_kernels),
     # (b) after it: `spmv_reps` back-to-back launches of the plain SpMV (glims_apply).
     x = np.random.default_rng(0).standard_normal(h.n_nodes)
@@ -674,7 +674,7 @@ def main():
                 "achieved_real": None if traffic is None else traffic / t_op / 1e9,
                 "frac_real": None if traffic is None else traffic / t_op / 1e9 / HBM_PEAK_GBS,
                 "kernel": dom_name + (" (one pass of the dot-free Krylov iteration: SELL-64 operator pass, fp64 values, 16-bit "
-                                      "column codes, Chebyshev recurrence in the epilogue; algorithmic bytes 12 nnz + 60 rows)"
+                                      "column codes, Chebyshev recurrence in the epilogue; algorithmic bytes 12 nnz + 52 rows)"
                                       if cheb_dominant else
                                       " (SELL-64, fp64 values, columns streamed as 16-bit window codes; algorithmic bytes "
                                       "still count 4-byte CSR columns: 12 nnz + 20 rows)"),

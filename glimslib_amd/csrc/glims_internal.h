@@ -528,7 +528,8 @@ struct glims_ctx {
   } cheb;
   double cheb_test_hi = 1.0;               // TEST HOOK GLIMS_CHEB_TEST_SCALE_HI (read by glims_create): factor on the measured upper end
   dvec<double> cg_hist;                    // [2 * GL_CG_HIST] (alpha_k, beta_k) of the running PCG solve
-  dvec<double> cheb_delta;                 // accumulated correction of the running Chebyshev solve [n_nodes]
+  dvec<double> cheb_delta;                 // the correction the last Chebyshev solve added to the iterate [n_nodes] (take-back)
+  dvec<double> cheb_dir;                   // the running solve's direction d [n_nodes]
   dvec<int> cheb_plan;                     // [1] iteration count computed on the device (a step's first, warm-started solve)
   dvec<float> vKel32;                      // single-precision copy of K_el (inner solves of the elasticity solver)
   // vectors (internal numbering; length n_nodes unless noted)
@@ -632,9 +633,9 @@ void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* s
                     double* partials, int partial_off, const int* done, const float* vals32 = nullptr,
                     hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 void gl_launch_cheb(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* slice_list, const double* vals,
-                    const float* vals32, const double* d_in, double* d_out, double* r, const double* dinv, double* delta,
-                    double* x, const uint8_t* fixed, double c1, double c2, int k, int m_host, const int* plan, int want_res,
-                    const PackMap& pm, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, int shift = 0,
+                    const float* vals32, const double* y_in, double* y_out, double* b, const double* dinv, double* dvec,
+                    double* ylast, double* x, const uint8_t* fixed, double c1, double c2, int k, int m_host, const int* plan,
+                    int want_res, const PackMap& pm, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, int shift = 0,
                     double* nrm = nullptr);
 void gl_launch_spmv_block(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* slice_list, const double* x,
                           double* y, const uint8_t* fixed, const double* r, double* partials, int partial_off,

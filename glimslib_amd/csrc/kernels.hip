@@ -964,78 +964,80 @@ __global__ __launch_bounds__(256) void k_spmv(int n_launch, int chunk, const int
   if (DOTS) spmv_dot_partial(pd, b, partials, partial_off);
 }
 
-// Dot-free Krylov iteration (round 5): ONE launch per iteration.  Step k of the Chebyshev semi-iteration for A x = b on the
-// spectrum [lmin, lmax] of Dinv A, in residual form, with the vector work in the operator pass's epilogue -- the row owner has
-// (A d)_row in registers, and d_in[row] arrives with the gather of the diagonal entry:
-//     r <- r - A d_in;   d_out = c1 d_in + c2 Dinv r;   delta += d_out                      (launches 1 .. last)
-// No dot product, no reduction kernel, no all-reduce: the iteration count m follows from the interval and the wanted
-// reduction (solver.hip, cheb_solve), either known to the host (m_host) or, for a step's first solve, computed on the device
-// from the norm of the warm-started residual (*plan).  The accumulated correction delta = d_0 + .. + d_(m-1) is added to
-// the Newton iterate x by the LAST launch, so that a solve whose interval turns out wrong can be taken back (x -= delta).
-//   want_res = 1: m operator passes, the last one (k = m) only updates r -- r is then the residual of the final iterate, which
-//                 the quadratic-structure evaluation of the Newton residual builds on;
-//   want_res = 0: m - 1 passes (a sweep re-evaluates the residual anyway), the last one (k = m - 1) computes d_(m-1).
-// d_in is gathered (ghosts included), d_out written by the row owner: two buffers that change roles every launch.
+// Dot-free Krylov iteration (round 5): ONE launch per iteration.  Step k of the Chebyshev semi-iteration for A y = b on the
+// spectrum [lmin, lmax] of Dinv A, with the vector work in the operator pass's epilogue -- the row owner has (A y)_row in
+// registers, and y_in[row] arrives with the gather of the diagonal entry:
+//     t = b - A y_in;   d = c1 d + c2 Dinv t;   y_out = y_in + d                              (passes 1 .. last)
+// The residual is recomputed from the iterate in every pass (no recurrence drift), the direction d is read and written by its
+// row only, so the pass moves 40 B of vectors per row (b, Dinv, d twice, y_out) next to the operator.  No dot product, no
+// reduction kernel, no all-reduce: the iteration count m follows from the interval and the wanted reduction (solver.hip,
+// cheb_solve), either known to the host (m_host) or, for a step's first solve, computed on the device from the norm of the
+// warm-started residual (*plan).  The LAST pass adds the correction y to the Newton iterate x and keeps a copy (ylast), so that
+// a solve whose interval turns out wrong can be taken back (x -= ylast).
+//   want_res = 1: one more pass (k = last) computes only t = b - A y and stores it in b -- the residual of the final iterate,
+//                 which the quadratic-structure evaluation of the Newton residual builds on;
+//   want_res = 0: a sweep re-evaluates the residual anyway; the last pass is a direction pass.
+// shift = 1: the solve started from a non-zero guess u that is the iterate of pass 1 (y_in = u, c1 = 0): the product A u the
+// warm start needs anyway IS this pass, no separate SpMV and no start kernel; every count moves by one.  nrm (pass 1 of such a
+// solve): the partial sums of |t|^2 per block, from which the device chooses the iteration count.
+// y_in is gathered (ghosts included), y_out written by the row owner: two buffers that change roles every launch.
 template <int UNR, int NT, int CIDX, class VT>
 __global__ __launch_bounds__(256) void k_cheb(int n_launch, int chunk, const int32_t* __restrict__ slice_list,
                                                int64_t n_own, const int64_t* __restrict__ slice_ptr,
                                                const int32_t* __restrict__ cols, const uint16_t* __restrict__ cols16,
                                                const int32_t* __restrict__ win_base, const uint8_t* __restrict__ win_ok,
                                                const uint8_t* __restrict__ diag_k, const uint8_t* __restrict__ rlen,
-                                               const VT* __restrict__ vals, const double* __restrict__ d_in,
-                                               double* __restrict__ d_out, double* __restrict__ r,
-                                               const double* __restrict__ dinv, double* __restrict__ delta,
-                                               double* __restrict__ x, const uint8_t* __restrict__ fixed, double c1,
-                                               double c2, int k, int m_host, const int* __restrict__ plan, int want_res,
-                                               const PackMap pm, int remap, int shift, double* __restrict__ nrm) {
-  // shift = 1: the solve started from a non-zero guess u that serves as direction 0 (d_in of pass 1 = u, delta = u): pass 1 turns
-  // r into the residual of that guess and takes the first Chebyshev direction from it -- the product A u the warm start needs
-  // anyway IS this pass, no separate SpMV and no start kernel; every count moves by one.  nrm (pass 1 of such a solve): the
-  // partial sums of |r|^2 per block, from which the device chooses the iteration count.
+                                               const VT* __restrict__ vals, const double* __restrict__ y_in,
+                                               double* __restrict__ y_out, double* __restrict__ b,
+                                               const double* __restrict__ dinv, double* __restrict__ dvec,
+                                               double* __restrict__ ylast, double* __restrict__ x,
+                                               const uint8_t* __restrict__ fixed, double c1, double c2, int k, int m_host,
+                                               const int* __restrict__ plan, int want_res, const PackMap pm, int remap,
+                                               int shift, double* __restrict__ nrm) {
   const int m = plan ? *plan : m_host;
   const int last = (want_res ? m : m - 1) + shift;
   if (k > last) return;
   const bool direction = !want_res || k < m + shift, fin = k == last;
   double pn = 0.0;
-  const int b = remap > 1 ? xcd_chunk_remap(blockIdx.x, gridDim.x, remap) : blockIdx.x;
+  const int blk = remap > 1 ? xcd_chunk_remap(blockIdx.x, gridDim.x, remap) : blockIdx.x;
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int s_end = min(n_launch, (b + 1) * chunk);
-  for (int si = b * chunk + wid; si < s_end; si += 4) {
+  const int s_end = min(n_launch, (blk + 1) * chunk);
+  for (int si = blk * chunk + wid; si < s_end; si += 4) {
     const int s = slice_list ? slice_list[si] : si;
     const int64_t row = (int64_t)s * GL_WAVE + lane;
     const int64_t base = slice_ptr[s];
     const int len = (int)((slice_ptr[s + 1] - base) >> 6);
     const VT* v = vals + base + lane;
-    double acc, dd = 0.0;
+    double acc, yn = 0.0;
     const int dk = (int)diag_k[row];
     const int rl = (int)rlen[row];
     if (CIDX && win_ok[s]) {   // wave-uniform
       const int32_t wb = win_base[(int64_t)s * GL_N_WIN + (lane & (GL_N_WIN - 1))];
-      acc = spmv_row<1, UNR, NT, 1, VT>(nullptr, cols16 + base + lane, wb, v, d_in, len, rl, dk, dd);
+      acc = spmv_row<1, UNR, NT, 1, VT>(nullptr, cols16 + base + lane, wb, v, y_in, len, rl, dk, yn);
     } else {
-      acc = spmv_row<0, UNR, NT, 1, VT>(cols + base + lane, nullptr, 0, v, d_in, len, rl, dk, dd);
+      acc = spmv_row<0, UNR, NT, 1, VT>(cols + base + lane, nullptr, 0, v, y_in, len, rl, dk, yn);
     }
     if (row >= n_own) continue;
-    if (fixed && fixed[row]) acc = 0.0;   // constrained rows: r = 0 there, so every direction stays 0
-    const double rn = r[row] - acc;
-    r[row] = rn;
-    pn += rn * rn;
-    double dl = delta[row];
+    if (fixed && fixed[row]) acc = 0.0;   // constrained rows: b = 0 there, so every direction and the iterate stay 0
+    const double t = b[row] - acc;
+    pn += t * t;
     if (direction) {
-      const double dn = c1 * dd + c2 * dinv[row] * rn;
-      dl += dn;
+      const double dn = (c1 != 0.0 ? c1 * dvec[row] : 0.0) + c2 * dinv[row] * t;
+      yn += dn;
       if (!fin) {
-        d_out[row] = dn;
-        delta[row] = dl;
-        if (pm.ref) pack_row<1>(pm, row, &dn);
+        dvec[row] = dn;
+        y_out[row] = yn;
+        if (pm.ref) pack_row<1>(pm, row, &yn);
       }
+    } else {
+      b[row] = t;   // the residual of the final iterate (want_res)
     }
     if (fin) {
-      delta[row] = dl;
-      x[row] += dl;
+      ylast[row] = yn;
+      x[row] += yn;
     }
   }
-  if (nrm) spmv_dot_partial(pn, b, nrm, 0);
+  if (nrm) spmv_dot_partial(pn, blk, nrm, 0);
 }
 
 // Pipelined block SpMV: KB block entries per batch -- all column loads, then all KB*BS*BS value loads (non-temporal:
@@ -1665,9 +1667,9 @@ void gl_launch_spmv(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* s
 // One launch of the dot-free Krylov iteration (k_cheb) over a slice subset; same launch shape, stream policy and column-code
 // choice as the SpMV it replaces.
 void gl_launch_cheb(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* slice_list, const double* vals,
-                    const float* vals32, const double* d_in, double* d_out, double* r, const double* dinv, double* delta,
-                    double* x, const uint8_t* fixed, double c1, double c2, int k, int m_host, const int* plan, int want_res,
-                    const PackMap& pm, hipEvent_t ev0, hipEvent_t ev1, int shift, double* nrm) {
+                    const float* vals32, const double* y_in, double* y_out, double* b, const double* dinv, double* dvec,
+                    double* ylast, double* x, const uint8_t* fixed, double c1, double c2, int k, int m_host, const int* plan,
+                    int want_res, const PackMap& pm, hipEvent_t ev0, hipEvent_t ev1, int shift, double* nrm) {
   if (n_launch <= 0) return;
   const DevPattern& p = h->pat;
   const int grid = gl_spmv_grid(n_launch);
@@ -1679,13 +1681,13 @@ void gl_launch_cheb(glims_ctx* h, hipStream_t st, int n_launch, const int32_t* s
     if (ev0 || ev1)                                                                                                  \
       hipExtLaunchKernelGGL((k_cheb<UNR, NT, CIDX, VT>), dim3(grid), dim3(256), 0, st, ev0, ev1, 0, n_launch, chunk,  \
                             slice_list, h->n_own, p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, p.win_ok.p,     \
-                            p.diag_k.p, p.rlen.p, VPTR, d_in, d_out, r, dinv, delta, x, fixed, c1, c2, k, m_host,    \
-                            plan, want_res, pm, remap, shift, nrm);                                                  \
+                            p.diag_k.p, p.rlen.p, VPTR, y_in, y_out, b, dinv, dvec, ylast, x, fixed, c1, c2, k,      \
+                            m_host, plan, want_res, pm, remap, shift, nrm);                                          \
     else                                                                                                             \
       hipLaunchKernelGGL((k_cheb<UNR, NT, CIDX, VT>), dim3(grid), dim3(256), 0, st, n_launch, chunk, slice_list,      \
                          h->n_own, p.slice_ptr.p, p.cols.p, p.cols16.p, p.win_base.p, p.win_ok.p, p.diag_k.p,        \
-                         p.rlen.p, VPTR, d_in, d_out, r, dinv, delta, x, fixed, c1, c2, k, m_host, plan, want_res,   \
-                         pm, remap, shift, nrm);                                                                     \
+                         p.rlen.p, VPTR, y_in, y_out, b, dinv, dvec, ylast, x, fixed, c1, c2, k, m_host, plan,       \
+                         want_res, pm, remap, shift, nrm);                                                           \
   } while (0)
 #define GL_CH3(UNR, CIDX, VT, VPTR)                                                                                  \
   do {                                                                                                               \

@@ -486,14 +486,13 @@ __global__ void k_extrapolate(int64_t n, double* __restrict__ c, double* __restr
 // ms; C3 17.95 -> 16.55, 1.60 -> 1.53 ms; brain-like mesh 29.65 -> 28.65.  A quadratic extrapolation (three increments) buys
 // C3 another 1.6 iterations and costs C4 0.1 ms: not taken.
 __global__ void k_ws_delta(int64_t n, const double* __restrict__ c, double* __restrict__ c_old, double* __restrict__ u,
-                           double* __restrict__ du, int second_order, double* __restrict__ delta) {
+                           double* __restrict__ du, int second_order) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double ci = c[i];
   const double d1 = ci - c_old[i];
   const double ui = second_order ? 2.0 * d1 - du[i] : d1;
   u[i] = ui;
-  if (delta) delta[i] = ui;   // dot-free solve: the guess is direction 0 of the solve, the accumulated correction starts as u
   du[i] = d1;
   c_old[i] = ci;
 }
@@ -1344,17 +1343,18 @@ struct ChebRun {
   bool planned = false;  // the count is computed on the device; it arrives in the Krylov info of the next decision mail
 };
 
-// Solves A x = r for the correction of v.x (accumulated in cheb_delta, added to v.x by the last pass).  On entry v.r is the
-// residual at v.x -- or, with ws_w / ws_u, the residual BEFORE the warm start u is applied (r -= ws_w, x += ws_u happen in the
-// start kernel).  r_norm: |r| on entry if the host knows it (then the count is fixed here); <= 0: unknown (warm start,
-// midpoint correction) -- `norm_in_partials` says where the start of the solve finds it: 0 = the start kernel computes it,
-// n > 0 = the caller has left n pairs (|r|^2, .) in h->partials.
+// Solves A y = b (b = v.r, the Newton right-hand side at v.x) for the correction y of v.x: iterates in v.p / v.s (two buffers
+// that change roles every pass), direction in cheb_dir; the last pass adds y to v.x and keeps it in cheb_delta (take-back).
+// v.r is left untouched unless want_res, in which case the final pass turns it into the residual b - A y.
+// warm_u: the solve starts from this guess (the predicted increment, ghosts valid) instead of zero; the iteration count is then
+// chosen on the device from |b - A u| (r_bound bounds the launches), otherwise from r_norm = |b| here.
 static ChebRun cheb_solve(glims_ctx* h, const CgVecs& v, double tol_abs, double r_norm, double r_bound, bool want_res,
                           const double* warm_u) {
   const DevPattern& p = h->pat;
   const bool split = h->world > 1 && h->n_peers > 0;
   const int64_t n = h->n_own;
   h->cheb_delta.alloc((size_t)h->n_nodes);
+  h->cheb_dir.alloc((size_t)h->n_nodes);
   h->cheb_plan.alloc(1);
   double ia, ib;
   cheb_interval(h, tol_abs / std::max(r_norm > 0.0 ? r_norm : r_bound, tol_abs), &ia, &ib);
@@ -1380,17 +1380,17 @@ static ChebRun cheb_solve(glims_ctx* h, const CgVecs& v, double tol_abs, double 
   else if (r_norm > tol_abs) m = std::min(GL_CHEB_MAX, std::max(m_min, rec.iterations(tol_abs / r_norm)));
   const unsigned g = grid_for(n);
   double* info_dev = h->scal.p + 2 * SC_COUNT;
-  // Warm-started solve (warm_u = the predicted increment u, ghosts valid; cheb_delta = u on entry): u is direction 0.  Pass 1
-  // computes r - A u -- the product the warm start needs anyway -- takes the first Chebyshev direction from it and leaves
-  // the partial sums of |r|^2, from which the device chooses the count; no separate SpMV, no start kernel.
+  // Warm-started solve (warm_u = the predicted increment u, ghosts valid): u is the iterate of pass 1, which computes b - A u --
+  // the product the warm start needs anyway --, takes the first Chebyshev direction from it and leaves the partial sums of its
+  // square, from which the device chooses the count; no separate SpMV, no start kernel.
   const int shift = warm_u ? 1 : 0;
   double *d_in = v.p, *d_out = v.s;
   if (warm_u) {
     hipEvent_t* ev = h->timing(glims_ctx::TK_CHEB) ? h->pair(glims_ctx::TK_CHEB) : nullptr;
     // (one launch over all slices: the ghosts of u are current, nothing to exchange; the payload of d_1 is packed for pass 2)
-    gl_launch_cheb(h, h->st, p.n_slices, nullptr, v.vals, v.vals32, warm_u, v.p, v.r, v.dinv, h->cheb_delta.p, v.x, v.fixed,
-                   0.0, 1.0 / rec.theta, 1, GL_CHEB_MAX + 8, nullptr, want_res ? 1 : 0, pm, ev ? ev[0] : nullptr,
-                   ev ? ev[1] : nullptr, shift, h->partials.p);
+    gl_launch_cheb(h, h->st, p.n_slices, nullptr, v.vals, v.vals32, warm_u, v.p, v.r, v.dinv, h->cheb_dir.p,
+                   h->cheb_delta.p, v.x, v.fixed, 0.0, 1.0 / rec.theta, 1, GL_CHEB_MAX + 8, nullptr, want_res ? 1 : 0, pm,
+                   ev ? ev[0] : nullptr, ev ? ev[1] : nullptr, shift, h->partials.p);
     reduce_partials(h, gl_spmv_grid(p.n_slices), 1, nullptr);
     allreduce_sum(h, h->red.p, 1);
     hipLaunchKernelGGL(k_cheb_plan, dim3(1), dim3(1), 0, h->st, (const double*)h->red.p, tol_abs * tol_abs,
@@ -1398,8 +1398,9 @@ static ChebRun cheb_solve(glims_ctx* h, const CgVecs& v, double tol_abs, double 
     GL_HIP(hipGetLastError());
     m = std::max(2, m);
   } else {
+    // (zero guess: the first iterate y_1 = d_1 = Dinv b / theta needs no operator pass)
     hipLaunchKernelGGL(k_cheb_start, dim3(g), dim3(256), 0, h->st, n, v.r, (const double*)nullptr, v.x, (const double*)nullptr,
-                       v.dinv, 1.0 / rec.theta, v.p, h->cheb_delta.p, (double*)nullptr, pm);
+                       v.dinv, 1.0 / rec.theta, v.p, h->cheb_dir.p, (double*)nullptr, pm);
     GL_HIP(hipGetLastError());
   }
   const int last = (want_res ? m : m - 1) + shift;
@@ -1410,17 +1411,19 @@ static ChebRun cheb_solve(glims_ctx* h, const CgVecs& v, double tol_abs, double 
     const int* plan = run.planned ? h->cheb_plan.p : nullptr;
     hipEvent_t* ev = h->timing(glims_ctx::TK_CHEB) ? h->pair(glims_ctx::TK_CHEB) : nullptr;
     if (!split) {
-      gl_launch_cheb(h, h->st, p.n_slices, nullptr, v.vals, v.vals32, d_in, d_out, v.r, v.dinv, h->cheb_delta.p, v.x,
-                     v.fixed, c1, c2, k, m, plan, want_res ? 1 : 0, pm, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr, shift);
+      gl_launch_cheb(h, h->st, p.n_slices, nullptr, v.vals, v.vals32, d_in, d_out, v.r, v.dinv, h->cheb_dir.p,
+                     h->cheb_delta.p, v.x, v.fixed, c1, c2, k, m, plan, want_res ? 1 : 0, pm, ev ? ev[0] : nullptr,
+                     ev ? ev[1] : nullptr, shift);
     } else {
       // the ghosts of d_in travel (payload packed by the kernel that produced it) while the slices without ghost columns run
       halo_start(h, d_in, 1, /*prepacked=*/true);
       gl_launch_cheb(h, h->st, p.n_interior, p.interior_slices.p, v.vals, v.vals32, d_in, d_out, v.r, v.dinv,
-                     h->cheb_delta.p, v.x, v.fixed, c1, c2, k, m, plan, want_res ? 1 : 0, pm, ev ? ev[0] : nullptr,
-                     ev ? ev[1] : nullptr, shift);
+                     h->cheb_dir.p, h->cheb_delta.p, v.x, v.fixed, c1, c2, k, m, plan, want_res ? 1 : 0, pm,
+                     ev ? ev[0] : nullptr, ev ? ev[1] : nullptr, shift);
       halo_finish(h);
       gl_launch_cheb(h, h->st, p.n_boundary, p.boundary_slices.p, v.vals, v.vals32, d_in, d_out, v.r, v.dinv,
-                     h->cheb_delta.p, v.x, v.fixed, c1, c2, k, m, plan, want_res ? 1 : 0, pm, nullptr, nullptr, shift);
+                     h->cheb_dir.p, h->cheb_delta.p, v.x, v.fixed, c1, c2, k, m, plan, want_res ? 1 : 0, pm, nullptr, nullptr,
+                     shift);
     }
     std::swap(d_in, d_out);
   }
@@ -1775,10 +1778,8 @@ int gl_step(glims_ctx* h, int n_steps) {
         // (dot-free solve: the guess u becomes direction 0 of the solve -- the product A u is then the solve's first operator
         //  pass and the correction accumulates from u: cheb_solve, warm_u)
         ws_fused = use_cheb && h->have_c_old;
-        if (ws_fused) h->cheb_delta.alloc((size_t)h->n_nodes);
         hipLaunchKernelGGL(k_ws_delta, dim3(grid_exact(h->n_nodes)), dim3(256), 0, h->st, h->n_nodes, h->c.p,
-                           h->c_old.p, h->cg_u.p, h->ws_du.p, (h->have_c_old && h->ws_depth >= 1) ? 1 : 0,
-                           ws_fused ? h->cheb_delta.p : (double*)nullptr);
+                           h->c_old.p, h->cg_u.p, h->ws_du.p, (h->have_c_old && h->ws_depth >= 1) ? 1 : 0);
         h->ws_depth = h->have_c_old ? 1 : 0;   // (ws_du holds a real increment from the second warm-started step on)
         if (h->have_c_old) {
           warm = true;
