@@ -365,7 +365,7 @@ def alt_rank_sized(Handle, device, headline_ns_per_row, steps=20, warmup=5, n=10
            "per_row_rate_relative_to_headline": (headline_ns_per_row / ns_row) if headline_ns_per_row else None,
            "projected_8gpu_speedup_without_communication": (8.0 * headline_ns_per_row / ns_row) if headline_ns_per_row else None}
     out.update(solver_counts(s, steps))
-    pmc, pmc_file = load_pmc(s, ("r05_a_pmc_c4_107.json",))
+    pmc, pmc_file = load_pmc(s, ("r05_c_pmc_c4_107.json", "r05_a_pmc_c4_107.json"))
     out["kernels"] = kernel_list(s, k, steps, 1e3 * el / steps, k_steps, 8, pmc)
     out["traffic_source"] = None if pmc is None else "lookup, not measured in this run: " + pmc_file
     h.close()
@@ -408,7 +408,7 @@ def alt_unstructured(Handle, device, steps=20, warmup=5, n_points=1000000):
     h.reset_stats()
     st |= h.step(k_steps)
     k = h.stats()
-    pmc, pmc_file = load_pmc(s, ("r05_a_pmc_bl.json", "r04_a_pmc_bl.json"))
+    pmc, pmc_file = load_pmc(s, ("r05_c_pmc_bl.json", "r05_a_pmc_bl.json"))
     kernels = kernel_list(s, k, steps, 1e3 * el / steps, k_steps, 16, pmc)
     out["traffic_source"] = None if pmc is None else "lookup, not measured in this run: " + pmc_file
     out["kernels"] = kernels
@@ -658,7 +658,7 @@ def main():
     # calibrated on kernels with exactly known byte counts).  A LOOKUP into the committed summary of those passes, not
     # a measurement of this run: only reported when this run's operator is the one the passes measured, and
     # `traffic_source` names the file.
-    pmc, pmc_file = load_pmc(st, ("r05_a_pmc_c4.json", "r04_a_pmc_c4.json")) if world == 1 else (None, None)
+    pmc, pmc_file = load_pmc(st, ("r05_c_pmc_c4.json", "r05_a_pmc_c4.json")) if world == 1 else (None, None)
     unr = 16 if args.workload.lower() in ("bl", "brain_like", "brain-like", "u", "unstructured") else 8
     traffic = pmc_lookup(pmc, "k_cheb" if cheb_dominant else "k_spmv<1" if in_step else "k_spmv<0")
     steps_n = max(1, steps_done)

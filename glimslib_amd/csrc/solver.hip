@@ -944,34 +944,22 @@ void gl_apply_dirichlet_c(glims_ctx* h) {
 // ===================================================================================================
 // Dot-free RD linear solves: Chebyshev semi-iteration on the interval the run's right-hand sides excite
 // ===================================================================================================
-// Start of a solve: [warm start: r -= w (= A u), c += u;]  d_0 = Dinv r / theta,  delta = d_0, halo payload of d_0, and -- for
-// the device-side choice of the iteration count -- the partial sums of |r|^2.
-__global__ __launch_bounds__(256) void k_cheb_start(int64_t n_own, double* __restrict__ r, const double* __restrict__ w,
-                                                     double* __restrict__ c, const double* __restrict__ u,
-                                                     const double* __restrict__ dinv, double inv_theta,
-                                                     double* __restrict__ d, double* __restrict__ delta,
-                                                     double* __restrict__ pv, const PackMap pm) {
+// Start of a solve from a zero guess: the first iterate needs no operator pass -- y_1 = d_1 = Dinv b / theta (+ its halo payload).
+__global__ __launch_bounds__(256) void k_cheb_start(int64_t n_own, const double* __restrict__ b, const double* __restrict__ dinv,
+                                                     double inv_theta, double* __restrict__ y, double* __restrict__ d,
+                                                     const PackMap pm) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  double pr = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_own; i += stride) {
-    double ri = r[i];
-    if (w) {
-      ri -= w[i];
-      r[i] = ri;
-      c[i] += u[i];
-    }
-    const double d0 = inv_theta * dinv[i] * ri;
+    const double d0 = inv_theta * dinv[i] * b[i];
+    y[i] = d0;
     d[i] = d0;
-    delta[i] = d0;
     if (pm.ref) pack_row<1>(pm, i, &d0);
-    pr += ri * ri;
   }
-  if (pv) block_sum2(pr, 0.0, pv);
 }
-// Iteration count of a warm-started solve, on the device: the smallest m with 1 / T_m(sigma) <= tol / |r|, i.e.
-// m = ceil(acosh(|r| / tol) / acosh(sigma)), at least m_min (2 when no residual pass follows: the correction is added to the
-// iterate by pass m - 1), at most m_max; 0 = the warm start alone meets the tolerance.  Left in plan[0] for the launches and
-// in the Krylov info slot for the host's statistics (travels with the next decision mail).
+// Iteration count of a warm-started solve, on the device, from the residual |t| of the guess (pass 1 has left its square in red[0]):
+// the smallest m with 1 / T_m(sigma) <= tol / |t|, i.e. m = ceil(acosh(|t| / tol) / acosh(sigma)), at least m_min, at most m_max;
+// m_done if the guess alone meets the tolerance.  Left in plan[0] for the launches and in the Krylov info slot for the host's
+// statistics (travels with the next decision mail).
 __global__ void k_cheb_plan(const double* __restrict__ red, double tol2, double inv_acosh_sigma, int m_min, int m_max,
                             int m_done, int* __restrict__ plan, double* __restrict__ info) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -1399,8 +1387,8 @@ static ChebRun cheb_solve(glims_ctx* h, const CgVecs& v, double tol_abs, double 
     m = std::max(2, m);
   } else {
     // (zero guess: the first iterate y_1 = d_1 = Dinv b / theta needs no operator pass)
-    hipLaunchKernelGGL(k_cheb_start, dim3(g), dim3(256), 0, h->st, n, v.r, (const double*)nullptr, v.x, (const double*)nullptr,
-                       v.dinv, 1.0 / rec.theta, v.p, h->cheb_dir.p, (double*)nullptr, pm);
+    hipLaunchKernelGGL(k_cheb_start, dim3(g), dim3(256), 0, h->st, n, (const double*)v.r, v.dinv, 1.0 / rec.theta, v.p,
+                       h->cheb_dir.p, pm);
     GL_HIP(hipGetLastError());
   }
   const int last = (want_res ? m : m - 1) + shift;
