@@ -147,6 +147,25 @@ def config_c4(n=215, mechanics=False):
     return _brain_box(n, mechanics, 500, "C4 brain-extent box n=%d, 2 tissues" % n)
 
 
+def config_c4_octant(n=107):
+    """The central octant of config C4 at C4's OWN mesh width (half the extent per axis, n = 107 cells: h = 1.12 mm against
+    1.116): what one rank of an 8-GPU run of C4 holds -- same spacing, same tissues, same seed, hence the same spectrum and
+    iteration counts as the headline run (the brain-extent box at n = 107 is a coarser PROBLEM with more Krylov passes per step)."""
+    ctr = np.array([120.0, -120.0, 77.5])
+    half = np.array([60.0, 60.0, 38.75])
+    mesh = BoxMesh(tuple(ctr - half), tuple(ctr + half), n, n, n)
+    mid = mesh.cell_midpoints()
+    q = ((mid[:, 0] - 120.0) / 80.0) ** 2 + ((mid[:, 1] + 120.0) / 80.0) ** 2 + ((mid[:, 2] - 77.5) / 50.0) ** 2
+    label = np.where(q < 1.0, WM, GM).astype(np.int32)
+    tables = dict(D=[0.0, 0.0, 0.01, 0.05, 0.0], rho=[0.0, 0.0, 0.05, 0.05, 0.0],
+                  gamma=[0.0, 0.1, 0.1, 0.1, 0.1], E=[1.0, 1000e-6, 3000e-6, 3000e-6, 1000e-6],
+                  nu=[0.3, 0.45, 0.45, 0.45, 0.3])
+    d2 = ((mesh.points - np.array([118.0, -109.0, 72.0])) ** 2).sum(axis=1)
+    c0 = np.exp(-0.5 * d2)
+    return Workload("C4 central octant n=%d (C4's mesh width, 1/8 of its rows), 2 tissues" % n, mesh, label, tables, c0, 1.0, 500,
+                    False)
+
+
 def config_c5(n=99):
     return _brain_box(n, True, 50, "C5 coupled (c + u) brain-extent box n=%d" % n)
 
@@ -206,6 +225,8 @@ def by_name(name, n=None):
         return config_c4(*([n] if n else []))
     if name == 'c5':
         return config_c5(*([n] if n else []))
+    if name in ('c4o', 'c4_octant'):
+        return config_c4_octant(*([n] if n else []))
     if name in ('u', 'unstructured'):
         return config_unstructured(*([n] if n else []))
     if name in ('bl', 'brain_like', 'brain-like'):     # n = number of points here
