@@ -99,6 +99,17 @@ def rcb_owners(points, n_parts, weights):
         cum = np.cumsum(w[idx][order])
         cut = int(np.searchsorted(cum, cum[-1] * kl / k, side='left')) + 1
         cut = min(max(cut, kl), len(idx) - (k - kl))          # every rank owns at least one node
+        # lattice meshes: the cut would fall INSIDE a plane of equal coordinates (a jagged interface, two parts sharing the plane);
+        # take the whole plane to the nearer side if that moves less than 1 % of the set's work (small lattices keep the jagged cut: equal work matters more there)
+        xs = p[order, axis]
+        if 0 < cut < len(idx) and xs[cut - 1] == xs[cut]:
+            lo_ = int(np.searchsorted(xs, xs[cut], side='left'))
+            hi_ = int(np.searchsorted(xs, xs[cut], side='right'))
+            for cand in sorted((lo_, hi_), key=lambda c_: abs(c_ - cut)):
+                moved = abs(cum[cand - 1] - cum[cut - 1]) if cand > 0 else cum[cut - 1]
+                if kl <= cand <= len(idx) - (k - kl) and moved <= 0.01 * cum[-1]:
+                    cut = cand
+                    break
         stack.append((idx[order[:cut]], first, kl))
         stack.append((idx[order[cut:]], first + kl, k - kl))
     return owner
