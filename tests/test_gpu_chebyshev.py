@@ -114,3 +114,20 @@ def test_brain_like_mesh_chebyshev_against_pcg(backend):
     assert st1['cheb_solves'] > 0
     assert rel_l2(c1, c2) < 1e-9
     assert st1['cg_its'] <= 1.3 * st2['cg_its'] + 10
+
+
+def test_stream_policy_and_explicit_chebyshev_do_not_change_the_bits(backend):
+    """The cache policy of the operator streams (glims_options.stream_policy) only changes how loads are issued: cached and
+    non-temporal runs are bitwise equal, counters included; rd_linear = CHEBYSHEV differs from AUTO only where AUTO's cost model
+    sends a tight solve to PCG -- on this problem nowhere."""
+    w = _c3_reduced(24)
+    s1, c1, st1 = _run(backend, w, 10, stream_policy=backend.STREAM_CACHED)
+    s2, c2, st2 = _run(backend, w, 10, stream_policy=backend.STREAM_NONTEMPORAL)
+    s3, c3, st3 = _run(backend, w, 10, rd_linear=backend.RD_LINEAR_CHEBYSHEV)
+    assert s1 == 0 and s2 == 0 and s3 == 0
+    assert st1['stream_nontemporal'] == 0 and st2['stream_nontemporal'] == 1
+    assert np.array_equal(c1, c2)
+    for k in ('newton_its', 'cg_its', 'cheb_its', 'cheb_solves', 'rd_assemblies', 'rd_quad_updates'):
+        assert st1[k] == st2[k], k
+    assert st1['krylov_working_set'] > 0
+    assert np.array_equal(c1, c3) or rel_l2(c1, c3) < 1e-10
