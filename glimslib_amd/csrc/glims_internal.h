@@ -516,6 +516,7 @@ struct glims_ctx {
     double acc_lmin0 = 0.0, acc_lmax0 = 0.0;
     int learned = 0, learned0 = 0;         // PCG solves that contributed to acc_* / acc_*0
     int age = 0;                           // steps since the interval was measured
+    int weak = 0;                          // consecutive dot-free solves that contracted far less than they were sized for
     int m_hint = 0;                        // passes the device chose for the last warm-started solve (bounds the next one's launches)
     // Which iteration a solve AFTER a step's first one uses (the first, loose one always takes the dot-free iteration): PCG
     // needs fewer operator passes for a tight solve (superlinear convergence: 8 iterations where the Chebyshev bound asks for

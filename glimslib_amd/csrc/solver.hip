@@ -1899,6 +1899,17 @@ int gl_step(glims_ctx* h, int n_steps) {
         rebase = false;
         continue;
       }
+      // A dot-free solve that contracts, but far less than it was sized for (10 x its tolerance plus the quadratic remainder),
+      // has an interval that no longer fits what the right-hand sides excite: not a take-back -- the Newton iteration copes --
+      // but two of them in a row make the next step a learning step instead of waiting for the 32nd.
+      if (use_cheb && it >= 1 && std::isfinite(nr)) {
+        const bool weak = nr > target && nr > 10.0 * (tol_lin + (adaptive_forcing ? floor_pred : 0.0));
+        cb.weak = weak ? cb.weak + 1 : 0;
+        if (cb.weak >= 2) {
+          cb.age = 1 << 20;
+          cb.weak = 0;
+        }
+      }
       if (std::isfinite(nr) && nr_before > 0.0) {
         ratio_est = nr / nr_before;
         if (it == 0) h->nq_first_ratio = ratio_est;
