@@ -127,15 +127,19 @@ typedef struct glims_options {
   /* ---- ABI 6: the Krylov iteration of the Jacobi-preconditioned RD solves, and how its operator streams are cached.  PETSc's
    * counterpart is the KSP type (-ksp_type cg | chebyshev) behind solver.parameters (simulation_tumor_growth.py:126-130). */
   int    rd_linear;       /* GLIMS_RD_LINEAR_AUTO | _PCG | _CHEBYSHEV.  CHEBYSHEV: the dot-free iteration -- ONE kernel per
-                             iteration (operator pass with the Chebyshev recurrence in its epilogue), no dot product, no
-                             reduction kernel, no all-reduce in partitioned runs; the iteration count follows from the wanted
-                             reduction and the interval [lmin, lmax] of Dinv A(c) that the run's right-hand sides excite, taken
-                             from the Lanczos coefficients of PCG solves: all solves of the first step after glims_set_state
-                             and of every 32nd step run PCG and (re)measure it.  Every solve is followed by a Newton residual
-                             evaluation anyway; one that did not contract (interval too narrow) is taken back, the interval
-                             dropped and the iteration repeated with PCG (glims_stats.cheb_fallbacks).  Same iteration counts
-                             as PCG +-1 on the BASELINE configs (tools/proto_chebyshev.py).  AUTO = CHEBYSHEV wherever the RD
-                             solves are Jacobi-preconditioned; solves with the multigrid preconditioner always use PCG
+                             iteration (operator pass with the Chebyshev recurrence in its epilogue; a step's first solve takes the
+                             warm-start guess as its first iterate, so the product A u is that solve's first pass), no dot
+                             product, no reduction kernel, no all-reduce in partitioned runs.  The iteration count follows from
+                             the wanted reduction and an interval [lmin, lmax] of Dinv A(c) chosen from the spectral measure of the
+                             run's own right-hand sides (Lanczos coefficients of PCG solves: all solves of the first step after
+                             glims_set_state and of every 32nd step run PCG and (re)measure it; loose and tight solves keep
+                             intervals of their own).  Every solve is followed by a Newton residual evaluation anyway: one that
+                             did not contract is taken back, the interval dropped and the iteration repeated with PCG
+                             (glims_stats.cheb_fallbacks); two that contract far less than sized for bring the next learning step
+                             forward; a solve whose bound exceeds 48 passes runs PCG.  AUTO = CHEBYSHEV wherever the RD solves
+                             are Jacobi-preconditioned, except that a tight solve goes to PCG when a byte model of the two
+                             iterations and PCG's measured rate say it is cheaper; solves with the multigrid preconditioner
+                             always use PCG.  The choice never depends on timings: runs are bitwise reproducible
                                                                                                           default AUTO  */
   int    stream_policy;   /* GLIMS_STREAM_AUTO | _NONTEMPORAL | _CACHED: cache policy of the operator's value / column-code
                              streams in the Krylov operator pass.  Non-temporal keeps the gathered vector in L2 when the
