@@ -54,3 +54,15 @@ def test_config_brain_like_has_two_tissues_with_a_curved_interface():
     assert 0.05 < (lab == workloads.WM).mean() < 0.4
     assert w.dirichlet_nodes is not None and len(w.dirichlet_nodes) > 0
     assert 0.0 < w.c0.max() <= 1.0
+
+
+def test_c4_octant_has_the_mesh_width_of_c4_and_an_eighth_of_its_rows():
+    """alt.rank_octant's workload: the central octant of config C4 at C4's own spacing (what a rank of the 8-GPU run holds)."""
+    w = workloads.config_c4_octant(12)
+    assert w.mesh.num_vertices() == 13 ** 3 and w.mesh.num_cells() == 6 * 12 ** 3
+    ext = w.mesh.points.max(axis=0) - w.mesh.points.min(axis=0)
+    assert np.allclose(ext, [120.0, 120.0, 77.5])
+    # n = 107 on half the extent: within 0.5 % of C4's spacing (n = 215 on the whole extent), and 1/8 of C4's rows to 1.5 %
+    assert abs((120.0 / 107) / (240.0 / 215) - 1.0) < 5e-3
+    assert abs(8 * 108 ** 3 / 216.0 ** 3 - 1.0) < 1e-12
+    assert set(np.unique(w.cell_label)) <= {workloads.GM, workloads.WM} and w.c0.max() <= 1.0
