@@ -507,6 +507,7 @@ int glims_setup(glims_ctx* h, int with_mechanics) {
     h->use_idx16 = (h->opt.flags & GLIMS_FLAG_INT32_COLUMNS) == 0;
     h->stats.nnz_idx16 = h->use_idx16 ? h->nnz_idx16_avail : 0;
     h->cheb = glims_ctx::ChebState();   // the interval belongs to one operator
+    h->have_d2 = false;
     {
       // Cache policy of the operator streams in the Krylov pass.  What one Krylov iteration touches: the stored entries
       // (values + column codes) and the iteration's vector traffic.  While that fits the 256 MiB Infinity Cache with room to
@@ -533,6 +534,9 @@ int glims_set_state(glims_ctx* h, const double* c, const double* u) {
     GL_REQUIRE(c, "null concentration");
     h->pending = false;
     h->have_c_old = false;
+    h->have_d2 = false;
+    h->d2_off = h->d2_good = 0;
+    h->d2_backoff = 8;
     // A new state starts a new run (FenicsSimulation.run() may be called again on the same object, simulation_base.py:166-168,
     // run_for_adjoint does): what the Newton iteration has learnt from the previous run's steps is forgotten, so that the run
     // takes the iteration path -- and produces the bits -- of a fresh handle.  (What stays: the operators, both multigrid

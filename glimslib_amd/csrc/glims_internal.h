@@ -517,7 +517,8 @@ struct glims_ctx {
     int learned = 0, learned0 = 0;         // PCG solves that contributed to acc_* / acc_*0
     int age = 0;                           // steps since the interval was measured
     int weak = 0;                          // consecutive dot-free solves that contracted far less than they were sized for
-    int m_hint = 0;                        // passes the device chose for the last warm-started solve (bounds the next one's launches)
+    int m_hint[2] = {0, 0};                // passes the device chose for the last warm-started solve (bounds the next one's launches):
+                                           // [0] a step's first solve, [1] its second
     // Which iteration a solve AFTER a step's first one uses (the first, loose one always takes the dot-free iteration): PCG
     // needs fewer operator passes for a tight solve (superlinear convergence: 8 iterations where the Chebyshev bound asks for
     // 13-15 at config C4), the dot-free iteration cheaper ones.  cost_ratio = cost of a Chebyshev pass / cost of a PCG
@@ -530,6 +531,15 @@ struct glims_ctx {
   double cheb_test_hi = 1.0;               // TEST HOOK GLIMS_CHEB_TEST_SCALE_HI (read by glims_create): factor on the measured upper end
   dvec<double> cg_hist;                    // [2 * GL_CG_HIST] (alpha_k, beta_k) of the running PCG solve
   dvec<double> cheb_delta;                 // the correction the last Chebyshev solve added to the iterate [n_nodes] (take-back)
+  dvec<double> cheb_delta2;                // the same of a step's SECOND solve: kept across the step boundary, it is the next step's guess
+  bool have_d2 = false;                    // ... cheb_delta2 holds the previous step's second correction (same run, no jump in the state)
+  dvec<double> d2_prev;                    // the second correction of the step before that one (linear extrapolation of the guess)
+  int d2_depth = 0;                        // consecutive steps whose second correction was kept (2: d2_prev is a real one)
+  int d2_regime = -1;                      // the step cheb_delta2 comes from: passes of its FIRST solve and the forcing mode (what that solve
+                                           // left behind depends on them) ...
+  double d2_r1 = 0.0;                      // ... and the Newton residual its second solve started from
+  int d2_off = 0, d2_backoff = 8, d2_good = 0;   // steps for which the guess stays unused after one that missed the target; the length
+                                           // doubles with every miss (8 .. 256) and returns to 8 after 32 guesses that did not
   dvec<double> cheb_dir;                   // the running solve's direction d [n_nodes]
   dvec<int> cheb_plan;                     // [1] iteration count computed on the device (a step's first, warm-started solve)
   dvec<float> vKel32;                      // single-precision copy of K_el (inner solves of the elasticity solver)

@@ -496,6 +496,16 @@ __global__ void k_ws_delta(int64_t n, const double* __restrict__ c, double* __re
   du[i] = d1;
   c_old[i] = ci;
 }
+// Guess of a step's second linear solve from the second corrections of the two previous steps: u = 2 d - d_prev (or d alone when
+// only one is known); d_prev = d.
+__global__ void k_d2_guess(int64_t n, const double* __restrict__ d, double* __restrict__ d_prev, double* __restrict__ u,
+                           int second_order) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double a = d[i];
+  u[i] = second_order ? 2.0 * a - d_prev[i] : a;
+  d_prev[i] = a;
+}
 // r -= A u (w = A u), c += u
 __global__ void k_ws_apply(int64_t n, double* __restrict__ r, const double* __restrict__ w, double* __restrict__ c,
                            const double* __restrict__ u) {
@@ -939,6 +949,7 @@ void gl_apply_dirichlet_c(glims_ctx* h) {
                      h->fixed_c.p, (const double*)h->fixed_c_val.p);
   GL_HIP(hipGetLastError());
   h->have_c_old = false;
+  h->have_d2 = false;
 }
 
 // ===================================================================================================
@@ -1323,6 +1334,10 @@ static double cheb_cost_ratio(glims_ctx* h) {
   return (12.0 * v[1] + 60.0 * v[0] + B0) / (12.0 * v[1] + 136.0 * v[0] + 3.0 * B0);
 }
 
+#ifndef GL_D2_ORDER
+#define GL_D2_ORDER 2                  // guess of a step's second solve: 1 = the previous step's correction, 2 = extrapolated from the last two
+#endif
+static const double GL_D2_KAPPA_MAX = 6.0;   // ... only where the solve's interval has lmax / lmin below this
 static const int GL_CHEB_MAX = 96;    // launches of one solve at most
 static const int GL_CHEB_LONG = 48;   // solves that would need more passes than this run PCG
 
@@ -1332,16 +1347,15 @@ struct ChebRun {
 };
 
 // Solves A y = b (b = v.r, the Newton right-hand side at v.x) for the correction y of v.x: iterates in v.p / v.s (two buffers
-// that change roles every pass), direction in cheb_dir; the last pass adds y to v.x and keeps it in cheb_delta (take-back).
+// that change roles every pass), direction in cheb_dir; the last pass adds y to v.x and keeps it in ylast (take-back; next step's guess).
 // v.r is left untouched unless want_res, in which case the final pass turns it into the residual b - A y.
-// warm_u: the solve starts from this guess (the predicted increment, ghosts valid) instead of zero; the iteration count is then
-// chosen on the device from |b - A u| (r_bound bounds the launches), otherwise from r_norm = |b| here.
+// warm_u: the solve starts from this guess (the predicted increment, ghosts valid; may be ylast) instead of zero; the iteration count
+// is then chosen on the device from |b - A u| (r_bound bounds the launches; hint_slot: which solve of the step), otherwise from r_norm = |b| here.
 static ChebRun cheb_solve(glims_ctx* h, const CgVecs& v, double tol_abs, double r_norm, double r_bound, bool want_res,
-                          const double* warm_u) {
+                          const double* warm_u, double* ylast, int hint_slot) {
   const DevPattern& p = h->pat;
   const bool split = h->world > 1 && h->n_peers > 0;
   const int64_t n = h->n_own;
-  h->cheb_delta.alloc((size_t)h->n_nodes);
   h->cheb_dir.alloc((size_t)h->n_nodes);
   h->cheb_plan.alloc(1);
   double ia, ib;
@@ -1363,7 +1377,7 @@ static ChebRun cheb_solve(glims_ctx* h, const CgVecs& v, double tol_abs, double 
     // + 2 (like the PCG solves' hints: the launches beyond the device's count return at once, but each still costs a dispatch
     // and, in a partitioned run, a halo exchange); a count clipped by the bound is a slightly weaker Newton step
     m = std::min(GL_CHEB_MAX, std::max(m_min, rec.iterations(tol_abs / std::max(r_bound, tol_abs)) + 3));
-    if (h->cheb.m_hint > 0) m = std::max(m_min, std::min(m, h->cheb.m_hint + 2));
+    if (h->cheb.m_hint[hint_slot] > 0) m = std::max(m_min, std::min(m, h->cheb.m_hint[hint_slot] + 2 + hint_slot));
   }
   else if (r_norm > tol_abs) m = std::min(GL_CHEB_MAX, std::max(m_min, rec.iterations(tol_abs / r_norm)));
   const unsigned g = grid_for(n);
@@ -1377,7 +1391,7 @@ static ChebRun cheb_solve(glims_ctx* h, const CgVecs& v, double tol_abs, double 
     hipEvent_t* ev = h->timing(glims_ctx::TK_CHEB) ? h->pair(glims_ctx::TK_CHEB) : nullptr;
     // (one launch over all slices: the ghosts of u are current, nothing to exchange; the payload of d_1 is packed for pass 2)
     gl_launch_cheb(h, h->st, p.n_slices, nullptr, v.vals, v.vals32, warm_u, v.p, v.r, v.dinv, h->cheb_dir.p,
-                   h->cheb_delta.p, v.x, v.fixed, 0.0, 1.0 / rec.theta, 1, GL_CHEB_MAX + 8, nullptr, want_res ? 1 : 0, pm,
+                   ylast, v.x, v.fixed, 0.0, 1.0 / rec.theta, 1, GL_CHEB_MAX + 8, nullptr, want_res ? 1 : 0, pm,
                    ev ? ev[0] : nullptr, ev ? ev[1] : nullptr, shift, h->partials.p);
     reduce_partials(h, gl_spmv_grid(p.n_slices), 1, nullptr);
     allreduce_sum(h, h->red.p, 1);
@@ -1400,17 +1414,17 @@ static ChebRun cheb_solve(glims_ctx* h, const CgVecs& v, double tol_abs, double 
     hipEvent_t* ev = h->timing(glims_ctx::TK_CHEB) ? h->pair(glims_ctx::TK_CHEB) : nullptr;
     if (!split) {
       gl_launch_cheb(h, h->st, p.n_slices, nullptr, v.vals, v.vals32, d_in, d_out, v.r, v.dinv, h->cheb_dir.p,
-                     h->cheb_delta.p, v.x, v.fixed, c1, c2, k, m, plan, want_res ? 1 : 0, pm, ev ? ev[0] : nullptr,
+                     ylast, v.x, v.fixed, c1, c2, k, m, plan, want_res ? 1 : 0, pm, ev ? ev[0] : nullptr,
                      ev ? ev[1] : nullptr, shift);
     } else {
       // the ghosts of d_in travel (payload packed by the kernel that produced it) while the slices without ghost columns run
       halo_start(h, d_in, 1, /*prepacked=*/true);
       gl_launch_cheb(h, h->st, p.n_interior, p.interior_slices.p, v.vals, v.vals32, d_in, d_out, v.r, v.dinv,
-                     h->cheb_dir.p, h->cheb_delta.p, v.x, v.fixed, c1, c2, k, m, plan, want_res ? 1 : 0, pm,
+                     h->cheb_dir.p, ylast, v.x, v.fixed, c1, c2, k, m, plan, want_res ? 1 : 0, pm,
                      ev ? ev[0] : nullptr, ev ? ev[1] : nullptr, shift);
       halo_finish(h);
       gl_launch_cheb(h, h->st, p.n_boundary, p.boundary_slices.p, v.vals, v.vals32, d_in, d_out, v.r, v.dinv,
-                     h->cheb_dir.p, h->cheb_delta.p, v.x, v.fixed, c1, c2, k, m, plan, want_res ? 1 : 0, pm, nullptr, nullptr,
+                     h->cheb_dir.p, ylast, v.x, v.fixed, c1, c2, k, m, plan, want_res ? 1 : 0, pm, nullptr, nullptr,
                      shift);
     }
     std::swap(d_in, d_out);
@@ -1614,7 +1628,7 @@ int gl_step(glims_ctx* h, int n_steps) {
     if (cheb_learning) {
       cb.learned = cb.learned0 = 0;
       cb.pcg_best_its = 0;
-      cb.m_hint = 0;
+      cb.m_hint[0] = cb.m_hint[1] = 0;
       h->cg_hist.alloc((size_t)2 * GL_CG_HIST);
     }
     if (h->pending) {
@@ -1637,6 +1651,7 @@ int gl_step(glims_ctx* h, int n_steps) {
         // rank that wrote the values has dropped its own in gl_apply_dirichlet_c; a rank that kept it would run a differently
         // shaped first solve -- the warm-started dot-free solve reduces |r| first -- and the ranks' collectives would no longer pair up)
         h->have_c_old = false;
+        h->have_d2 = false;
       }
       if (extrapolate) {
         hipLaunchKernelGGL(k_extrapolate, dim3(grid_exact(n)), dim3(256), 0, h->st, n, h->c.p, h->c_old.p,
@@ -1692,6 +1707,17 @@ int gl_step(glims_ctx* h, int n_steps) {
       for (dvec<double>* v : {&h->nq_c0, &h->nq_ck}) v->alloc((size_t)h->n_nodes);
       h->nq_ad.alloc((size_t)2 * h->n_nodes);
     }
+    double* last_ylast = nullptr;   // where the last dot-free solve left its correction
+    int regime_now = -1;            // passes of this step's first solve when it was a dot-free one, and the forcing mode
+    double r1_now = 0.0;            // the Newton residual this step's second solve started from
+    bool pcg_rest = false;          // a dot-free solve of this step under-delivered: its remaining solves run PCG
+    bool used_warm2 = false;        // this step's second solve started from the previous step's second correction
+    bool warm2_miss = false;        // ... and left the residual above the target (the third iteration is the guess's doing)
+    if (h->d2_off > 0) {
+      --h->d2_off;
+      h->have_d2 = false;
+    }
+    bool d2_written = false;        // this step's second solve was a dot-free one (its correction is in cheb_delta2)
     for (int it = 0;; ++it) {
       if (!std::isfinite(nr)) {
         status = GLIMS_NAN;
@@ -1741,7 +1767,7 @@ int gl_step(glims_ctx* h, int n_steps) {
         GL_HIP(hipMemcpyAsync(ck_is_c0 ? h->nq_c0.p : h->nq_ck.p, h->c.p, (size_t)h->n_nodes * sizeof(double),
                               hipMemcpyDeviceToDevice, h->st));
       }
-      bool use_cheb = cheb_allowed && cb.valid;
+      bool use_cheb = cheb_allowed && cb.valid && !pcg_rest;
       if (use_cheb && tol_lin < nr) {
         double ia, ib;
         cheb_interval(h, tol_lin / nr, &ia, &ib);
@@ -1811,12 +1837,54 @@ int gl_step(glims_ctx* h, int n_steps) {
       if (use_cheb) {
         // |r| on entry: known to the host unless the solve starts from the warm-start guess -- then the count is chosen on the
         // device from the norm its first pass measures
-        crun = cheb_solve(h, v, tol_lin, nr, nr, cheap_next, ws_fused ? h->cg_u.p : (const double*)nullptr);
+        // A step's SECOND solve starts from the previous step's second correction: what the first solve leaves behind -- the
+        // quadratic remainder and the residual of a fixed polynomial applied to the extrapolation error -- changes by about a
+        // per cent from one step to the next (|R_1| over steps 20-28 of config C4: 1.31, 1.32, 1.34, 1.36, 1.40e-5), so the
+        // correction that removes it does too.
+        const bool second = it == 1;
+        h->cheb_delta.alloc((size_t)h->n_nodes);
+        if (second) h->cheb_delta2.alloc((size_t)h->n_nodes);
+        // (what the first solve leaves behind is a fixed polynomial of the operator applied to the extrapolation error: a first solve
+        //  of another degree leaves something else -- config C4 / 8, step 24: 3 -> 2 passes, |R_1| 1.8e-5 -> 2.8e-5 -- and the
+        //  second corrections before and after such a change do not continue each other)
+        // The same for the forcing mode (a midpoint-corrected first right-hand side leaves a residual twenty times smaller), and
+        // the check that needs no model: the correction is proportional to the residual it removes, so |R_1| has to continue too.
+        if (second && h->have_d2 && (regime_now != h->d2_regime || !(nr > 0.7 * h->d2_r1 && nr < 1.43 * h->d2_r1)))
+          h->have_d2 = false;
+        if (!h->have_d2) h->d2_depth = 0;   // (dropped since the last step: a new state, new boundary values, a take-back)
+        // Only on a narrow interval: the components that come back with the guess are the ones the solves' polynomial amplifies --
+        // outside the interval, where it grows like exp(degree) -- and a wide interval means long solves (random-point mesh, 1 M
+        // nodes, [0.18, 3.3]: 27-34 passes instead of 41-44 for eight steps, then a residual three times the target and a third
+        // Newton iteration per step for the sixteen after: 2.9 -> 3.6 ms per step; not used there).
+        bool narrow = false;
+        if (second && h->have_d2) {
+          double ia, ib;
+          cheb_interval(h, tol_lin / nr, &ia, &ib);
+          narrow = ib <= GL_D2_KAPPA_MAX * ia;
+        }
+        const bool warm2 = GL_D2_ORDER >= 1 && second && h->have_d2 && narrow && (o.flags & GLIMS_FLAG_WARM_START) && !extrapolate;
+        if (warm2) {
+          // (linearly extrapolated from the last two; the guess goes where the first solve's went: cg_u is free again)
+          h->d2_prev.alloc((size_t)h->n_nodes);
+          hipLaunchKernelGGL(k_d2_guess, dim3(grid_exact(n)), dim3(256), 0, h->st, n, (const double*)h->cheb_delta2.p,
+                             h->d2_prev.p, h->cg_u.p, (h->d2_depth >= 2 && GL_D2_ORDER >= 2) ? 1 : 0);
+          GL_HIP(hipGetLastError());
+          if (h->world > 1) gl_halo_exchange(h, h->cg_u.p, 1);   // (corrections are kept by their row owners: ghosts)
+        }
+        last_ylast = second ? h->cheb_delta2.p : h->cheb_delta.p;
+        if (second) {
+          d2_written = true;
+          r1_now = nr;
+          used_warm2 = warm2;
+        }
+        crun = cheb_solve(h, v, tol_lin, nr, nr, cheap_next, (ws_fused || warm2) ? h->cg_u.p : (const double*)nullptr,
+                          last_ylast, second ? 1 : 0);
         deferred = crun.planned;
         if (!deferred) {
           h->stats.cg_its += crun.passes;
           h->stats.cheb_its += crun.passes;
           h->stats.last_cg_res = tol_lin;
+          if (it == 0) regime_now = 1000 + crun.passes + 100 * nw_mode;   // (a cold first solve: not the same thing as a warm one of that count)
         }
       } else {
         if (cheb_learning) v.hist = h->cg_hist.p;
@@ -1856,7 +1924,10 @@ int gl_step(glims_ctx* h, int n_steps) {
       }
       if (deferred && use_cheb) {   // the count the device chose for the warm-started solve
         const int64_t m_dev = (int64_t)km.info[0];
-        cb.m_hint = (int)std::max<int64_t>(1, m_dev);
+        cb.m_hint[it == 1 ? 1 : 0] = (int)std::max<int64_t>(1, m_dev);
+        if (it == 0) regime_now = (int)m_dev + 100 * nw_mode;
+        // (a count that used up its launches: the guess was further off than the last ones -- not a basis for the next step's)
+        if (it == 1 && m_dev >= crun.passes) d2_written = false;
         const int64_t passes = std::max<int64_t>(0, std::min<int64_t>(crun.passes, (cheap ? m_dev : m_dev - 1) + 1));
         h->stats.cg_its += passes;
         h->stats.cheb_its += passes;
@@ -1887,7 +1958,14 @@ int gl_step(glims_ctx* h, int n_steps) {
           fprintf(stderr, "glims dot-free solves: step %lld, Newton iteration %d: residual %.3e -> %.3e (target %.3e, linear tolerance "
                   "%.3e, %s count, %d passes enqueued) -- taken back, PCG from here\n", (long long)h->stats.steps, it, nr_before, nr,
                   target, tol_lin, crun.planned ? "device-side" : "host-side", crun.passes);
-        hipLaunchKernelGGL(k_sub_inplace, dim3(grid_exact(n)), dim3(256), 0, h->st, n, h->c.p, h->cheb_delta.p);
+        hipLaunchKernelGGL(k_sub_inplace, dim3(grid_exact(n)), dim3(256), 0, h->st, n, h->c.p, (const double*)last_ylast);
+        d2_written = false;
+        h->have_d2 = false;
+        if (it == 1 && used_warm2) {
+          h->d2_off = h->d2_backoff;
+          h->d2_backoff = std::min(256, 2 * h->d2_backoff);
+          h->d2_good = 0;
+        }
         GL_HIP(hipGetLastError());
         cb.valid = false;
         cb.lmax0 = cb.lmin0 = 0.0;   // (the loose interval is re-learnt from scratch)
@@ -1898,6 +1976,22 @@ int gl_step(glims_ctx* h, int n_steps) {
         base_is_current = true;
         rebase = false;
         continue;
+      }
+      // A second solve that started from the guess and left the residual above the target (by any margin): what it left is more
+      // likely the guess's doing (components that the previous steps' solves amplified instead of damping come back with it) than
+      // the quadratic remainder -- the third solve runs PCG, and the guess stays unused for a while (the solves from zero in
+      // between start clean): 8 steps, doubling with every miss.
+      if (use_cheb && it == 1 && used_warm2 && std::isfinite(nr)) {
+        if (nr > target) {
+          pcg_rest = true;
+          d2_written = false;
+          warm2_miss = true;
+          h->d2_off = h->d2_backoff;
+          h->d2_backoff = std::min(256, 2 * h->d2_backoff);
+          h->d2_good = 0;
+        } else if (++h->d2_good >= 32) {
+          h->d2_backoff = 8;
+        }
       }
       // A dot-free solve that contracts, but far less than it was sized for (10 x its tolerance plus the quadratic remainder),
       // has an interval that no longer fits what the right-hand sides excite: not a take-back -- the Newton iteration copes --
@@ -1944,6 +2038,12 @@ int gl_step(glims_ctx* h, int n_steps) {
       }
     }
     ++h->nw_steps;
+    h->have_d2 = d2_written && status == GLIMS_OK;
+    if (h->have_d2) {
+      h->d2_regime = regime_now;
+      h->d2_r1 = r1_now;
+    }
+    h->d2_depth = h->have_d2 ? std::min(2, h->d2_depth + 1) : 0;
     if (cheb_learning && status == GLIMS_OK && cb.learned > 0) {
       if (cb.cost_ratio == 0.0) cb.cost_ratio = cheb_cost_ratio(h);
       // (the interval forgets slowly: an upper end that one step's right-hand sides did not excite is not dropped at once)
@@ -1969,7 +2069,8 @@ int gl_step(glims_ctx* h, int n_steps) {
     // (the first steps of a run have no increments to extrapolate from and take three iterations whatever the mode: they do
     //  not speak for it)
     if (quad && status == GLIMS_OK && !fixed_forcing && h->nw_steps > 8) {
-      const int64_t count = h->stats.newton_its - newton0;
+      // (a third iteration that the second solve's guess caused says nothing about the forcing mode)
+      const int64_t count = h->stats.newton_its - newton0 - (warm2_miss ? 1 : 0);
       if (h->nw_mode == 0) {
         // (one step in ten taking a third iteration is cheaper than the correction's pass on every step: two within a few)
         h->nw_hold = count >= 3 ? h->nw_hold + 4 : std::max(0, h->nw_hold - 1);

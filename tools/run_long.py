@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Long run of a BASELINE config in chunks, printing the solver statistics of every chunk (robustness check).
-    python tools/run_long.py [c4] [500] [20] [summary.json]
+    python tools/run_long.py [c4 | c4:107 | c4o:107 | c3 | bl ...] [500] [20] [summary.json]
 The JSON summary (steps completed, status, mean / min / max ms per step over the chunks, hash of the library sources) is what
 bench.py quotes as config.full_run_* -- commit it as profiles/long_c4_run.json together with the printed log."""
 import json, os, sys
@@ -14,7 +14,8 @@ from glimslib_amd._backend import Handle
 name = sys.argv[1] if len(sys.argv) > 1 else 'c4'
 total = int(sys.argv[2]) if len(sys.argv) > 2 else 500
 chunk = int(sys.argv[3]) if len(sys.argv) > 3 else 10
-w = workloads.by_name(name)
+name, _, size = name.partition(':')   # (c4:107 = the same configuration at another size)
+w = workloads.by_name(name, int(size)) if size else workloads.by_name(name)
 h = Handle(w.mesh.points, w.mesh.cells, w.cell_label)
 t = w.tables
 h.set_materials(t['D'], t['rho'], t['gamma'], t['E'], t['nu'])
