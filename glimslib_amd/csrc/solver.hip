@@ -506,6 +506,11 @@ __global__ void k_d2_guess(int64_t n, const double* __restrict__ d, double* __re
   u[i] = second_order ? 2.0 * a - d_prev[i] : a;
   d_prev[i] = a;
 }
+// d = c - d (d held the state before a solve: now the correction the solve added)
+__global__ void k_d2_from_state(int64_t n, const double* __restrict__ c, double* __restrict__ d) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) d[i] = c[i] - d[i];
+}
 // r -= A u (w = A u), c += u
 __global__ void k_ws_apply(int64_t n, double* __restrict__ r, const double* __restrict__ w, double* __restrict__ c,
                            const double* __restrict__ u) {
@@ -1713,6 +1718,7 @@ int gl_step(glims_ctx* h, int n_steps) {
     bool pcg_rest = false;          // a dot-free solve of this step under-delivered: its remaining solves run PCG
     bool used_warm2 = false;        // this step's second solve started from the previous step's second correction
     bool warm2_miss = false;        // ... and left the residual above the target (the third iteration is the guess's doing)
+    bool d2_pcg = false;            // ... the second solve was a PCG one
     if (h->d2_off > 0) {
       --h->d2_off;
       h->have_d2 = false;
@@ -1888,7 +1894,43 @@ int gl_step(glims_ctx* h, int n_steps) {
         }
       } else {
         if (cheb_learning) v.hist = h->cg_hist.p;
+        // The second solve's guess with PCG (the brain-like mesh's tight solves, multigrid-preconditioned stiff steps,
+        // rd_linear = PCG): same guess, applied like the first solve's (r -= A u, c += u).  PCG accumulates into c, so the
+        // correction is recovered as c after - c before.  No feedback problem here (PCG damps whatever the guess carries); the
+        // learning steps' solves start from zero (their Lanczos coefficients are to describe the right-hand side itself).
+        const bool second_pcg = it == 1 && !cheb_learning && (o.flags & GLIMS_FLAG_WARM_START) && !extrapolate;
+        if (second_pcg) {
+          h->cheb_delta2.alloc((size_t)h->n_nodes);
+          const int regime_pcg = regime_now + 500;
+          if (h->have_d2 && (regime_pcg != h->d2_regime || !(nr > 0.7 * h->d2_r1 && nr < 1.43 * h->d2_r1))) h->have_d2 = false;
+          if (!h->have_d2) h->d2_depth = 0;
+          const bool warm2 = GL_D2_ORDER >= 1 && h->have_d2;
+          if (warm2) {
+            h->d2_prev.alloc((size_t)h->n_nodes);
+            hipLaunchKernelGGL(k_d2_guess, dim3(grid_exact(n)), dim3(256), 0, h->st, n, (const double*)h->cheb_delta2.p,
+                               h->d2_prev.p, h->cg_u.p, (h->d2_depth >= 2 && GL_D2_ORDER >= 2) ? 1 : 0);
+            if (h->world > 1) gl_halo_exchange(h, h->cg_u.p, 1);
+          }
+          GL_HIP(hipMemcpyAsync(h->cheb_delta2.p, h->c.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->st));
+          if (warm2) {
+            gl_launch_spmv(h, h->st, p.n_slices, nullptr, h->vA.p, h->cg_u.p, h->cg_w.p,
+                           h->have_fixed_c ? h->fixed_c.p : nullptr, nullptr, nullptr, nullptr, 0, nullptr,
+                           h->jac32 ? h->vA32.p : nullptr);
+            hipLaunchKernelGGL(k_ws_apply, dim3(grid_exact(n)), dim3(256), 0, h->st, n, h->cg_r.p, h->cg_w.p, h->c.p,
+                               h->cg_u.p);
+            GL_HIP(hipGetLastError());
+          }
+          d2_written = true;
+          d2_pcg = true;
+          r1_now = nr;
+          used_warm2 = warm2;
+        }
         cs = cg_solve(h, v, tol_lin, o.cg_maxit, h->cg_hint[slot], &its, &res, /*defer=*/!cheb_learning);
+        if (second_pcg) {
+          hipLaunchKernelGGL(k_d2_from_state, dim3(grid_exact(n)), dim3(256), 0, h->st, n, (const double*)h->c.p,
+                             h->cheb_delta2.p);
+          GL_HIP(hipGetLastError());
+        }
         deferred = its < 0;
         if (!deferred) {
           h->cg_hint[slot] = (int)its;
@@ -1981,7 +2023,7 @@ int gl_step(glims_ctx* h, int n_steps) {
       // likely the guess's doing (components that the previous steps' solves amplified instead of damping come back with it) than
       // the quadratic remainder -- the third solve runs PCG, and the guess stays unused for a while (the solves from zero in
       // between start clean): 8 steps, doubling with every miss.
-      if (use_cheb && it == 1 && used_warm2 && std::isfinite(nr)) {
+      if (it == 1 && used_warm2 && std::isfinite(nr)) {
         if (nr > target) {
           pcg_rest = true;
           d2_written = false;
@@ -2040,7 +2082,7 @@ int gl_step(glims_ctx* h, int n_steps) {
     ++h->nw_steps;
     h->have_d2 = d2_written && status == GLIMS_OK;
     if (h->have_d2) {
-      h->d2_regime = regime_now;
+      h->d2_regime = regime_now + (d2_pcg ? 500 : 0);
       h->d2_r1 = r1_now;
     }
     h->d2_depth = h->have_d2 ? std::min(2, h->d2_depth + 1) : 0;
