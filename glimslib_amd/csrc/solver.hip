@@ -1836,7 +1836,7 @@ int gl_step(glims_ctx* h, int n_steps) {
       }
       int64_t its = 0;
       double res = 0.0;
-      const int slot = std::min(it, 7);
+      int slot = std::min(it, 6);   // (slot 7: second solves that start from the guess -- their counts say nothing about the ones from zero)
       int cs = GLIMS_OK;
       bool deferred = false;
       ChebRun crun;
@@ -1924,6 +1924,7 @@ int gl_step(glims_ctx* h, int n_steps) {
           d2_pcg = true;
           r1_now = nr;
           used_warm2 = warm2;
+          if (warm2) slot = 7;
         }
         cs = cg_solve(h, v, tol_lin, o.cg_maxit, h->cg_hint[slot], &its, &res, /*defer=*/!cheb_learning);
         if (second_pcg) {
