@@ -506,6 +506,26 @@ __global__ void k_d2_guess(int64_t n, const double* __restrict__ d, double* __re
   u[i] = second_order ? 2.0 * a - d_prev[i] : a;
   d_prev[i] = a;
 }
+// Is a guess u better than none?  Partial sums of |r - A u|^2 and |r|^2 (w = A u), grid-stride, two per block.
+__global__ __launch_bounds__(256) void k_guess_norms(int64_t n, const double* __restrict__ r, const double* __restrict__ w,
+                                                      double* __restrict__ pv) {
+  double a = 0.0, b = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double ri = r[i], t = ri - w[i];
+    a += t * t;
+    b += ri * ri;
+  }
+  block_sum2(a, b, pv);
+}
+// r -= A u (w = A u), c += u -- if the guess brings the residual down to a fifth (red = global sums of k_guess_norms), else nothing
+__global__ void k_ws_apply_if(int64_t n, double* __restrict__ r, const double* __restrict__ w, double* __restrict__ c,
+                              const double* __restrict__ u, const double* __restrict__ red) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !(red[0] < 0.04 * red[1])) return;   // (|r - A u| < 0.2 |r|: less than that is gone after PCG's first iterations anyway)
+  r[i] -= w[i];
+  c[i] += u[i];
+}
 // d = c - d (d held the state before a solve: now the correction the solve added)
 __global__ void k_d2_from_state(int64_t n, const double* __restrict__ c, double* __restrict__ d) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1916,15 +1936,26 @@ int gl_step(glims_ctx* h, int n_steps) {
             gl_launch_spmv(h, h->st, p.n_slices, nullptr, h->vA.p, h->cg_u.p, h->cg_w.p,
                            h->have_fixed_c ? h->fixed_c.p : nullptr, nullptr, nullptr, nullptr, 0, nullptr,
                            h->jac32 ? h->vA32.p : nullptr);
-            hipLaunchKernelGGL(k_ws_apply, dim3(grid_exact(n)), dim3(256), 0, h->st, n, h->cg_r.p, h->cg_w.p, h->c.p,
-                               h->cg_u.p);
+            // (applied only if it lowers the residual -- decided on the device from two sums: on stiff steps, where the solution
+            //  does not evolve smoothly from step to step, the extrapolated correction can be worse than none; 5.3 -> 5.6
+            //  V-cycle-preconditioned iterations per solve at 1 M rows with the guess always applied)
+            const unsigned gg = grid_for(n, 256, 1024);
+            hipLaunchKernelGGL(k_guess_norms, dim3(gg), dim3(256), 0, h->st, n, (const double*)h->cg_r.p, (const double*)h->cg_w.p,
+                               h->partials.p);
+            reduce_partials(h, (int)gg, 2, nullptr);
+            allreduce_sum(h, h->red.p, 2);
+            hipLaunchKernelGGL(k_ws_apply_if, dim3(grid_exact(n)), dim3(256), 0, h->st, n, h->cg_r.p, (const double*)h->cg_w.p,
+                               h->c.p, (const double*)h->cg_u.p, (const double*)h->red.p);
             GL_HIP(hipGetLastError());
           }
           d2_written = true;
           d2_pcg = true;
           r1_now = nr;
           used_warm2 = warm2;
-          if (warm2) slot = 7;
+          if (warm2) {
+            slot = 7;
+            if (h->cg_hint[7] <= 0) h->cg_hint[7] = h->cg_hint[1];   // (a first count to bound the launches: the solve from zero's)
+          }
         }
         cs = cg_solve(h, v, tol_lin, o.cg_maxit, h->cg_hint[slot], &its, &res, /*defer=*/!cheb_learning);
         if (second_pcg) {
