@@ -131,3 +131,28 @@ def test_stream_policy_and_explicit_chebyshev_do_not_change_the_bits(backend):
         assert st1[k] == st2[k], k
     assert st1['krylov_working_set'] > 0
     assert np.array_equal(c1, c3) or rel_l2(c1, c3) < 1e-10
+
+
+def test_guesses_of_both_solves_change_the_counts_not_the_fields(backend):
+    """Both linear solves of a step start from a guess (GLIMS_FLAG_WARM_START, default): the first from the extrapolated increment,
+    the second from the extrapolated second correction of the two steps before (solver.hip: k_d2_guess; on the PCG path applied only
+    if it brings the residual down to a fifth).  Reduced C3, 40 steps, on the dot-free path and on the PCG path, each against the
+    same run without guesses: the same fields (the Newton tolerance decides what a step returns, not where its solves start),
+    fewer Krylov passes, no more Newton iterations than a few."""
+    w = _c3_reduced(32)
+    out = {}
+    for name, opts in (("dot-free", {}), ("pcg", dict(rd_linear=backend.RD_LINEAR_PCG))):
+        s_w, c_w, st_w = _run(backend, w, 40, **opts)
+        h = backend.Handle(w.mesh.points, w.mesh.cells, w.cell_label)
+        flags = h.options.flags & ~backend.FLAG_WARM_START   # (the library's defaults, minus the guesses)
+        h.close()
+        s_c, c_c, st_c = _run(backend, w, 40, flags=flags, **opts)
+        assert s_w == 0 and s_c == 0
+        print("%s: with guesses Newton %d, Krylov passes %d (take-backs %d) | without Newton %d, passes %d | fields %.1e apart" %
+              (name, st_w['newton_its'], st_w['cg_its'], st_w['cheb_fallbacks'], st_c['newton_its'], st_c['cg_its'],
+               rel_l2(c_w, c_c)))
+        assert rel_l2(c_w, c_c) < 1e-9
+        assert st_w['cg_its'] < 0.9 * st_c['cg_its']
+        assert st_w['newton_its'] <= st_c['newton_its'] + 4
+        out[name] = c_w
+    assert rel_l2(out["dot-free"], out["pcg"]) < 1e-9
