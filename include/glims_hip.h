@@ -197,7 +197,10 @@ typedef struct glims_options {
                                            diagonals (the edge's term taken out whole: positive semi-definite, row sums kept) --
                                            sliver meshes 51 / 45 / 35 -> 48 / 39 / 32 iterations; lattices and quality-controlled
                                            meshes have no such edges and are not affected (rebuilds the hierarchies) */
-#define GLIMS_FLAG_WARM_START 2         /* first linear solve of a step starts from the increment extrapolated from the previous two steps'
+#define GLIMS_FLAG_WARM_START 2         /* first linear solve of a step starts from the increment extrapolated from the previous two steps',
+                                           its second solve from the second correction extrapolated likewise (round 5; only where the
+                                           previous steps' continue each other); iteration counts change, what a
+                                           step returns does not -- the Newton tolerance decides that
                                            (ignored when GLIMS_FLAG_EXTRAPOLATE_GUESS is set) */
 
 typedef struct glims_stats {
